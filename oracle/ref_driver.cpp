@@ -1,0 +1,123 @@
+// ref_driver.cpp -- TEST INFRASTRUCTURE.  A thin command-line driver around the REAL
+// reference objects that compile from their own sources (common.cpp, shuffle.cpp,
+// dist.cpp under /root/reference/src; see oracle/Makefile target `ref`).  It contains no
+// reference code: it only calls the reference's public functions
+//   initParameter        (src/common.h:48)
+//   write_shuffle_dim_file (src/shuffle.h:28)
+//   index_tridist / index_dist / tri_dist (src/dist.h:35-38)
+// so that the C restatement in kssd_oracle.c can be validated against them and golden
+// fixtures can be generated (tests/golden/make_golden.py).
+//
+// sketch.cpp (sketchFastaFile/transSketches/readSketches) needs the un-vendored RabbitFX
+// submodule and is NOT built; .sketch/.dict/.index inputs are produced by the oracle.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unistd.h>
+#include <vector>
+
+#include "common.h"
+#include "dist.h"
+#include "shuffle.h"
+#include "sketch.h"
+
+#include "kssd_oracle.h"
+
+static void load_sketches(const char *path, std::vector<sketch_t> &out, sketchInfo_t &info)
+{
+    ok_sketch_info_t oi;
+    char *names = nullptr;
+    uint32_t *hashes = nullptr;
+    uint64_t *off = nullptr;
+    int rc = ok_read_sketches32(path, &oi, &names, &hashes, &off);
+    if (rc) {
+        fprintf(stderr, "ref_driver: cannot read %s (%d)\n", path, rc);
+        exit(2);
+    }
+    info.id = oi.id;
+    info.half_k = oi.half_k;
+    info.half_subk = oi.half_subk;
+    info.drlevel = oi.drlevel;
+    info.genomeNumber = oi.genomeNumber;
+    const char *p = names;
+    for (int i = 0; i < oi.genomeNumber; i++) {
+        sketch_t s;
+        s.fileName = p;
+        p += strlen(p) + 1;
+        s.id = i;
+        s.hashSet.assign(hashes + off[i], hashes + off[i + 1]);
+        out.push_back(s);
+    }
+    free(names);
+    free(hashes);
+    free(off);
+}
+
+static int usage()
+{
+    fprintf(stderr,
+            "usage:\n"
+            "  ref_driver param K S L\n"
+            "  ref_driver shuffle K S L out.shuf\n"
+            "  ref_driver alldist WORKDIR in.sketch OUT maxDist isContainment threads\n"
+            "  ref_driver tridist WORKDIR in.sketch OUT maxDist threads\n"
+            "  ref_driver dist WORKDIR ref.sketch qry.sketch OUT maxDist maxNeighbor isNeighbor "
+            "isContainment threads\n"
+            "(sketch paths absolute; OUT is a bare file name created inside WORKDIR;\n"
+            " <in.sketch>.dict/.index must already exist)\n");
+    return 2;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return usage();
+    std::string cmd = argv[1];
+    if (cmd == "param" && argc == 5) {
+        int k = atoi(argv[2]), s = atoi(argv[3]), l = atoi(argv[4]);
+        kssd_parameter_t p = initParameter(k, s, l, nullptr);
+        printf("%d %d %d %d %d %d %d %u %lx %lx %lx %lx\n", p.half_k, p.half_subk, p.drlevel,
+               p.rev_add_move, p.half_outctx_len, p.dim_start, p.dim_end, p.kmer_size,
+               (unsigned long)p.domask, (unsigned long)p.tupmask, (unsigned long)p.undomask0,
+               (unsigned long)p.undomask1);
+        return 0;
+    }
+    if (cmd == "shuffle" && argc == 6) {
+        dim_shuffle_stat_t st;
+        st.k = atoi(argv[2]);
+        st.subk = atoi(argv[3]);
+        st.drlevel = atoi(argv[4]);
+        st.id = 0;
+        write_shuffle_dim_file(&st, argv[5]);
+        return 0;
+    }
+    if (cmd == "alldist" && argc == 8) {
+        if (chdir(argv[2])) return 3;
+        std::vector<sketch_t> sk;
+        sketchInfo_t info;
+        load_sketches(argv[3], sk, info);
+        index_tridist(sk, info, argv[3], argv[4], 2 * info.half_k, atof(argv[5]), atoi(argv[6]),
+                      atoi(argv[7]));
+        return 0;
+    }
+    if (cmd == "tridist" && argc == 7) {
+        if (chdir(argv[2])) return 3;
+        std::vector<sketch_t> sk;
+        sketchInfo_t info;
+        load_sketches(argv[3], sk, info);
+        tri_dist(sk, argv[4], 2 * info.half_k, atof(argv[5]), atoi(argv[6]));
+        return 0;
+    }
+    if (cmd == "dist" && argc == 11) {
+        if (chdir(argv[2])) return 3;
+        std::vector<sketch_t> rs, qs;
+        sketchInfo_t ri, qi;
+        load_sketches(argv[3], rs, ri);
+        load_sketches(argv[4], qs, qi);
+        index_dist(rs, ri, argv[3], qs, argv[5], 2 * ri.half_k, atof(argv[6]),
+                   strtoull(argv[7], nullptr, 10), atoi(argv[8]) != 0, atoi(argv[9]),
+                   atoi(argv[10]));
+        return 0;
+    }
+    return usage();
+}
