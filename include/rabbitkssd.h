@@ -1,0 +1,208 @@
+/*
+ * rabbitkssd.h -- C ABI of the MI355X-native sketch + distance engine (librabbitkssd.so).
+ *
+ * Drop-in boundary for RabbitKSSD's hot path.  The reference has no FFI of its own; the
+ * seams this ABI replaces are four C++ free functions and the arithmetic inside them
+ * (citations are file:line into the reference tree):
+ *
+ *   rk_params_init         <- initParameter             src/common.cpp:35-78
+ *   rk_filter_create       <- shuffled_map construction  src/sketch.cpp:336-345
+ *   rk_sketch_batch        <- per-genome loop of sketchFastaFile
+ *                                                        src/sketch.cpp:455-566 (and :173-238)
+ *   rk_index_build         <- transSketches (32-bit)     src/sketch.cpp:970-1017
+ *   rk_index_import/export <- .dict/.index load/store    src/dist.cpp:86-129, src/sketch.cpp:991-1011
+ *   rk_dist_rows           <- row loop of index_tridist  src/dist.cpp:174-258
+ *                             row loop of index_dist     src/dist.cpp:560-692 (without -N)
+ *   rk_topn_rows           <- -N max-heap of index_dist  src/dist.cpp:599,625-640,683-689
+ *
+ * Conventions
+ *   - plain C types only; every call returns 0 on success or a negative rk_status and
+ *     never calls exit(); rk_last_error(ctx) returns a message for the last failure on
+ *     that context.
+ *   - pointers are HOST pointers unless the parameter name ends in _dev.
+ *   - objects (rk_filter, rk_sketches, rk_index) are library-owned, device-resident and
+ *     freed with their *_free function; buffers the caller receives from the library are
+ *     released with rk_free_host.  Nothing crosses allocators.
+ *   - calls without a `stream` argument are synchronous at return.  *_dev calls are
+ *     asynchronous on the given HIP stream (void* == hipStream_t, NULL = default stream).
+ *   - one context per (process, GPU); one host thread per context.
+ *   - the engine has NO CPU fallback: creating a context without a usable GPU fails
+ *     with RK_ERR_NO_DEVICE.
+ */
+#ifndef RABBITKSSD_H
+#define RABBITKSSD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rk_status {
+    RK_OK = 0,
+    RK_ERR_ARG = -1,        /* invalid argument (incl. the reference's parameter checks) */
+    RK_ERR_NO_DEVICE = -2,  /* no HIP device / device ordinal out of range              */
+    RK_ERR_HIP = -3,        /* a HIP runtime call failed                                */
+    RK_ERR_NOMEM = -4,      /* host or device allocation failed                         */
+    RK_ERR_CAPACITY = -5,   /* caller-provided output buffer too small                  */
+    RK_ERR_UNSUPPORTED = -6 /* e.g. 64-bit hash layout (half_k - drlevel > 8)           */
+} rk_status;
+
+typedef struct rk_ctx rk_ctx;
+typedef struct rk_filter rk_filter;
+typedef struct rk_sketches rk_sketches;
+typedef struct rk_index rk_index;
+
+/* kssd_parameter_t (src/common.h:8-25), the fields the hot path reads. */
+typedef struct rk_params {
+    int32_t half_k, half_subk, drlevel;
+    int32_t rev_add_move, half_outctx_len;
+    int32_t dim_start, dim_end;
+    uint32_t kmer_size;
+    uint64_t domask, tupmask, undomask0, undomask1;
+} rk_params;
+
+/* One reported pair.  alldist (triangle=1): row=i, col=j>i, size0=|S_i|, size1=|S_j|
+ * (src/dist.cpp:207-217); dist (triangle=0): row=query, col=ref, size0=|ref|,
+ * size1=|query| (src/dist.cpp:600-609). */
+typedef struct rk_hit {
+    uint32_t row, col;
+    int32_t common, size0, size1, pad_;
+    double jorc; /* jaccard (metric 0) or containment (metric 1) */
+    double dist; /* mashD   (metric 0) or AafD        (metric 1) */
+} rk_hit;
+
+/* ---- context ------------------------------------------------------------------- */
+int rk_device_count(void);
+int rk_ctx_create(int device, rk_ctx **out);
+void rk_ctx_destroy(rk_ctx *ctx);
+const char *rk_last_error(const rk_ctx *ctx);
+const char *rk_version(void);
+void rk_free_host(void *p);
+
+/* ---- parameters (host arithmetic only) -------------------------------------------- */
+/* RK_ERR_ARG when half_subk - drlevel < 3 (src/common.cpp:37), half_k < half_subk or
+ * half_subk >= 8 (src/shuffle.cpp:26,30), half_k > 16. */
+int rk_params_init(int half_k, int half_subk, int drlevel, rk_params *out);
+/* number of hash bits = 4*(half_k-drlevel); >32 means the 64-bit layout (use64) */
+int rk_hash_bits(const rk_params *p);
+
+/* ---- sketching ---------------------------------------------------------------- */
+/* Uploads the .shuf table (int32[16^half_subk], src/shuffle.cpp:8-23) and builds the
+ * on-chip pre-filter for entries < dim_end. */
+int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_dim,
+                     rk_filter **out);
+void rk_filter_free(rk_filter *f);
+
+/* Sketches n_genomes genomes.  seq holds the sequence bytes of all records back to
+ * back (newlines already removed, kseq semantics); rec_off[n_rec+1] delimits records
+ * (windows never span records, src/sketch.cpp:487-488); genome_rec[n_genomes+1] gives
+ * each genome's record range.  Result: per-genome SORTED UNIQUE 32-bit hashes. */
+int rk_sketch_batch(rk_ctx *ctx, const rk_filter *f, const uint8_t *seq, const uint64_t *rec_off,
+                    uint64_t n_rec, const uint64_t *genome_rec, uint32_t n_genomes,
+                    rk_sketches **out);
+
+/* Same, inputs already packed and resident in HBM: packed_dev holds each genome at
+ * gbeg[g] (a multiple of 1024) .. gend[g]; records of a genome are separated by one
+ * 0x00 byte and the gap up to the next multiple of 1024 is zero-filled (see
+ * rk_pack_layout / rk_pack_genomes).  gbeg/gend are host arrays.  All device work is
+ * enqueued on `stream`; the call synchronises that stream before returning (it needs the
+ * candidate and hash counts on the host). */
+int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_dev,
+                         uint64_t packed_bytes, const uint64_t *gbeg, const uint64_t *gend,
+                         uint32_t n_genomes, void *stream, rk_sketches **out);
+/* host helpers for the packed layout: sizes first, then fill a caller buffer */
+int rk_pack_layout(const uint64_t *rec_off, uint64_t n_rec, const uint64_t *genome_rec,
+                   uint32_t n_genomes, uint64_t *gbeg, uint64_t *gend, uint64_t *packed_bytes);
+int rk_pack_genomes(const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
+                    const uint64_t *genome_rec, uint32_t n_genomes, const uint64_t *gbeg,
+                    uint8_t *packed, uint64_t packed_bytes);
+
+/* device-resident CSR of sketches */
+int rk_sketches_from_host(rk_ctx *ctx, const uint32_t *hashes, const uint64_t *off,
+                          uint32_t n_genomes, rk_sketches **out);
+/* same from device-resident arrays (copied device-to-device into a library-owned object) */
+int rk_sketches_from_dev(rk_ctx *ctx, const uint32_t *hashes_dev, const uint64_t *off_dev,
+                         uint32_t n_genomes, rk_sketches **out);
+uint32_t rk_sketches_count(const rk_sketches *s);
+uint64_t rk_sketches_total(const rk_sketches *s);
+/* number of k-mer windows seen by the last sketch call that produced s (0 if imported) */
+uint64_t rk_sketches_windows(const rk_sketches *s);
+/* copies off[n+1] and hashes[total] to caller buffers (either may be NULL) */
+int rk_sketches_download(const rk_sketches *s, uint32_t *hashes, uint64_t *off);
+const uint32_t *rk_sketches_hashes_dev(const rk_sketches *s);
+const uint64_t *rk_sketches_off_dev(const rk_sketches *s);
+void rk_sketches_free(rk_sketches *s);
+
+/* ---- inverted index ------------------------------------------------------------- */
+/* Builds the reference index from device-resident sketches: postings ordered
+ * (hash asc, genome asc) exactly like the .dict file, a compact CSR over the distinct
+ * hashes, and the per-hash "later genomes" ranges used by the all-vs-all triangle. */
+int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **out);
+/* From the on-disk pair: postings = .dict payload (u32[total]), counts = the dense
+ * u32[2^hash_bits] array of the .index file, ref_sizes = sketch sizes of the
+ * reference genomes (from the .sketch).  Replaces the load + prefix sum of
+ * src/dist.cpp:86-129. */
+int rk_index_import(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const uint32_t *counts,
+                    int hash_bits, const uint32_t *ref_sizes, uint32_t n_ref, rk_index **out);
+/* To the on-disk pair: postings[total] and (optional) dense counts[2^hash_bits]. */
+int rk_index_export(const rk_index *idx, uint32_t *postings, uint32_t *counts);
+uint64_t rk_index_total(const rk_index *idx);    /* H = number of postings        */
+uint64_t rk_index_distinct(const rk_index *idx); /* U = number of distinct hashes */
+uint32_t rk_index_genomes(const rk_index *idx);
+int rk_index_hash_bits(const rk_index *idx);
+/* sum over all reference hashes h of c_h^2 = postings streamed by a full alldist
+ * (the T of the roofline formula) */
+uint64_t rk_index_sum_sq(const rk_index *idx);
+/* Multi-GPU: the whole index as ONE contiguous device blob, so that the owner can hand it
+ * to an RCCL broadcast (one collective, no reduction: query rows are independent) and every
+ * peer rebuilds an identical rk_index from the received bytes.  pack/unpack only enqueue
+ * device-to-device copies on `stream` and synchronise it before returning. */
+uint64_t rk_index_blob_bytes(const rk_index *idx);
+int rk_index_pack_dev(const rk_index *idx, void *blob_dev, uint64_t blob_cap, void *stream);
+int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, void *stream,
+                        rk_index **out);
+void rk_index_free(rk_index *idx);
+
+/* ---- distances ------------------------------------------------------------------- */
+typedef struct rk_dist_opts {
+    int32_t triangle;   /* 1: alldist (queries ARE the indexed sketches, cols j>i, keep
+                              dist <  max_dist, src/dist.cpp:207,232)
+                           0: dist (all cols, keep dist <= max_dist, src/dist.cpp:600,624) */
+    int32_t metric;     /* 0 jaccard->mashD, 1 containment->AafD (-M)                  */
+    int32_t kmer_size;  /* 2*half_k                                                    */
+    int32_t reserved_;
+    double max_dist;    /* -D                                                          */
+    uint32_t row_first; /* rows row_first, row_first+row_step, ... (< n_query):        */
+    uint32_t row_step;  /*   interleaved row sharding across GPUs; 0,1 = all rows      */
+} rk_dist_opts;
+
+/* Counts |S_q n S_r| through the inverted index and applies the reference's epilogue.
+ * queries == NULL is only valid with triangle=1 (the indexed sketches are the queries).
+ * hits_out is library-allocated (rk_free_host), sorted by (row, col).
+ * common_dense (optional, host, n_query*n_ref int32, row-major) receives the full
+ * counter rows of the selected rows (other rows untouched) -- used by parity tests. */
+int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
+                 const rk_dist_opts *opts, rk_hit **hits_out, uint64_t *n_hits,
+                 int32_t *common_dense);
+
+/* Asynchronous all-in-HBM variant: hits are appended (unordered) to hits_dev
+ * (capacity hits_cap records); *n_hits_dev (uint64, zeroed by the caller) counts every
+ * hit, including those beyond the capacity, so an overflow is detectable. */
+int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
+                     const rk_dist_opts *opts, rk_hit *hits_dev, uint64_t hits_cap,
+                     uint64_t *n_hits_dev, void *stream);
+
+/* -N: keeps, per query row, the max_neighbor nearest hits with the reference's heap
+ * order (emitted largest distance first).  hits must be sorted by (row, col); the
+ * result is written in place and its length returned through n_hits. */
+int rk_topn_rows(rk_hit *hits, uint64_t *n_hits, uint64_t max_neighbor);
+
+/* one output line, "%s\t%s\t%d|%d|%d\t%f\t%f\n" (src/dist.cpp:233 / :642) */
+int rk_format_hit(char *buf, size_t cap, const char *name_a, const char *name_b,
+                  const rk_hit *hit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RABBITKSSD_H */

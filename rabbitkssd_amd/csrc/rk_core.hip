@@ -1,0 +1,178 @@
+// rk_core.hip -- context, parameters and host-side helpers of the C ABI.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "rk_internal.h"
+
+int rk_fail(rk_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+extern "C" {
+
+const char *rk_version(void) { return "rabbitkssd-amd 0.1.0 (gfx950)"; }
+
+int rk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rk_ctx_create(int device, rk_ctx **out)
+{
+    if (!out) return RK_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RK_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return RK_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RK_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RK_ERR_HIP;
+    rk_ctx *ctx = new (std::nothrow) rk_ctx;
+    if (!ctx) return RK_ERR_NOMEM;
+    ctx->device = device;
+    ctx->num_cu = prop.multiProcessorCount;
+    ctx->max_lds = prop.sharedMemPerBlock;  // 64 KiB by default; larger via opt-in attribute
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess &&
+        (size_t)optin > ctx->max_lds)
+        ctx->max_lds = (size_t)optin;
+    *out = ctx;
+    return RK_OK;
+}
+
+void rk_ctx_destroy(rk_ctx *ctx) { delete ctx; }
+
+const char *rk_last_error(const rk_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+void rk_free_host(void *p) { free(p); }
+
+// src/common.cpp:35-78 (initParameter); argument checks of src/shuffle.cpp:26,30 folded in.
+int rk_params_init(int half_k, int half_subk, int drlevel, rk_params *p)
+{
+    if (!p) return RK_ERR_ARG;
+    if (half_subk - drlevel < 3) return RK_ERR_ARG;  // src/common.cpp:37
+    if (half_k < half_subk || half_subk >= 8 || half_subk < 1) return RK_ERR_ARG;
+    if (half_k > 16 || drlevel < 0) return RK_ERR_ARG;
+    memset(p, 0, sizeof(*p));
+    const int out = half_k - half_subk;
+    p->half_k = half_k;
+    p->half_subk = half_subk;
+    p->drlevel = drlevel;
+    p->half_outctx_len = out;
+    p->rev_add_move = 4 * half_k - 2;
+    p->kmer_size = 2u * (uint32_t)half_k;
+    p->dim_start = 0;
+    p->dim_end = 1 << (4 * (half_subk - drlevel));
+    const uint64_t tupmask = ~0ULL >> (64 - 4 * half_k);
+    const uint64_t domask = (tupmask >> (4 * out)) << (2 * out);
+    const uint64_t undomask = (tupmask ^ domask) & tupmask;
+    const uint64_t undomask1 = undomask & (tupmask >> ((half_k + half_subk) * 2));
+    p->tupmask = tupmask;
+    p->domask = domask;
+    p->undomask1 = undomask1;
+    p->undomask0 = undomask ^ undomask1;
+    return RK_OK;
+}
+
+int rk_hash_bits(const rk_params *p) { return p ? 4 * (p->half_k - p->drlevel) : 0; }
+
+// ---- packed layout for the sketch kernel --------------------------------------------
+// genome g occupies [gbeg[g], gend[g]) of the packed buffer, gbeg a multiple of 1024;
+// its records are separated by one 0x00 byte; the gap to the next genome is zero-filled.
+int rk_pack_layout(const uint64_t *rec_off, uint64_t n_rec, const uint64_t *genome_rec,
+                   uint32_t n_genomes, uint64_t *gbeg, uint64_t *gend, uint64_t *packed_bytes)
+{
+    if (!rec_off || !genome_rec || !gbeg || !gend || !packed_bytes) return RK_ERR_ARG;
+    uint64_t pos = 0;
+    for (uint32_t g = 0; g < n_genomes; g++) {
+        const uint64_t r0 = genome_rec[g], r1 = genome_rec[g + 1];
+        if (r1 < r0 || r1 > n_rec) return RK_ERR_ARG;
+        uint64_t len = rec_off[r1] - rec_off[r0];
+        if (r1 > r0) len += (r1 - r0 - 1);  // separators
+        gbeg[g] = pos;
+        gend[g] = pos + len;
+        pos = (pos + len + 1023) & ~1023ULL;
+        if (len == 0) pos += 0;
+    }
+    *packed_bytes = pos ? pos : 1024;
+    return RK_OK;
+}
+
+int rk_pack_genomes(const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
+                    const uint64_t *genome_rec, uint32_t n_genomes, const uint64_t *gbeg,
+                    uint8_t *packed, uint64_t packed_bytes)
+{
+    if (!seq || !rec_off || !genome_rec || !gbeg || !packed) return RK_ERR_ARG;
+    memset(packed, 0, packed_bytes);
+    for (uint32_t g = 0; g < n_genomes; g++) {
+        uint64_t pos = gbeg[g];
+        for (uint64_t r = genome_rec[g]; r < genome_rec[g + 1]; r++) {
+            if (r >= n_rec) return RK_ERR_ARG;
+            const uint64_t len = rec_off[r + 1] - rec_off[r];
+            if (pos + len > packed_bytes) return RK_ERR_CAPACITY;
+            memcpy(packed + pos, seq + rec_off[r], len);
+            pos += len + 1;  // leaves one 0x00 separator
+        }
+    }
+    return RK_OK;
+}
+
+// ---- -N nearest neighbours -----------------------------------------------------------
+// std::priority_queue<DistInfo, vector<DistInfo>, cmpDistInfo> (src/dist.h:19-32) as used
+// at src/dist.cpp:599,625-640,683-689.  The heap is kept with the same libstdc++
+// primitives the reference gets from <queue>, so ties are broken identically.
+struct HitLess {
+    bool operator()(const rk_hit &a, const rk_hit &b) const { return a.dist < b.dist; }
+};
+
+int rk_topn_rows(rk_hit *hits, uint64_t *n_hits, uint64_t max_neighbor)
+{
+    if (!hits || !n_hits) return RK_ERR_ARG;
+    const uint64_t n = *n_hits;
+    std::vector<rk_hit> heap;
+    uint64_t w = 0, i = 0;
+    HitLess less;
+    while (i < n) {
+        const uint32_t row = hits[i].row;
+        heap.clear();
+        uint64_t j = i;
+        for (; j < n && hits[j].row == row; j++) {
+            if (heap.size() < max_neighbor) {
+                heap.push_back(hits[j]);
+                std::push_heap(heap.begin(), heap.end(), less);
+            } else if (!heap.empty() && hits[j].dist < heap.front().dist) {
+                heap.push_back(hits[j]);
+                std::push_heap(heap.begin(), heap.end(), less);
+                std::pop_heap(heap.begin(), heap.end(), less);
+                heap.pop_back();
+            }
+        }
+        while (!heap.empty()) {  // top() first: largest distance first
+            hits[w++] = heap.front();
+            std::pop_heap(heap.begin(), heap.end(), less);
+            heap.pop_back();
+        }
+        i = j;
+    }
+    *n_hits = w;
+    return RK_OK;
+}
+
+int rk_format_hit(char *buf, size_t cap, const char *name_a, const char *name_b, const rk_hit *h)
+{
+    if (!buf || !name_a || !name_b || !h) return RK_ERR_ARG;
+    return snprintf(buf, cap, "%s\t%s\t%d|%d|%d\t%f\t%f\n", name_a, name_b, h->common, h->size0,
+                    h->size1, h->jorc, h->dist);
+}
+
+}  // extern "C"

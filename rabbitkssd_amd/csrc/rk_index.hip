@@ -1,0 +1,496 @@
+// rk_index.hip -- device-side inverted index (replaces transSketches, src/sketch.cpp:970-1017,
+// and the .index load + prefix sum of src/dist.cpp:86-129).
+//
+// HBM layout of an index over N genomes, H postings, U distinct hashes:
+//   postings  u32[H]    genome ids ordered (hash asc, genome asc)      == the .dict payload
+//   uhash     u32[U]    sorted distinct hashes                         (compact, not 2^bits)
+//   upos      u32[U+1]  posting offsets of each distinct hash
+//   dir       u32[2^d+1] prefix directory: uhash index of the first hash >= b << shift
+//   sizes     u32[N]    sketch sizes
+//   selfrange uint2[H]  for source element e (genome g, hash h): the slice of h's posting
+//                       list holding genomes > g   (all-vs-all triangle needs no lookup)
+// The dense 2^bits count array of the .index file is only materialised by
+// rk_index_export / consumed by rk_index_import.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "rk_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
+
+__global__ void k_iota(uint32_t *v, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+
+__global__ void k_sizes(const uint64_t *off, uint32_t n, uint32_t *sizes)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) sizes[g] = (uint32_t)(off[g + 1] - off[g]);
+}
+
+__global__ void k_head_flags(const uint32_t *keys, uint64_t n, uint32_t *flags)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) flags[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1u : 0u;
+}
+
+// gidx = inclusive scan of head flags (1-based group number)
+__global__ void k_scatter_heads(const uint32_t *keys, const uint32_t *gidx, uint64_t n,
+                                uint32_t *uhash, uint32_t *upos, uint64_t U)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t g = gidx[k] - 1;
+    if (k == 0 || gidx[k - 1] != gidx[k]) {
+        uhash[g] = keys[k];
+        upos[g] = (uint32_t)k;
+    }
+    if (k == n - 1) upos[U] = (uint32_t)n;
+}
+
+// genome of source element e: largest g with off[g] <= e
+__device__ inline uint32_t genome_of(const uint64_t *off, uint32_t n, uint64_t e)
+{
+    uint32_t lo = 0, hi = n;  // invariant off[lo] <= e < off[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_postings_selfrange(const uint32_t *sorted_e, const uint32_t *gidx,
+                                     const uint32_t *upos, const uint64_t *off, uint32_t n_genomes,
+                                     uint64_t n, uint32_t *postings, uint2 *selfrange)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t e = sorted_e[k];
+    postings[k] = genome_of(off, n_genomes, e);
+    const uint32_t g = gidx[k] - 1;
+    // the sort is stable and source elements are genome-major, so positions k+1..end of
+    // the group hold strictly later genomes (a sketch is a set: no repeated hash inside it)
+    selfrange[e] = make_uint2((uint32_t)k + 1, upos[g + 1]);
+}
+
+__global__ void k_dir(const uint32_t *uhash, uint64_t U, int shift, uint32_t n_buckets,
+                      uint32_t *dir)
+{
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets) return;
+    if (b == n_buckets) { dir[b] = (uint32_t)U; return; }
+    const uint64_t key = (uint64_t)b << shift;
+    uint64_t lo = 0, hi = U;  // first index with uhash >= key
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)uhash[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    dir[b] = (uint32_t)lo;
+}
+
+__global__ void k_sum_sq(const uint32_t *upos, uint64_t U, unsigned long long *acc)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (i < U) {
+        unsigned long long c = upos[i + 1] - upos[i];
+        v = c * c;
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(acc, v);
+}
+
+// ---- import/export of the dense .index array --------------------------------------
+__global__ void k_nonzero_flags(const uint32_t *counts, uint64_t n, uint32_t *flags)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = counts[i] ? 1u : 0u;
+}
+
+// rank = exclusive scan of flags, cpos = exclusive scan of counts
+__global__ void k_compact_dense(const uint32_t *counts, const uint32_t *rank, const uint32_t *cpos,
+                                uint64_t n, uint32_t *uhash, uint32_t *upos)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && counts[i]) {
+        uhash[rank[i]] = (uint32_t)i;
+        upos[rank[i]] = cpos[i];
+    }
+}
+
+__global__ void k_scatter_counts(const uint32_t *uhash, const uint32_t *upos, uint64_t U,
+                                 uint32_t *counts)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < U) counts[uhash[i]] = upos[i + 1] - upos[i];
+}
+
+__global__ void k_resolve(const uint32_t *q, uint64_t n, const uint32_t *uhash,
+                          const uint32_t *upos, const uint32_t *dir, int dir_shift, int hash_bits,
+                          uint2 *ranges)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = q[i];
+    uint2 r = make_uint2(0, 0);
+    if (hash_bits >= 32 || (h >> hash_bits) == 0) {
+        const uint32_t b = h >> dir_shift;
+        uint32_t lo = dir[b], hi = dir[b + 1];
+        while (lo < hi) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (uhash[mid] < h) lo = mid + 1; else hi = mid;
+        }
+        if (lo < dir[b + 1] && uhash[lo] == h) r = make_uint2(upos[lo], upos[lo + 1]);
+    }
+    ranges[i] = r;
+}
+
+int finish_index(rk_ctx *ctx, rk_index *idx)
+{
+    // prefix directory + sum of squares; idx->d_uhash/d_upos/U/H/hash_bits are set
+    int dbits = 10;
+    while (dbits < 24 && (1ULL << dbits) < 2 * idx->U) dbits++;
+    if (dbits > idx->hash_bits) dbits = idx->hash_bits;
+    idx->dir_bits = dbits;
+    idx->dir_shift = idx->hash_bits - dbits;
+    const uint32_t nb = 1u << dbits;
+    DevBuf<uint32_t> dir;
+    RK_HIP(ctx, dir.alloc((size_t)nb + 1));
+    hipLaunchKernelGGL(k_dir, dim3(blocks_for((uint64_t)nb + 1)), dim3(kThreads), 0, 0, idx->d_uhash,
+                       idx->U, idx->dir_shift, nb, dir.p);
+    DevBuf<unsigned long long> acc;
+    RK_HIP(ctx, acc.alloc(1));
+    RK_HIP(ctx, hipMemset(acc.p, 0, 8));
+    if (idx->U)
+        hipLaunchKernelGGL(k_sum_sq, dim3(blocks_for(idx->U)), dim3(kThreads), 0, 0, idx->d_upos,
+                           idx->U, acc.p);
+    unsigned long long ss = 0;
+    RK_HIP(ctx, hipMemcpy(&ss, acc.p, 8, hipMemcpyDeviceToHost));
+    RK_HIP(ctx, hipGetLastError());
+    idx->sum_sq = ss;
+    idx->d_dir = dir.release();
+    return RK_OK;
+}
+
+}  // namespace
+
+int rk_resolve_ranges(rk_ctx *ctx, const rk_index *idx, const uint32_t *q_hashes_dev, uint64_t n,
+                      uint2 *ranges_dev, hipStream_t stream)
+{
+    if (!n) return RK_OK;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n)), dim3(kThreads), 0, stream, q_hashes_dev, n,
+                       idx->d_uhash, idx->d_upos, idx->d_dir, idx->dir_shift, idx->hash_bits,
+                       ranges_dev);
+    RK_HIP(ctx, hipGetLastError());
+    return RK_OK;
+}
+
+extern "C" {
+
+void rk_index_free(rk_index *idx)
+{
+    if (!idx) return;
+    (void)hipFree(idx->d_postings);
+    (void)hipFree(idx->d_uhash);
+    (void)hipFree(idx->d_upos);
+    (void)hipFree(idx->d_dir);
+    (void)hipFree(idx->d_sizes);
+    (void)hipFree(idx->d_selfrange);
+    (void)hipFree(idx->d_src_off);
+    delete idx;
+}
+
+uint64_t rk_index_total(const rk_index *idx) { return idx ? idx->H : 0; }
+uint64_t rk_index_distinct(const rk_index *idx) { return idx ? idx->U : 0; }
+uint32_t rk_index_genomes(const rk_index *idx) { return idx ? idx->n_ref : 0; }
+int rk_index_hash_bits(const rk_index *idx) { return idx ? idx->hash_bits : 0; }
+uint64_t rk_index_sum_sq(const rk_index *idx) { return idx ? idx->sum_sq : 0; }
+
+int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **out)
+{
+    if (!ctx || !s || !out) return RK_ERR_ARG;
+    *out = nullptr;
+    if (hash_bits < 1) return rk_fail(ctx, RK_ERR_ARG, "hash_bits must be positive");
+    if (hash_bits > 32)
+        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "64-bit hash layout (hash_bits=%d) not supported",
+                       hash_bits);
+    const uint64_t H = s->total;
+    if (H >= 0xFFFFFFFFULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "more than 2^32-1 postings");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    rk_index *idx = new (std::nothrow) rk_index;
+    if (!idx) return RK_ERR_NOMEM;
+    idx->ctx = ctx;
+    idx->n_ref = s->n;
+    idx->H = H;
+    idx->hash_bits = hash_bits;
+    struct Guard { rk_index *p; ~Guard() { if (p) rk_index_free(p); } } guard{idx};
+
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_sizes, ((size_t)s->n + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_src_off, ((size_t)s->n + 1) * 8));
+    RK_HIP(ctx, hipMemcpy(idx->d_src_off, s->d_off, ((size_t)s->n + 1) * 8, hipMemcpyDeviceToDevice));
+    if (s->n)
+        hipLaunchKernelGGL(k_sizes, dim3(blocks_for(s->n)), dim3(kThreads), 0, 0, s->d_off, s->n,
+                           idx->d_sizes);
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (H + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_selfrange, (H + 1) * sizeof(uint2)));
+
+    DevBuf<uint32_t> iota, keys_sorted, sorted_e, flags;
+    RK_HIP(ctx, iota.alloc(H));
+    RK_HIP(ctx, keys_sorted.alloc(H));
+    RK_HIP(ctx, sorted_e.alloc(H));
+    RK_HIP(ctx, flags.alloc(H));
+    if (H) {
+        hipLaunchKernelGGL(k_iota, dim3(blocks_for(H)), dim3(kThreads), 0, 0, iota.p, H);
+        // stable LSD radix sort by hash; values = source element index (genome-major), so
+        // equal hashes stay in ascending genome order == hashMapId[hash].push_back(i) for
+        // i ascending (src/sketch.cpp:979-985)
+        size_t tmp_bytes = 0;
+        RK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, s->d_hashes, keys_sorted.p, iota.p,
+                                              sorted_e.p, H, 0, (unsigned)hash_bits));
+        DevBuf<char> tmp;
+        RK_HIP(ctx, tmp.alloc(tmp_bytes));
+        RK_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, s->d_hashes, keys_sorted.p, iota.p,
+                                              sorted_e.p, H, 0, (unsigned)hash_bits));
+        hipLaunchKernelGGL(k_head_flags, dim3(blocks_for(H)), dim3(kThreads), 0, 0, keys_sorted.p, H,
+                           flags.p);
+        size_t tmp2 = 0;
+        RK_HIP(ctx, rocprim::inclusive_scan(nullptr, tmp2, flags.p, iota.p, H, rocprim::plus<uint32_t>()));
+        if (tmp2 > tmp_bytes) { RK_HIP(ctx, tmp.alloc(tmp2)); }
+        RK_HIP(ctx, rocprim::inclusive_scan(tmp.p, tmp2, flags.p, iota.p, H, rocprim::plus<uint32_t>()));
+        uint32_t U32 = 0;
+        RK_HIP(ctx, hipMemcpy(&U32, iota.p + (H - 1), 4, hipMemcpyDeviceToHost));
+        idx->U = U32;
+    }
+    uint32_t *gidx = iota.p;  // 1-based group number of each sorted position
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash, (idx->U + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_upos, (idx->U + 2) * 4));
+    if (H) {
+        hipLaunchKernelGGL(k_scatter_heads, dim3(blocks_for(H)), dim3(kThreads), 0, 0, keys_sorted.p,
+                           gidx, H, idx->d_uhash, idx->d_upos, idx->U);
+        hipLaunchKernelGGL(k_postings_selfrange, dim3(blocks_for(H)), dim3(kThreads), 0, 0, sorted_e.p,
+                           gidx, idx->d_upos, s->d_off, s->n, H, idx->d_postings, idx->d_selfrange);
+    } else {
+        RK_HIP(ctx, hipMemset(idx->d_upos, 0, 8));
+    }
+    RK_HIP(ctx, hipGetLastError());
+    int rc = finish_index(ctx, idx);
+    if (rc) return rc;
+    RK_HIP(ctx, hipDeviceSynchronize());
+    guard.p = nullptr;
+    *out = idx;
+    return RK_OK;
+}
+
+int rk_index_import(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const uint32_t *counts,
+                    int hash_bits, const uint32_t *ref_sizes, uint32_t n_ref, rk_index **out)
+{
+    if (!ctx || !out || !counts || (!postings && total) || (!ref_sizes && n_ref)) return RK_ERR_ARG;
+    *out = nullptr;
+    if (hash_bits < 1 || hash_bits > 32)
+        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "hash_bits=%d outside the 32-bit layout", hash_bits);
+    if (total >= 0xFFFFFFFFULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "more than 2^32-1 postings");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t hs = 1ULL << hash_bits;
+    rk_index *idx = new (std::nothrow) rk_index;
+    if (!idx) return RK_ERR_NOMEM;
+    idx->ctx = ctx;
+    idx->n_ref = n_ref;
+    idx->H = total;
+    idx->hash_bits = hash_bits;
+    struct Guard { rk_index *p; ~Guard() { if (p) rk_index_free(p); } } guard{idx};
+
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_sizes, ((size_t)n_ref + 1) * 4));
+    RK_HIP(ctx, hipMemcpy(idx->d_sizes, ref_sizes, (size_t)n_ref * 4, hipMemcpyHostToDevice));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (total + 1) * 4));
+    RK_HIP(ctx, hipMemcpy(idx->d_postings, postings, total * 4, hipMemcpyHostToDevice));
+
+    DevBuf<uint32_t> d_counts, flags, rank, cpos;
+    RK_HIP(ctx, d_counts.alloc(hs));
+    RK_HIP(ctx, flags.alloc(hs));
+    RK_HIP(ctx, rank.alloc(hs));
+    RK_HIP(ctx, cpos.alloc(hs));
+    RK_HIP(ctx, hipMemcpy(d_counts.p, counts, hs * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_nonzero_flags, dim3(blocks_for(hs)), dim3(kThreads), 0, 0, d_counts.p, hs,
+                       flags.p);
+    size_t tb = 0;
+    RK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, flags.p, rank.p, 0u, hs, rocprim::plus<uint32_t>()));
+    DevBuf<char> tmp;
+    RK_HIP(ctx, tmp.alloc(tb));
+    RK_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb, flags.p, rank.p, 0u, hs, rocprim::plus<uint32_t>()));
+    RK_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb, d_counts.p, cpos.p, 0u, hs, rocprim::plus<uint32_t>()));
+    uint32_t last_rank = 0, last_flag = 0, last_cpos = 0, last_cnt = 0;
+    RK_HIP(ctx, hipMemcpy(&last_rank, rank.p + (hs - 1), 4, hipMemcpyDeviceToHost));
+    RK_HIP(ctx, hipMemcpy(&last_flag, flags.p + (hs - 1), 4, hipMemcpyDeviceToHost));
+    RK_HIP(ctx, hipMemcpy(&last_cpos, cpos.p + (hs - 1), 4, hipMemcpyDeviceToHost));
+    RK_HIP(ctx, hipMemcpy(&last_cnt, d_counts.p + (hs - 1), 4, hipMemcpyDeviceToHost));
+    idx->U = (uint64_t)last_rank + last_flag;
+    if ((uint64_t)last_cpos + last_cnt != total)  // src/dist.cpp:107-110
+        return rk_fail(ctx, RK_ERR_ARG, "mismatched total hash number: index says %llu, dict has %llu",
+                       (unsigned long long)last_cpos + last_cnt, (unsigned long long)total);
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash, (idx->U + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_upos, (idx->U + 2) * 4));
+    hipLaunchKernelGGL(k_compact_dense, dim3(blocks_for(hs)), dim3(kThreads), 0, 0, d_counts.p,
+                       rank.p, cpos.p, hs, idx->d_uhash, idx->d_upos);
+    const uint32_t tot32 = (uint32_t)total;
+    RK_HIP(ctx, hipMemcpy(idx->d_upos + idx->U, &tot32, 4, hipMemcpyHostToDevice));
+    RK_HIP(ctx, hipGetLastError());
+    int rc = finish_index(ctx, idx);
+    if (rc) return rc;
+    RK_HIP(ctx, hipDeviceSynchronize());
+    guard.p = nullptr;
+    *out = idx;
+    return RK_OK;
+}
+
+int rk_index_export(const rk_index *idx, uint32_t *postings, uint32_t *counts)
+{
+    if (!idx) return RK_ERR_ARG;
+    rk_ctx *ctx = idx->ctx;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    if (postings && idx->H)
+        RK_HIP(ctx, hipMemcpy(postings, idx->d_postings, idx->H * 4, hipMemcpyDeviceToHost));
+    if (counts) {
+        const uint64_t hs = 1ULL << idx->hash_bits;
+        DevBuf<uint32_t> d_counts;
+        RK_HIP(ctx, d_counts.alloc(hs));
+        RK_HIP(ctx, hipMemset(d_counts.p, 0, hs * 4));
+        if (idx->U)
+            hipLaunchKernelGGL(k_scatter_counts, dim3(blocks_for(idx->U)), dim3(kThreads), 0, 0,
+                               idx->d_uhash, idx->d_upos, idx->U, d_counts.p);
+        RK_HIP(ctx, hipGetLastError());
+        RK_HIP(ctx, hipMemcpy(counts, d_counts.p, hs * 4, hipMemcpyDeviceToHost));
+    }
+    return RK_OK;
+}
+
+}  // extern "C"
+
+// ---- single-blob form for the RCCL broadcast ------------------------------------------
+namespace {
+struct BlobHeader {
+    uint64_t magic, bytes;
+    uint64_t H, U, sum_sq;
+    uint32_t n_ref, has_self;
+    int32_t hash_bits, dir_bits, dir_shift, pad_;
+    uint64_t off_postings, off_uhash, off_upos, off_dir, off_sizes, off_self, off_src;
+};
+constexpr uint64_t kBlobMagic = 0x31584449444b5352ULL;  // "RSKDIDX1"
+inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ULL; }
+
+void blob_layout(const rk_index *idx, BlobHeader *h)
+{
+    memset(h, 0, sizeof(*h));
+    h->magic = kBlobMagic;
+    h->H = idx->H;
+    h->U = idx->U;
+    h->sum_sq = idx->sum_sq;
+    h->n_ref = idx->n_ref;
+    h->has_self = idx->d_selfrange ? 1 : 0;
+    h->hash_bits = idx->hash_bits;
+    h->dir_bits = idx->dir_bits;
+    h->dir_shift = idx->dir_shift;
+    uint64_t p = al256(sizeof(BlobHeader));
+    h->off_postings = p; p = al256(p + (idx->H + 1) * 4);
+    h->off_uhash = p;    p = al256(p + (idx->U + 1) * 4);
+    h->off_upos = p;     p = al256(p + (idx->U + 2) * 4);
+    h->off_dir = p;      p = al256(p + ((1ULL << idx->dir_bits) + 1) * 4);
+    h->off_sizes = p;    p = al256(p + ((uint64_t)idx->n_ref + 1) * 4);
+    if (h->has_self) {
+        h->off_self = p; p = al256(p + (idx->H + 1) * sizeof(uint2));
+        h->off_src = p;  p = al256(p + ((uint64_t)idx->n_ref + 1) * 8);
+    }
+    h->bytes = p;
+}
+}  // namespace
+
+extern "C" {
+
+uint64_t rk_index_blob_bytes(const rk_index *idx)
+{
+    if (!idx) return 0;
+    BlobHeader h;
+    blob_layout(idx, &h);
+    return h.bytes;
+}
+
+int rk_index_pack_dev(const rk_index *idx, void *blob_dev, uint64_t blob_cap, void *stream_v)
+{
+    if (!idx || !blob_dev) return RK_ERR_ARG;
+    rk_ctx *ctx = idx->ctx;
+    hipStream_t st = (hipStream_t)stream_v;
+    BlobHeader h;
+    blob_layout(idx, &h);
+    if (blob_cap < h.bytes) return rk_fail(ctx, RK_ERR_CAPACITY, "blob needs %llu bytes", (unsigned long long)h.bytes);
+    char *b = (char *)blob_dev;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    RK_HIP(ctx, hipMemcpyAsync(b, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    RK_HIP(ctx, hipMemcpyAsync(b + h.off_postings, idx->d_postings, idx->H * 4, hipMemcpyDeviceToDevice, st));
+    RK_HIP(ctx, hipMemcpyAsync(b + h.off_uhash, idx->d_uhash, idx->U * 4, hipMemcpyDeviceToDevice, st));
+    RK_HIP(ctx, hipMemcpyAsync(b + h.off_upos, idx->d_upos, (idx->U + 1) * 4, hipMemcpyDeviceToDevice, st));
+    RK_HIP(ctx, hipMemcpyAsync(b + h.off_dir, idx->d_dir, ((1ULL << idx->dir_bits) + 1) * 4, hipMemcpyDeviceToDevice, st));
+    RK_HIP(ctx, hipMemcpyAsync(b + h.off_sizes, idx->d_sizes, (uint64_t)idx->n_ref * 4, hipMemcpyDeviceToDevice, st));
+    if (h.has_self) {
+        RK_HIP(ctx, hipMemcpyAsync(b + h.off_self, idx->d_selfrange, idx->H * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+        RK_HIP(ctx, hipMemcpyAsync(b + h.off_src, idx->d_src_off, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
+    }
+    RK_HIP(ctx, hipStreamSynchronize(st));
+    return RK_OK;
+}
+
+int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, void *stream_v, rk_index **out)
+{
+    if (!ctx || !blob_dev || !out || blob_bytes < sizeof(BlobHeader)) return RK_ERR_ARG;
+    *out = nullptr;
+    hipStream_t st = (hipStream_t)stream_v;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    BlobHeader h;
+    RK_HIP(ctx, hipMemcpyAsync(&h, blob_dev, sizeof(h), hipMemcpyDeviceToHost, st));
+    RK_HIP(ctx, hipStreamSynchronize(st));
+    if (h.magic != kBlobMagic || h.bytes > blob_bytes) return rk_fail(ctx, RK_ERR_ARG, "not an index blob");
+    rk_index *idx = new (std::nothrow) rk_index;
+    if (!idx) return RK_ERR_NOMEM;
+    struct Guard { rk_index *p; ~Guard() { if (p) rk_index_free(p); } } guard{idx};
+    idx->ctx = ctx;
+    idx->n_ref = h.n_ref;
+    idx->H = h.H;
+    idx->U = h.U;
+    idx->sum_sq = h.sum_sq;
+    idx->hash_bits = h.hash_bits;
+    idx->dir_bits = h.dir_bits;
+    idx->dir_shift = h.dir_shift;
+    BlobHeader chk;
+    blob_layout(idx, &chk);  // offsets must be the ones this library would produce
+    idx->d_selfrange = nullptr;
+    const char *b = (const char *)blob_dev;
+    const uint64_t nb = (1ULL << idx->dir_bits) + 1;
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (idx->H + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash, (idx->U + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_upos, (idx->U + 2) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_dir, nb * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_sizes, ((size_t)idx->n_ref + 1) * 4));
+    RK_HIP(ctx, hipMemcpyAsync(idx->d_postings, b + h.off_postings, idx->H * 4, hipMemcpyDeviceToDevice, st));
+    RK_HIP(ctx, hipMemcpyAsync(idx->d_uhash, b + h.off_uhash, idx->U * 4, hipMemcpyDeviceToDevice, st));
+    RK_HIP(ctx, hipMemcpyAsync(idx->d_upos, b + h.off_upos, (idx->U + 1) * 4, hipMemcpyDeviceToDevice, st));
+    RK_HIP(ctx, hipMemcpyAsync(idx->d_dir, b + h.off_dir, nb * 4, hipMemcpyDeviceToDevice, st));
+    RK_HIP(ctx, hipMemcpyAsync(idx->d_sizes, b + h.off_sizes, (uint64_t)idx->n_ref * 4, hipMemcpyDeviceToDevice, st));
+    if (h.has_self) {
+        RK_HIP(ctx, hipMalloc((void **)&idx->d_selfrange, (idx->H + 1) * sizeof(uint2)));
+        RK_HIP(ctx, hipMalloc((void **)&idx->d_src_off, ((size_t)idx->n_ref + 1) * 8));
+        RK_HIP(ctx, hipMemcpyAsync(idx->d_selfrange, b + h.off_self, idx->H * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+        RK_HIP(ctx, hipMemcpyAsync(idx->d_src_off, b + h.off_src, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
+    }
+    RK_HIP(ctx, hipStreamSynchronize(st));
+    guard.p = nullptr;
+    *out = idx;
+    return RK_OK;
+}
+
+}  // extern "C"

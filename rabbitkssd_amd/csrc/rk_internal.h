@@ -1,0 +1,91 @@
+// rk_internal.h -- shared declarations of librabbitkssd.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "rabbitkssd.h"
+
+struct rk_ctx {
+    int device = 0;
+    int num_cu = 0;
+    size_t max_lds = 0;  // bytes of LDS one workgroup may use
+    std::string err;
+};
+
+int rk_fail(rk_ctx *ctx, int code, const char *fmt, ...);
+
+#define RK_HIP(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return rk_fail((ctx), RK_ERR_HIP, "%s failed: %s (%s:%d)", #call,               \
+                           hipGetErrorString(e__), __FILE__, __LINE__);                     \
+    } while (0)
+
+// owning device pointer; freed on scope exit unless release()d
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { reset(); }
+    hipError_t alloc(size_t n) {
+        reset();
+        return hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T));
+    }
+    void reset() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    T *release() {
+        T *q = p;
+        p = nullptr;
+        return q;
+    }
+    operator T *() const { return p; }
+};
+
+struct rk_filter {
+    rk_ctx *ctx = nullptr;
+    rk_params params{};
+    int32_t *d_table = nullptr;   // the full .shuf table, int32[16^half_subk]
+    uint32_t *d_bitmap = nullptr; // pre-filter, 2^bitmap_bits bits
+    int bitmap_bits = 0;
+    uint32_t n_keys = 0;          // entries with value in [dim_start, dim_end)
+};
+
+struct rk_sketches {
+    rk_ctx *ctx = nullptr;
+    uint32_t n = 0;
+    uint64_t total = 0;
+    uint64_t windows = 0;
+    uint32_t *d_hashes = nullptr;
+    uint64_t *d_off = nullptr;
+    std::vector<uint64_t> h_off;  // host mirror of d_off (n+1)
+};
+
+struct rk_index {
+    rk_ctx *ctx = nullptr;
+    uint32_t n_ref = 0;
+    uint64_t H = 0;         // postings
+    uint64_t U = 0;         // distinct hashes
+    int hash_bits = 0;
+    int dir_bits = 0, dir_shift = 0;
+    uint64_t sum_sq = 0;
+    uint32_t *d_postings = nullptr;  // u32[H]   (.dict order)
+    uint32_t *d_uhash = nullptr;     // u32[U]   sorted distinct hashes
+    uint32_t *d_upos = nullptr;      // u32[U+1] posting offsets
+    uint32_t *d_dir = nullptr;       // u32[2^dir_bits+1] prefix directory into d_uhash
+    uint32_t *d_sizes = nullptr;     // u32[n_ref] sketch sizes
+    uint2 *d_selfrange = nullptr;    // uint2[H] per source element: postings of LATER genomes
+    uint64_t *d_src_off = nullptr;   // u64[n_ref+1] offsets of the source sketches (built only)
+};
+
+// kernels/launchers implemented in the .hip files
+int rk_resolve_ranges(rk_ctx *ctx, const rk_index *idx, const uint32_t *q_hashes_dev, uint64_t n,
+                      uint2 *ranges_dev, hipStream_t stream);

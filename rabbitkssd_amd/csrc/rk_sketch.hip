@@ -1,0 +1,524 @@
+// rk_sketch.hip -- shuffled-k-mer dimension-reduction sketcher.
+// Replaces the per-genome loop of sketchFastaFile (src/sketch.cpp:455-566) and the
+// identical arithmetic of consumer_fasta_task (src/sketch.cpp:173-238).
+//
+// Data layout (HBM): the "packed" sequence buffer holds every genome at a 1024-byte
+// aligned offset; records inside a genome are separated by one 0x00 byte (an invalid
+// base resets the window exactly like a record boundary does, src/sketch.cpp:487-488,
+// 502-504) and the tail up to the next 1 KiB boundary is zero.
+//
+// Kernel: one wavefront walks a chunk of consecutive 1 KiB blocks.  Per block every lane
+// loads 16 contiguous bases (one coalesced global_load_dwordx4 per lane, 1 KiB per wave),
+// converts them with SWAR arithmetic into a 32-bit word of 2-bit codes plus a 16-bit
+// validity mask, and fetches the words of the two preceding lanes.  All 16 k-mer windows
+// that END inside the lane are then cut out of that 96-bit string with funnel shifts
+// (forward strand) and out of its 2-bit-reversed complement (reverse strand): no serial
+// rolling dependency, 16 independent windows per lane.  The inner 2*subk bases of the
+// canonical k-mer (dim_id, src/sketch.cpp:509) are tested against a bitmap of the
+// selected .shuf entries held in LDS; the ~1/16^drlevel survivors are confirmed against
+// the full .shuf table in HBM/L2 and appended as (genome << 32 | dr_tuple) keys.
+// Per-genome dedup (the reference's unordered_set) = device radix sort + unique.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "rk_internal.h"
+
+namespace {
+
+constexpr int kSketchThreads = 512;            // 8 waves share one LDS bitmap
+constexpr int kWavesPerBlock = kSketchThreads / 64;
+constexpr int kBitmapBits = 19;                // 64 KiB of LDS
+
+struct SketchArgs {
+    const uint8_t *packed;
+    const uint32_t *chunk_gid;
+    const uint64_t *chunk_beg;     // byte offset of the chunk (multiple of 1024)
+    const uint32_t *chunk_blocks;  // number of 1 KiB blocks; bit 31 = first chunk of its genome
+    uint32_t n_chunks;
+    const uint32_t *bitmap;        // 2^kBitmapBits bits, index = dim_id & mask
+    const int32_t *table;          // int32[16^half_subk]
+    uint64_t tupmask, domask, undomask0, undomask1;
+    int32_t kmer, out2, dim_start, dim_end, dr_shift, und1_shift;
+    unsigned long long *cand;
+    unsigned long long cand_cap;
+    unsigned long long *n_cand;
+    unsigned long long *n_windows;
+};
+
+// low 64 bits of the 96-bit string w2:w1:w0 shifted right by sh (0 <= sh < 64)
+__device__ inline uint64_t ext96(uint32_t w2, uint32_t w1, uint32_t w0, int sh)
+{
+    const uint64_t lo = ((uint64_t)w1 << 32) | w0;
+    const uint64_t hi = ((uint64_t)w2 << 32) | w1;
+    if (sh == 0) return lo;
+    if (sh < 32) return (lo >> sh) | ((uint64_t)w2 << (64 - sh));
+    return hi >> (sh - 32);
+}
+
+// 16 ASCII bases -> F: 2-bit codes, oldest base in the top bits (same orientation as
+// `tuple`, src/sketch.cpp:498); V: bit i set when base i is one of ACGTacgt
+// (BaseMap, src/common.h:27-37).
+__device__ inline void pack16(const uint4 w, uint32_t &F, uint32_t &V)
+{
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    F = 0;
+    V = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t x = ws[d] | 0x20202020u;  // fold case
+        // a,c,g,t = 0x61,0x63,0x67,0x74 -> 0,1,2,3
+        const uint32_t t = ((x >> 1) & 0x03030303u) ^ ((x >> 2) & 0x01010101u);
+        F |= ((t * 0x40100401u) >> 24) << (24 - 8 * d);
+        // exact per-byte "is nonzero" (bit 7) for x ^ pattern; no cross-byte carries
+        uint32_t nz = 0x80808080u;
+#pragma unroll
+        for (int pi = 0; pi < 4; pi++) {
+            const uint32_t pat = pi == 0 ? 0x61616161u : pi == 1 ? 0x63636363u
+                               : pi == 2 ? 0x67676767u : 0x74747474u;
+            const uint32_t y = x ^ pat;
+            nz &= ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
+        }
+        const uint32_t f = ((~nz) >> 7) & 0x01010101u;  // 1 per valid byte
+        V |= ((f * 0x10204080u) >> 28) << (4 * d);
+    }
+}
+
+// complement of the 2-bit-group reversal: base i of the lane at bits 2i (rvs_tuple
+// orientation, src/sketch.cpp:499)
+__device__ inline uint32_t revcomp32(uint32_t F)
+{
+    const uint32_t b = __brev(F);
+    return ~(((b >> 1) & 0x55555555u) | ((b & 0x55555555u) << 1));
+}
+
+template <int KS>
+__global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
+{
+    extern __shared__ uint32_t bm[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.bitmap);
+        uint4 *dst = reinterpret_cast<uint4 *>(bm);
+        for (uint32_t i = threadIdx.x; i < (1u << kBitmapBits) / 128; i += kSketchThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int k = KS ? KS : a.kmer;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t bm_mask = (1u << kBitmapBits) - 1;
+    unsigned long long windows = 0;
+
+    for (uint32_t c = blockIdx.x * kWavesPerBlock + wave; c < a.n_chunks; c += gridDim.x * kWavesPerBlock) {
+        const uint32_t gid = a.chunk_gid[c];
+        const uint64_t beg = a.chunk_beg[c];
+        const uint32_t nbf = a.chunk_blocks[c];
+        const uint32_t nb = nbf & 0x7FFFFFFFu;
+        const uint8_t *base = a.packed + beg;
+
+        // words of the two 16-base groups before the chunk (lanes "-2" and "-1")
+        uint32_t cF2 = 0, cF1 = 0, cV2 = 0, cV1 = 0;
+        if (!(nbf >> 31)) {
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (lane < 2) w = *reinterpret_cast<const uint4 *>(base - 32 + 16 * lane);
+            uint32_t F, V;
+            pack16(w, F, V);
+            cF2 = __shfl(F, 0); cF1 = __shfl(F, 1);
+            cV2 = __shfl(V, 0); cV1 = __shfl(V, 1);
+        }
+
+        uint4 cur = *reinterpret_cast<const uint4 *>(base + 16 * lane);
+        for (uint32_t b = 0; b < nb; b++) {
+            uint4 nxt = make_uint4(0, 0, 0, 0);
+            if (b + 1 < nb) nxt = *reinterpret_cast<const uint4 *>(base + (size_t)(b + 1) * 1024 + 16 * lane);
+
+            uint32_t F, V;
+            pack16(cur, F, V);
+            uint32_t F1 = __shfl_up(F, 1), F2 = __shfl_up(F, 2);
+            uint32_t V1 = __shfl_up(V, 1), V2 = __shfl_up(V, 2);
+            if (lane == 0) { F1 = cF1; F2 = cF2; V1 = cV1; V2 = cV2; }
+            if (lane == 1) { F2 = cF1; V2 = cV1; }
+            cF2 = __shfl(F, 62); cF1 = __shfl(F, 63);
+            cV2 = __shfl(V, 62); cV1 = __shfl(V, 63);
+            const uint32_t R = revcomp32(F), R1 = revcomp32(F1), R2 = revcomp32(F2);
+
+            // bad[j]: the window ending at base j of this lane contains an invalid base
+            uint64_t inv = (uint64_t)(~V2 & 0xFFFFu) | ((uint64_t)(~V1 & 0xFFFFu) << 16) |
+                           ((uint64_t)(~V & 0xFFFFu) << 32);
+            int covered = 1;
+            while (covered * 2 <= k) { inv |= inv << covered; covered *= 2; }
+            if (k > covered) inv |= inv << (k - covered);
+            const uint32_t bad = (uint32_t)(inv >> 32) & 0xFFFFu;
+            windows += __popc(~bad & 0xFFFFu);
+
+            uint32_t maybe = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint64_t tuple = ext96(F2, F1, F, 2 * (15 - j)) & a.tupmask;
+                const uint64_t rvs = ext96(R, R1, R2, 2 * (33 + j - k)) & a.tupmask;
+                const uint64_t uni = tuple < rvs ? tuple : rvs;                 // :508
+                const uint32_t dim = (uint32_t)((uni & a.domask) >> a.out2);    // :509
+                const uint32_t ix = dim & bm_mask;
+                maybe |= ((bm[ix >> 5] >> (ix & 31)) & 1u) << j;
+            }
+            maybe &= ~bad;
+
+            while (maybe) {  // ~1 window in 16^drlevel gets here
+                const int j = __ffs((int)maybe) - 1;
+                maybe &= maybe - 1;
+                const uint64_t tuple = ext96(F2, F1, F, 2 * (15 - j)) & a.tupmask;
+                const uint64_t rvs = ext96(R, R1, R2, 2 * (33 + j - k)) & a.tupmask;
+                const uint64_t uni = tuple < rvs ? tuple : rvs;
+                const uint32_t dim = (uint32_t)((uni & a.domask) >> a.out2);
+                const int32_t v = a.table[dim];
+                if (v >= a.dim_start && v < a.dim_end) {                        // :341,:516
+                    const uint64_t pf = (uint64_t)(v - a.dim_start);            // :519-521
+                    const uint64_t dr = (((uni & a.undomask0) | ((uni & a.undomask1) << a.und1_shift)) >>
+                                         a.dr_shift) | pf;                      // :524
+                    const unsigned long long slot = atomicAdd(a.n_cand, 1ULL);
+                    if (slot < a.cand_cap) a.cand[slot] = ((unsigned long long)gid << 32) | (uint32_t)dr;
+                }
+            }
+            cur = nxt;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) windows += __shfl_down(windows, o);
+    if (lane == 0 && windows) atomicAdd(a.n_windows, windows);
+}
+
+__global__ void k_build_bitmap(const int32_t *table, uint64_t n, int32_t dim_start, int32_t dim_end,
+                               uint32_t *bitmap, uint32_t mask, uint32_t *n_keys)
+{
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int32_t v = table[t];
+    if (v >= dim_start && v < dim_end) {
+        const uint32_t ix = (uint32_t)t & mask;
+        atomicOr(&bitmap[ix >> 5], 1u << (ix & 31));
+        atomicAdd(n_keys, 1u);
+    }
+}
+
+__global__ void k_split_keys(const unsigned long long *ukeys, uint64_t n, uint32_t *hashes)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hashes[i] = (uint32_t)ukeys[i];
+}
+
+__global__ void k_genome_offsets(const unsigned long long *ukeys, uint64_t n, uint32_t n_genomes,
+                                 uint64_t *off)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_genomes) return;
+    const unsigned long long key = (unsigned long long)g << 32;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (ukeys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    off[g] = lo;
+}
+
+inline unsigned blocks_for(uint64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+
+typedef void (*sketch_kernel_t)(SketchArgs);
+sketch_kernel_t pick_kernel(int kmer)
+{
+    switch (kmer) {
+    case 16: return rk_sketch_kernel<16>;
+    case 20: return rk_sketch_kernel<20>;
+    default: return rk_sketch_kernel<0>;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_dim, rk_filter **out)
+{
+    if (!ctx || !p || !shuffled_dim || !out) return RK_ERR_ARG;
+    *out = nullptr;
+    if (rk_hash_bits(p) > 32)
+        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "64-bit hash layout (half_k - drlevel > 8) not supported");
+    if (p->half_subk < 1 || p->half_subk >= 8 || p->half_k > 16 || p->half_k < p->half_subk)
+        return rk_fail(ctx, RK_ERR_ARG, "bad kssd parameters");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = 1ULL << (4 * p->half_subk);
+    DevBuf<int32_t> table;
+    DevBuf<uint32_t> bitmap, nkeys;
+    RK_HIP(ctx, table.alloc(n));
+    RK_HIP(ctx, bitmap.alloc((1u << kBitmapBits) / 32));
+    RK_HIP(ctx, nkeys.alloc(1));
+    RK_HIP(ctx, hipMemcpy(table.p, shuffled_dim, n * 4, hipMemcpyHostToDevice));
+    RK_HIP(ctx, hipMemset(bitmap.p, 0, (1u << kBitmapBits) / 8));
+    RK_HIP(ctx, hipMemset(nkeys.p, 0, 4));
+    hipLaunchKernelGGL(k_build_bitmap, dim3(blocks_for(n)), dim3(256), 0, 0, table.p, n, p->dim_start,
+                       p->dim_end, bitmap.p, (1u << kBitmapBits) - 1, nkeys.p);
+    RK_HIP(ctx, hipGetLastError());
+    uint32_t nk = 0;
+    RK_HIP(ctx, hipMemcpy(&nk, nkeys.p, 4, hipMemcpyDeviceToHost));
+    rk_filter *f = new (std::nothrow) rk_filter;
+    if (!f) return RK_ERR_NOMEM;
+    f->ctx = ctx;
+    f->params = *p;
+    f->d_table = table.release();
+    f->d_bitmap = bitmap.release();
+    f->bitmap_bits = kBitmapBits;
+    f->n_keys = nk;
+    *out = f;
+    return RK_OK;
+}
+
+void rk_filter_free(rk_filter *f)
+{
+    if (!f) return;
+    (void)hipFree(f->d_table);
+    (void)hipFree(f->d_bitmap);
+    delete f;
+}
+
+void rk_sketches_free(rk_sketches *s)
+{
+    if (!s) return;
+    (void)hipFree(s->d_hashes);
+    (void)hipFree(s->d_off);
+    delete s;
+}
+
+uint32_t rk_sketches_count(const rk_sketches *s) { return s ? s->n : 0; }
+uint64_t rk_sketches_total(const rk_sketches *s) { return s ? s->total : 0; }
+uint64_t rk_sketches_windows(const rk_sketches *s) { return s ? s->windows : 0; }
+const uint32_t *rk_sketches_hashes_dev(const rk_sketches *s) { return s ? s->d_hashes : nullptr; }
+const uint64_t *rk_sketches_off_dev(const rk_sketches *s) { return s ? s->d_off : nullptr; }
+
+int rk_sketches_from_host(rk_ctx *ctx, const uint32_t *hashes, const uint64_t *off, uint32_t n,
+                          rk_sketches **out)
+{
+    if (!ctx || !off || !out || (!hashes && off[n])) return RK_ERR_ARG;
+    *out = nullptr;
+    for (uint32_t g = 0; g < n; g++)
+        if (off[g + 1] < off[g]) return rk_fail(ctx, RK_ERR_ARG, "offsets must be non-decreasing");
+    if (off[0] != 0) return rk_fail(ctx, RK_ERR_ARG, "off[0] must be 0");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    rk_sketches *s = new (std::nothrow) rk_sketches;
+    if (!s) return RK_ERR_NOMEM;
+    s->ctx = ctx;
+    s->n = n;
+    s->total = off[n];
+    s->h_off.assign(off, off + n + 1);
+    struct Guard { rk_sketches *p; ~Guard() { if (p) rk_sketches_free(p); } } guard{s};
+    RK_HIP(ctx, hipMalloc((void **)&s->d_hashes, (s->total + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&s->d_off, ((size_t)n + 1) * 8));
+    if (s->total) RK_HIP(ctx, hipMemcpy(s->d_hashes, hashes, s->total * 4, hipMemcpyHostToDevice));
+    RK_HIP(ctx, hipMemcpy(s->d_off, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+    guard.p = nullptr;
+    *out = s;
+    return RK_OK;
+}
+
+int rk_sketches_from_dev(rk_ctx *ctx, const uint32_t *hashes_dev, const uint64_t *off_dev, uint32_t n,
+                         rk_sketches **out)
+{
+    if (!ctx || !off_dev || !out) return RK_ERR_ARG;
+    *out = nullptr;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    rk_sketches *s = new (std::nothrow) rk_sketches;
+    if (!s) return RK_ERR_NOMEM;
+    s->ctx = ctx;
+    s->n = n;
+    struct Guard { rk_sketches *p; ~Guard() { if (p) rk_sketches_free(p); } } guard{s};
+    s->h_off.resize((size_t)n + 1);
+    RK_HIP(ctx, hipMemcpy(s->h_off.data(), off_dev, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+    s->total = s->h_off[n];
+    if (!hashes_dev && s->total) return rk_fail(ctx, RK_ERR_ARG, "hashes_dev is NULL");
+    RK_HIP(ctx, hipMalloc((void **)&s->d_hashes, (s->total + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&s->d_off, ((size_t)n + 1) * 8));
+    if (s->total) RK_HIP(ctx, hipMemcpy(s->d_hashes, hashes_dev, s->total * 4, hipMemcpyDeviceToDevice));
+    RK_HIP(ctx, hipMemcpy(s->d_off, off_dev, ((size_t)n + 1) * 8, hipMemcpyDeviceToDevice));
+    guard.p = nullptr;
+    *out = s;
+    return RK_OK;
+}
+
+int rk_sketches_download(const rk_sketches *s, uint32_t *hashes, uint64_t *off)
+{
+    if (!s) return RK_ERR_ARG;
+    rk_ctx *ctx = s->ctx;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    if (off) memcpy(off, s->h_off.data(), ((size_t)s->n + 1) * 8);
+    if (hashes && s->total)
+        RK_HIP(ctx, hipMemcpy(hashes, s->d_hashes, s->total * 4, hipMemcpyDeviceToHost));
+    return RK_OK;
+}
+
+int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_dev,
+                         uint64_t packed_bytes, const uint64_t *gbeg, const uint64_t *gend,
+                         uint32_t n_genomes, void *stream_v, rk_sketches **out)
+{
+    if (!ctx || !f || !out || (!packed_dev && packed_bytes) || ((!gbeg || !gend) && n_genomes))
+        return RK_ERR_ARG;
+    *out = nullptr;
+    hipStream_t stream = (hipStream_t)stream_v;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    const rk_params &P = f->params;
+
+    // ---- chunk table: one wave per chunk of up to `cb` consecutive 1 KiB blocks
+    uint64_t total_blocks = 0, total_len = 0;
+    for (uint32_t g = 0; g < n_genomes; g++) {
+        if (gend[g] < gbeg[g] || (gbeg[g] & 1023) || gend[g] > packed_bytes)
+            return rk_fail(ctx, RK_ERR_ARG, "genome %u: bad packed range", g);
+        if (((gend[g] + 1023) & ~1023ULL) > packed_bytes && gend[g] > gbeg[g])
+            return rk_fail(ctx, RK_ERR_ARG, "packed buffer must be padded to a multiple of 1024 bytes");
+        total_blocks += (gend[g] - gbeg[g] + 1023) >> 10;
+        total_len += gend[g] - gbeg[g];
+    }
+    // aim for >= 16 chunks per CU so 256 CUs x 16 waves stay busy, 16..256 blocks each
+    uint64_t cb = total_blocks / ((uint64_t)ctx->num_cu * 16 * 4 + 1);
+    cb = std::min<uint64_t>(256, std::max<uint64_t>(16, cb));
+    std::vector<uint32_t> c_gid, c_blocks;
+    std::vector<uint64_t> c_beg;
+    for (uint32_t g = 0; g < n_genomes; g++) {
+        const uint64_t nblk = (gend[g] - gbeg[g] + 1023) >> 10;
+        for (uint64_t b = 0; b < nblk; b += cb) {
+            c_gid.push_back(g);
+            c_beg.push_back(gbeg[g] + (b << 10));
+            c_blocks.push_back((uint32_t)std::min<uint64_t>(cb, nblk - b) | (b == 0 ? 0x80000000u : 0));
+        }
+    }
+    const uint32_t n_chunks = (uint32_t)c_gid.size();
+
+    DevBuf<uint32_t> d_gid, d_blocks;
+    DevBuf<uint64_t> d_beg;
+    DevBuf<unsigned long long> d_counters;  // [0]=n_cand [1]=n_windows
+    RK_HIP(ctx, d_gid.alloc(n_chunks));
+    RK_HIP(ctx, d_blocks.alloc(n_chunks));
+    RK_HIP(ctx, d_beg.alloc(n_chunks));
+    RK_HIP(ctx, d_counters.alloc(2));
+    if (n_chunks) {
+        RK_HIP(ctx, hipMemcpyAsync(d_gid.p, c_gid.data(), (size_t)n_chunks * 4, hipMemcpyHostToDevice, stream));
+        RK_HIP(ctx, hipMemcpyAsync(d_blocks.p, c_blocks.data(), (size_t)n_chunks * 4, hipMemcpyHostToDevice, stream));
+        RK_HIP(ctx, hipMemcpyAsync(d_beg.p, c_beg.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, stream));
+    }
+
+    // candidate capacity: expected survivors = windows / 16^drlevel; x2 + slack, exact retry
+    uint64_t cap = 2 * (total_len >> (4 * P.drlevel)) + (uint64_t)n_genomes * 64 + 65536;
+    const size_t lds = (1u << kBitmapBits) / 8;
+    sketch_kernel_t kern = pick_kernel((int)P.kmer_size);
+    RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+
+    DevBuf<unsigned long long> cand;
+    unsigned long long counters[2] = {0, 0};
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (cand.alloc(cap) != hipSuccess)
+            return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu candidate slots", (unsigned long long)cap);
+        RK_HIP(ctx, hipMemsetAsync(d_counters.p, 0, 16, stream));
+        if (n_chunks) {
+            SketchArgs a;
+            a.packed = packed_dev;
+            a.chunk_gid = d_gid.p;
+            a.chunk_beg = d_beg.p;
+            a.chunk_blocks = d_blocks.p;
+            a.n_chunks = n_chunks;
+            a.bitmap = f->d_bitmap;
+            a.table = f->d_table;
+            a.tupmask = P.tupmask;
+            a.domask = P.domask;
+            a.undomask0 = P.undomask0;
+            a.undomask1 = P.undomask1;
+            a.kmer = (int32_t)P.kmer_size;
+            a.out2 = 2 * P.half_outctx_len;
+            a.dim_start = P.dim_start;
+            a.dim_end = P.dim_end;
+            a.dr_shift = 4 * P.drlevel;
+            a.und1_shift = (int32_t)P.kmer_size * 2 - P.half_outctx_len * 4;
+            a.cand = cand.p;
+            a.cand_cap = cap;
+            a.n_cand = d_counters.p;
+            a.n_windows = d_counters.p + 1;
+            const uint32_t want = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+            const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu * 2 * 8);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kSketchThreads), lds, stream, a);
+            RK_HIP(ctx, hipGetLastError());
+        }
+        RK_HIP(ctx, hipMemcpyAsync(counters, d_counters.p, 16, hipMemcpyDeviceToHost, stream));
+        RK_HIP(ctx, hipStreamSynchronize(stream));
+        if (counters[0] <= cap) break;
+        cap = counters[0];  // overflow: rerun with the exact count
+        if (attempt == 1) return rk_fail(ctx, RK_ERR_CAPACITY, "candidate overflow persisted");
+    }
+    const uint64_t n_cand = counters[0];
+
+    // ---- per-genome dedup: sort (genome, hash) keys, unique, split into CSR
+    rk_sketches *s = new (std::nothrow) rk_sketches;
+    if (!s) return RK_ERR_NOMEM;
+    s->ctx = ctx;
+    s->n = n_genomes;
+    s->windows = counters[1];
+    struct Guard { rk_sketches *p; ~Guard() { if (p) rk_sketches_free(p); } } guard{s};
+    RK_HIP(ctx, hipMalloc((void **)&s->d_off, ((size_t)n_genomes + 1) * 8));
+    uint64_t n_unique = 0;
+    DevBuf<unsigned long long> sorted, uniq;
+    if (n_cand) {
+        int gbits = 1;
+        while ((1ULL << gbits) < n_genomes) gbits++;
+        RK_HIP(ctx, sorted.alloc(n_cand));
+        RK_HIP(ctx, uniq.alloc(n_cand));
+        DevBuf<unsigned long long> d_nuniq;
+        RK_HIP(ctx, d_nuniq.alloc(1));
+        size_t t1 = 0, t2 = 0;
+        RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t1, cand.p, sorted.p, n_cand, 0, (unsigned)(32 + gbits), stream));
+        RK_HIP(ctx, rocprim::unique(nullptr, t2, sorted.p, uniq.p, d_nuniq.p, n_cand,
+                                    rocprim::equal_to<unsigned long long>(), stream));
+        DevBuf<char> tmp;
+        RK_HIP(ctx, tmp.alloc(std::max(t1, t2)));
+        RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, t1, cand.p, sorted.p, n_cand, 0, (unsigned)(32 + gbits), stream));
+        RK_HIP(ctx, rocprim::unique(tmp.p, t2, sorted.p, uniq.p, d_nuniq.p, n_cand,
+                                    rocprim::equal_to<unsigned long long>(), stream));
+        unsigned long long nu = 0;
+        RK_HIP(ctx, hipMemcpyAsync(&nu, d_nuniq.p, 8, hipMemcpyDeviceToHost, stream));
+        RK_HIP(ctx, hipStreamSynchronize(stream));
+        n_unique = nu;
+    }
+    s->total = n_unique;
+    RK_HIP(ctx, hipMalloc((void **)&s->d_hashes, (n_unique + 1) * 4));
+    if (n_unique)
+        hipLaunchKernelGGL(k_split_keys, dim3(blocks_for(n_unique)), dim3(256), 0, stream, uniq.p, n_unique,
+                           s->d_hashes);
+    hipLaunchKernelGGL(k_genome_offsets, dim3(blocks_for((uint64_t)n_genomes + 1)), dim3(256), 0, stream,
+                       uniq.p, n_unique, n_genomes, s->d_off);
+    RK_HIP(ctx, hipGetLastError());
+    s->h_off.resize((size_t)n_genomes + 1);
+    RK_HIP(ctx, hipMemcpyAsync(s->h_off.data(), s->d_off, ((size_t)n_genomes + 1) * 8, hipMemcpyDeviceToHost, stream));
+    RK_HIP(ctx, hipStreamSynchronize(stream));
+    guard.p = nullptr;
+    *out = s;
+    return RK_OK;
+}
+
+int rk_sketch_batch(rk_ctx *ctx, const rk_filter *f, const uint8_t *seq, const uint64_t *rec_off,
+                    uint64_t n_rec, const uint64_t *genome_rec, uint32_t n_genomes, rk_sketches **out)
+{
+    if (!ctx || !f || !rec_off || !genome_rec || !out || (!seq && rec_off[n_rec])) return RK_ERR_ARG;
+    *out = nullptr;
+    std::vector<uint64_t> gbeg((size_t)n_genomes + 1), gend((size_t)n_genomes + 1);
+    uint64_t bytes = 0;
+    int rc = rk_pack_layout(rec_off, n_rec, genome_rec, n_genomes, gbeg.data(), gend.data(), &bytes);
+    if (rc) return rk_fail(ctx, rc, "bad record/genome offsets");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    uint8_t *h_packed = nullptr;
+    RK_HIP(ctx, hipHostMalloc((void **)&h_packed, bytes, hipHostMallocDefault));
+    rc = rk_pack_genomes(seq, rec_off, n_rec, genome_rec, n_genomes, gbeg.data(), h_packed, bytes);
+    DevBuf<uint8_t> d_packed;
+    if (!rc && d_packed.alloc(bytes) != hipSuccess) rc = rk_fail(ctx, RK_ERR_NOMEM, "device alloc of %llu bytes failed", (unsigned long long)bytes);
+    if (!rc && hipMemcpy(d_packed.p, h_packed, bytes, hipMemcpyHostToDevice) != hipSuccess)
+        rc = rk_fail(ctx, RK_ERR_HIP, "sequence upload failed");
+    (void)hipHostFree(h_packed);
+    if (rc) return rc;
+    return rk_sketch_packed_dev(ctx, f, d_packed.p, bytes, gbeg.data(), gend.data(), n_genomes, nullptr, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle and the
+golden fixtures.  Integer results (hash sets, postings, intersection counts, sizes) must be
+bit-exact; FP64 jaccard/containment exact, Mash/AafD distance within 1e-12 (north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as ok
+from rabbitkssd_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+DIST_TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return capi.Context(0)
+
+
+def assert_hits_equal(mine, want):
+    assert len(mine) == len(want)
+    for f in ("row", "col", "common", "size0", "size1"):
+        assert np.array_equal(mine[f], want[f]), f
+    assert np.array_equal(mine["jorc"], want["jorc"])          # one IEEE division
+    assert np.max(np.abs(mine["dist"] - want["dist"]), initial=0.0) <= DIST_TOL
+
+
+def load_dist_case():
+    d = os.path.join(GOLDEN, "dist")
+    man = json.load(open(os.path.join(d, "manifest.json")))
+    _, rnames, rh, roff = ok.read_sketches32(os.path.join(d, "ref.sketch"))
+    _, qnames, qh, qoff = ok.read_sketches32(os.path.join(d, "qry.sketch"))
+    return d, man, (rnames, rh, roff), (qnames, qh, qoff)
+
+
+def test_index_build_matches_dict_and_index_files(ctx):
+    _, man, (rnames, rh, roff), _ = load_dist_case()
+    postings, counts = ok.index_build32(rh, roff, man["hash_bits"])
+    sk = ctx.sketches_from_host(rh, roff)
+    idx = ctx.index_build(sk, man["hash_bits"])
+    p2, c2 = idx.export()
+    assert np.array_equal(p2, postings)      # .dict payload, src/sketch.cpp:991-1001
+    assert np.array_equal(c2, counts)        # .index payload, src/sketch.cpp:1008-1011
+    assert idx.total == len(rh) and idx.genomes == len(rnames)
+    assert idx.distinct == int((counts > 0).sum())
+    assert idx.sum_sq == int((counts.astype(np.int64) ** 2).sum())
+
+
+def test_golden_alldist_and_dist_text(ctx):
+    d, man, (rnames, rh, roff), (qnames, qh, qoff) = load_dist_case()
+    kmer = 2 * man["half_k"]
+    rsk = ctx.sketches_from_host(rh, roff)
+    qsk = ctx.sketches_from_host(qh, qoff)
+    built = ctx.index_build(rsk, man["hash_bits"])
+    postings, counts = ok.index_build32(rh, roff, man["hash_bits"])
+    imported = ctx.index_import(postings, counts, man["hash_bits"], np.diff(roff))
+    for case in man["cases"]:
+        want = open(os.path.join(d, case["file"])).read().split("\n")[:-1]
+        if case["cmd"] == "alldist":
+            variants = [(built, None), (built, rsk), (imported, rsk)]
+            for idx, q in variants:
+                hits, _ = ctx.dist_rows(idx, q, 1, case["metric"], kmer, case["max_dist"])
+                mine = sorted(capi.format_hit(rnames[h["col"]], rnames[h["row"]], h).rstrip("\n")
+                              for h in hits)
+                assert mine == want, case["file"]
+        else:
+            for idx in (built, imported):
+                hits, _ = ctx.dist_rows(idx, qsk, 0, case["metric"], kmer, case["max_dist"])
+                if case["max_neighbor"]:
+                    hits = capi.topn_rows(hits, case["max_neighbor"])
+                mine = [capi.format_hit(qnames[h["row"]], rnames[h["col"]], h).rstrip("\n") for h in hits]
+                assert mine == want, case["file"]
+
+
+def test_dense_counts_bit_exact(ctx):
+    _, man, (rnames, rh, roff), (qnames, qh, qoff) = load_dist_case()
+    postings, counts = ok.index_build32(rh, roff, man["hash_bits"])
+    rsizes = np.diff(roff).astype(np.uint32)
+    idx = ctx.index_build(ctx.sketches_from_host(rh, roff), man["hash_bits"])
+    for (h, off, tri) in ((qh, qoff, 0), (rh, roff, 1)):
+        want_hits, want = ok.index_dist32(counts, man["hash_bits"], postings, rsizes, h, off, tri, 0, 16,
+                                          0.2, want_dense=True)
+        hits, dense = ctx.dist_rows(idx, ctx.sketches_from_host(h, off), tri, 0, 16, 0.2, want_dense=True)
+        assert np.array_equal(dense, want)
+        assert_hits_equal(hits, want_hits)
+
+
+@pytest.mark.parametrize("n,m,bits,seed", [(300, 150, 24, 1), (1000, 60, 20, 2), (64, 1200, 28, 3)])
+def test_random_alldist_vs_oracle(ctx, n, m, bits, seed):
+    names, h, off = synth.clade_sketches(n, m, bits, seed=seed)
+    postings, counts = ok.index_build32(h, off, bits)
+    sizes = np.diff(off).astype(np.uint32)
+    idx = ctx.index_build(ctx.sketches_from_host(h, off), bits)
+    for metric, D in ((0, 0.05), (1, 0.1), (0, 1.0)):
+        want, _ = ok.index_dist32(counts, bits, postings, sizes, h, off, 1, metric, 20, D, threads=4)
+        mine, _ = ctx.dist_rows(idx, None, 1, metric, 20, D)
+        assert_hits_equal(mine, want)
+    # dense mode (threshold admits distance 1.0): every j>i pair is reported
+    want, _ = ok.index_dist32(counts, bits, postings, sizes, h, off, 1, 0, 20, 1.5, threads=4)
+    mine, _ = ctx.dist_rows(idx, None, 1, 0, 20, 1.5)
+    assert len(mine) == n * (n - 1) // 2
+    assert_hits_equal(mine, want)
+
+
+def test_row_sharding_union_equals_full(ctx):
+    names, h, off = synth.clade_sketches(500, 100, 22, seed=9)
+    idx = ctx.index_build(ctx.sketches_from_host(h, off), 22)
+    full, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.08)
+    parts = [ctx.dist_rows(idx, None, 1, 0, 20, 0.08, row_first=r, row_step=4)[0] for r in range(4)]
+    for r, p in enumerate(parts):
+        assert np.all(p["row"] % 4 == r)
+    merged = np.concatenate(parts)
+    merged = merged[np.lexsort((merged["col"], merged["row"]))]
+    assert merged.tobytes() == full.tobytes()
+
+
+def test_ref_vs_query_random_and_tiled_reference(ctx):
+    # 45,000 references: the LDS counter row is tiled (2 tiles of <= 40,960 columns)
+    rn, rh, roff = synth.clade_sketches(45000, 24, 24, seed=4)
+    qn, qh, qoff = synth.clade_sketches(40, 300, 24, seed=5)
+    qh[: 24] = rh[: 24]  # make query 0 contain reference 0
+    # keep every per-genome set sorted/unique after the overwrite
+    parts = [np.unique(qh[int(qoff[i]):int(qoff[i + 1])]) for i in range(40)]
+    qoff = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    qh = np.concatenate(parts)
+    postings, counts = ok.index_build32(rh, roff, 24)
+    sizes = np.diff(roff).astype(np.uint32)
+    idx = ctx.index_build(ctx.sketches_from_host(rh, roff), 24)
+    qs = ctx.sketches_from_host(qh, qoff)
+    for metric, D in ((0, 0.3), (1, 0.2)):
+        want, _ = ok.index_dist32(counts, 24, postings, sizes, qh, qoff, 0, metric, 20, D, threads=4)
+        mine, _ = ctx.dist_rows(idx, qs, 0, metric, 20, D)
+        assert len(want) > 0
+        assert_hits_equal(mine, want)
+
+
+def test_edge_cases_empty_inputs(ctx):
+    off = np.array([0, 0, 3, 3], dtype=np.uint64)
+    h = np.array([1, 5, 9], dtype=np.uint32)
+    sk = ctx.sketches_from_host(h, off)
+    idx = ctx.index_build(sk, 12)
+    hits, dense = ctx.dist_rows(idx, sk, 1, 0, 20, 2.0, want_dense=True)
+    assert dense.tolist() == [[0, 0, 0], [0, 3, 0], [0, 0, 0]]
+    assert len(hits) == 3 and np.all(hits["dist"] == 1.0) and np.all(hits["jorc"] == 0.0)
+    empty = ctx.sketches_from_host(np.zeros(0, dtype=np.uint32), np.zeros(1, dtype=np.uint64))
+    idx0 = ctx.index_build(empty, 12)
+    hits, _ = ctx.dist_rows(idx0, None, 1, 0, 20, 0.5)
+    assert len(hits) == 0 and idx0.total == 0 and idx0.distinct == 0
+    # query hash outside the reference hash space is ignored
+    q = ctx.sketches_from_host(np.array([1, 5, 9, 1 << 20], dtype=np.uint32), np.array([0, 4], dtype=np.uint64))
+    hits, dense = ctx.dist_rows(idx, q, 0, 0, 20, 0.9, want_dense=True)
+    assert dense.tolist() == [[0, 3, 0]] and len(hits) == 1 and hits[0]["common"] == 3
+
+
+# ------------------------------------------------------------------ sketching
+def sketch_case(ctx, k, s, l, genomes):
+    """genomes: list of (seq uint8, rec_off) -> GPU CSR vs oracle sets"""
+    param = ok.init_param(k, s, l)
+    table = ok.shuffle_table(k, s, l)
+    flt = ctx.filter(capi.params_init(k, s, l), table)
+    seqs, rec_off, genome_rec = [], [0], [0]
+    for seq, off in genomes:
+        seqs.append(seq)
+        for r in range(len(off) - 1):
+            rec_off.append(rec_off[-1] + int(off[r + 1] - off[r]))
+        genome_rec.append(len(rec_off) - 1)
+    seq = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
+    sk = ctx.sketch_batch(flt, seq, np.array(rec_off, dtype=np.uint64), np.array(genome_rec, dtype=np.uint64))
+    gh, goff = sk.download()
+    assert sk.count == len(genomes)
+    windows = 0
+    for g, (gs, off) in enumerate(genomes):
+        want = ok.sketch_records(param, table, gs, off)
+        mine = gh[int(goff[g]):int(goff[g + 1])]
+        assert np.array_equal(mine.astype(np.uint64), want), "genome %d" % g
+        windows += ok.count_windows(param, gs, off)
+    assert sk.windows == windows
+    return sk
+
+
+def test_sketch_golden_fixtures(ctx):
+    d = os.path.join(GOLDEN, "sketch")
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    genomes, want = [], []
+    for fn, e in sorted(exp["files"].items()):
+        genomes.append(ok.read_fasta(os.path.join(d, fn)))
+        want.append(e["hashes"])
+    sk = sketch_case(ctx, exp["half_k"], exp["half_subk"], exp["drlevel"], genomes)
+    gh, goff = sk.download()
+    for g, w in enumerate(want):
+        assert gh[int(goff[g]):int(goff[g + 1])].tolist() == w
+
+
+@pytest.mark.parametrize("k,s,l", [(10, 6, 3), (8, 5, 2), (9, 5, 2), (6, 4, 1), (16, 7, 4), (12, 6, 4)])
+def test_sketch_parameter_sets_vs_oracle(ctx, k, s, l):
+    if s - l < 3:
+        with pytest.raises(capi.RkError):
+            capi.params_init(k, s, l)
+        return
+    rng = np.random.default_rng(k * 100 + s * 10 + l)
+    genomes = []
+    for g in range(5):
+        n = [200000, 70001, 1024, 2048 + 19, 5][g]
+        b = synth.clade_genome(g // 2, g % 2, n).copy()
+        if n > 5000:
+            for p in rng.integers(0, n - 50, size=6):
+                b[p:p + int(rng.integers(1, 40))] = ord("N")
+            b[100:200] = np.frombuffer(bytes(b[100:200]).lower(), dtype=np.uint8)
+        cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n, size=3)]))
+        genomes.append((b, np.array(cuts, dtype=np.uint64)))
+    genomes.append((np.zeros(0, dtype=np.uint8), np.array([0], dtype=np.uint64)))      # no records
+    genomes.append((np.frombuffer(b"ACGT", dtype=np.uint8), np.array([0, 0, 4], dtype=np.uint64)))
+    sketch_case(ctx, k, s, l, genomes)
+
+
+def test_sketch_low_complexity_overflow_retry(ctx):
+    # a homopolymer / tandem repeat emits the same hash for every window if it passes
+    # the filter: exercises the candidate-overflow retry path and the dedup
+    k, s, l = 8, 5, 2
+    table = ok.shuffle_table(k, s, l)
+    param = ok.init_param(k, s, l)
+    # find a 2-base repeat unit whose dim_id passes the filter
+    best = None
+    for unit in (b"AC", b"AG", b"AT", b"CA", b"CG", b"GA", b"TA", b"AA", b"CC"):
+        seq = np.frombuffer(unit * 400, dtype=np.uint8)
+        if len(ok.sketch_records(param, table, seq, np.array([0, len(seq)], dtype=np.uint64))):
+            best = unit
+            break
+    genomes = [(np.frombuffer((best or b"AC") * 300000, dtype=np.uint8), np.array([0, 600000], dtype=np.uint64)),
+               (synth.clade_genome(1, 0, 50000), np.array([0, 50000], dtype=np.uint64))]
+    sketch_case(ctx, k, s, l, genomes)
+
+
+def test_end_to_end_sketch_index_alldist(ctx):
+    """config[0]-shaped plumbing at reduced genome length: FASTA -> sketch -> index -> alldist."""
+    k, s, l = 10, 6, 3
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    flt = ctx.filter(capi.params_init(k, s, l), table)
+    gs = synth.clade_genome_set(24, 300000)
+    seq = np.concatenate([b for _, b in gs])
+    rec_off = np.arange(25, dtype=np.uint64) * 300000
+    sk = ctx.sketch_batch(flt, seq, rec_off, np.arange(25, dtype=np.uint64))
+    gh, goff = sk.download()
+    want_parts = [ok.sketch_records(param, table, b, np.array([0, len(b)], dtype=np.uint64)) for _, b in gs]
+    want_h = np.concatenate(want_parts).astype(np.uint32)
+    want_off = np.concatenate([[0], np.cumsum([len(p) for p in want_parts])]).astype(np.uint64)
+    assert np.array_equal(gh, want_h) and np.array_equal(goff, want_off)
+    idx = ctx.index_build(sk, 28)
+    postings, counts = ok.index_build32(want_h, want_off, 28)
+    p2, _ = idx.export(want_counts=False)
+    assert np.array_equal(p2, postings)
+    want, _ = ok.index_dist32(counts, 28, postings, np.diff(want_off).astype(np.uint32), want_h, want_off,
+                              1, 0, 20, 0.05)
+    mine, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05)
+    assert len(want) >= 45 * 2  # two full clades of 10 strains
+    assert_hits_equal(mine, want)
