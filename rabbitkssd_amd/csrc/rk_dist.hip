@@ -20,6 +20,9 @@
 namespace {
 
 constexpr int kDistThreads = 256;
+constexpr int kRangeChunk = 512;   // posting ranges staged in LDS per pass (4 KiB)
+constexpr int kUnroll = 4;         // independent posting gathers in flight per lane
+constexpr int kRowsPerXcdChunk = 16;
 
 struct DistArgs {
     const uint2 *ranges;      // per query element: [x,y) slice of postings
@@ -28,7 +31,7 @@ struct DistArgs {
     const uint32_t *ref_sizes;
     uint32_t n_query, n_ref;
     uint32_t row_first, row_step, n_rows;
-    uint32_t tile_cols;
+    uint32_t tile_cols, cnt_words;
     int triangle, metric, kmer_size, dense_mode;
     double max_dist;
     rk_hit *hits;
@@ -62,36 +65,80 @@ __device__ inline void rk_distance(int common, int size0, int size1, int metric,
     }
 }
 
+// U16: two 16-bit counters per LDS word.  Valid when no count can reach 65536, i.e. the
+// largest query sketch has < 65536 hashes (a count never exceeds |S_q|); halves the LDS row
+// and doubles the resident rows per CU.
+template <bool U16>
 __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
 {
-    extern __shared__ uint32_t cnt[];
+    extern __shared__ uint32_t lds[];
+    uint32_t *cnt = lds;
+    uint2 *srange = reinterpret_cast<uint2 *>(lds + a.cnt_words);
     const uint32_t tid = threadIdx.x;
-    const uint32_t row = a.row_first + blockIdx.x * a.row_step;
+
+    // blockIdx.x -> row slot.  Workgroups are dealt round-robin over the 8 XCDs, so slots
+    // b, b+8, ... share an L2: give each XCD runs of 16 consecutive rows (strains of one
+    // clade share their posting lists) while keeping heavy (early) rows spread over all XCDs.
+    const uint32_t xcd = blockIdx.x & 7, s8 = blockIdx.x >> 3;
+    const uint32_t slot = ((s8 / kRowsPerXcdChunk) * 8 + xcd) * kRowsPerXcdChunk + s8 % kRowsPerXcdChunk;
+    if (slot >= a.n_rows) return;
+    const uint32_t row = a.row_first + slot * a.row_step;
     const uint32_t col0 = blockIdx.y * a.tile_cols;
     const uint32_t col1 = min(a.n_ref, col0 + a.tile_cols);
     const uint32_t ncol = col1 - col0;
     // tile entirely at or below the diagonal: nothing to report (uniform exit)
     if (a.triangle && col1 <= row + 1 && !a.common_dense) return;
 
-    for (uint32_t i = tid; i < ncol; i += kDistThreads) cnt[i] = 0;  // memset row, :179
-    __syncthreads();
+    for (uint32_t i = tid; i < a.cnt_words; i += kDistThreads) cnt[i] = 0;  // memset row, :179
 
     const uint64_t e0 = a.q_off[row], e1 = a.q_off[row + 1];
     const uint32_t grp = tid >> 3, sub = tid & 7;
     const bool tri_filter = a.triangle && !a.common_dense;
-    for (uint64_t e = e0 + grp; e < e1; e += kDistThreads / 8) {  // :194-203
-        const uint2 rg = a.ranges[e];
-        for (uint32_t k = rg.x + sub; k < rg.y; k += 8) {
-            const uint32_t id = a.postings[k];
-            const uint32_t c = id - col0;
-            if (c < ncol && !(tri_filter && id <= row)) atomicAdd(&cnt[c], 1u);
+    const uint32_t lo_id = tri_filter ? row + 1 : 0;  // ids below are not needed (j > i)
+
+    auto bump = [&](uint32_t id) {
+        const uint32_t c = id - col0;
+        if (c < ncol && id >= lo_id) {
+            if (U16) atomicAdd(&cnt[c >> 1], (c & 1) ? 0x10000u : 1u);
+            else atomicAdd(&cnt[c], 1u);
+        }
+    };
+
+    for (uint64_t cb = e0; cb < e1; cb += kRangeChunk) {  // :194-203
+        const uint32_t n = (uint32_t)min<uint64_t>(kRangeChunk, e1 - cb);
+        __syncthreads();  // previous chunk fully consumed (and the row zeroed)
+        for (uint32_t i = tid; i < n; i += kDistThreads) srange[i] = a.ranges[cb + i];
+        __syncthreads();
+        for (uint32_t base = 0; base < n; base += (kDistThreads / 8) * kUnroll) {
+            uint2 rg[kUnroll];
+            uint32_t id[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {
+                const uint32_t i = base + grp + (kDistThreads / 8) * u;
+                rg[u] = i < n ? srange[i] : make_uint2(0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++) {  // first 8 postings of 4 lists: 4 gathers in flight
+                const uint32_t k = rg[u].x + sub;
+                id[u] = k < rg[u].y ? a.postings[k] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++)
+                if (id[u] != 0xFFFFFFFFu) bump(id[u]);
+#pragma unroll
+            for (int u = 0; u < kUnroll; u++)  // tails of lists longer than 8
+                for (uint32_t k = rg[u].x + sub + 8; k < rg[u].y; k += 8) bump(a.postings[k]);
         }
     }
     __syncthreads();
 
+    auto count_at = [&](uint32_t c) -> uint32_t {
+        return U16 ? (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu : cnt[c];
+    };
+
     if (a.common_dense) {
         int32_t *dst = a.common_dense + (size_t)row * a.n_ref + col0;
-        for (uint32_t i = tid; i < ncol; i += kDistThreads) dst[i] = (int32_t)cnt[i];
+        for (uint32_t i = tid; i < ncol; i += kDistThreads) dst[i] = (int32_t)count_at(i);
     }
 
     const int qsize = (int)(e1 - e0);
@@ -103,7 +150,7 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
         int common = 0, size0 = 0, size1 = 0;
         double jorc = 0.0, dist = 1.0;
         if (j >= jbeg && j < col1) {
-            common = (int)cnt[j - col0];
+            common = (int)count_at(j - col0);
             // common == 0 gives dist == 1.0 exactly in both metrics; in sparse mode the
             // threshold excludes 1.0, so the pair cannot be reported
             if (a.dense_mode || common) {
@@ -116,13 +163,13 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
         }
         const unsigned long long m = __ballot(pass);
         if (m) {
-            unsigned long long slot = 0;
+            unsigned long long slot_h = 0;
             const int leader = __ffsll((long long)m) - 1;
-            if ((int)lane == leader) slot = atomicAdd(a.n_hits, (unsigned long long)__popcll(m));
-            slot = __shfl(slot, leader);
+            if ((int)lane == leader) slot_h = atomicAdd(a.n_hits, (unsigned long long)__popcll(m));
+            slot_h = __shfl(slot_h, leader);
             if (pass) {
-                slot += __popcll(m & ((1ULL << lane) - 1));
-                if (slot < a.cap) {
+                slot_h += __popcll(m & ((1ULL << lane) - 1));
+                if (slot_h < a.cap) {
                     rk_hit h;
                     h.row = row;
                     h.col = j;
@@ -132,7 +179,7 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
                     h.pad_ = 0;
                     h.jorc = jorc;
                     h.dist = dist;
-                    a.hits[slot] = h;
+                    a.hits[slot_h] = h;
                 }
             }
         }
@@ -140,12 +187,14 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
 }
 
 struct Plan {
-    uint32_t n_rows, tile_cols, n_tiles;
+    uint32_t n_rows, tile_cols, n_tiles, cnt_words;
     size_t lds_bytes;
     int dense_mode;
+    bool u16;
 };
 
-int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, const rk_dist_opts *o, Plan *p)
+int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_query_size,
+              const rk_dist_opts *o, Plan *p)
 {
     if (o->kmer_size <= 0) return rk_fail(ctx, RK_ERR_ARG, "kmer_size must be positive");
     if (o->metric != 0 && o->metric != 1) return rk_fail(ctx, RK_ERR_ARG, "metric must be 0 or 1");
@@ -153,7 +202,9 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, const rk_dist_
     p->n_rows = o->row_first < n_query ? (n_query - o->row_first + step - 1) / step : 0;
     // counter row in LDS; tile the reference range when it does not fit.  40 KiB rows let
     // four workgroups share a CU, which hides the posting-gather latency.
-    const uint32_t max_cols = (uint32_t)((ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) / 4);
+    p->u16 = max_query_size < 65536;
+    const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - kRangeChunk * sizeof(uint2);
+    const uint32_t max_cols = (uint32_t)(p->u16 ? lds_cap / 2 : lds_cap / 4) & ~63u;
     uint32_t tile = idx->n_ref ? idx->n_ref : 1;
     if (tile > max_cols) {
         const uint32_t nt = (idx->n_ref + max_cols - 1) / max_cols;
@@ -161,7 +212,8 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, const rk_dist_
     }
     p->tile_cols = tile;
     p->n_tiles = idx->n_ref ? (idx->n_ref + tile - 1) / tile : 1;
-    p->lds_bytes = (size_t)tile * 4;
+    p->cnt_words = ((p->u16 ? (tile + 1) / 2 : tile) + 1) & ~1u;  // keeps srange 8-byte aligned
+    p->lds_bytes = (size_t)p->cnt_words * 4 + kRangeChunk * sizeof(uint2);
     // does a pair with distance exactly 1.0 (common == 0) pass the threshold?
     p->dense_mode = o->triangle ? (1.0 < o->max_dist) : (1.0 <= o->max_dist);
     return RK_OK;
@@ -183,6 +235,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.row_step = o->row_step ? o->row_step : 1;
     a.n_rows = p.n_rows;
     a.tile_cols = p.tile_cols;
+    a.cnt_words = p.cnt_words;
     a.triangle = o->triangle;
     a.metric = o->metric;
     a.kmer_size = o->kmer_size;
@@ -192,11 +245,13 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.cap = cap;
     a.n_hits = n_hits_dev;
     a.common_dense = dense_dev;
+    void (*kern)(DistArgs) = p.u16 ? rk_dist_kernel<true> : rk_dist_kernel<false>;
     if (p.lds_bytes > 48 * 1024)
-        RK_HIP(ctx, hipFuncSetAttribute((const void *)rk_dist_kernel,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-    hipLaunchKernelGGL(rk_dist_kernel, dim3(p.n_rows, p.n_tiles), dim3(kDistThreads), p.lds_bytes,
-                       stream, a);
+        RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)p.lds_bytes));
+    const uint32_t per = 8 * kRowsPerXcdChunk;  // grid padded to whole XCD chunks
+    const uint32_t gx = (p.n_rows + per - 1) / per * per;
+    hipLaunchKernelGGL(kern, dim3(gx, p.n_tiles), dim3(kDistThreads), p.lds_bytes, stream, a);
     RK_HIP(ctx, hipGetLastError());
     return RK_OK;
 }
@@ -216,7 +271,7 @@ int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *querie
     if (!opts->triangle || !idx->d_selfrange)
         return rk_fail(ctx, RK_ERR_ARG, "queries == NULL needs triangle=1 and an index built by rk_index_build");
     Plan p;
-    int rc = make_plan(ctx, idx, idx->n_ref, opts, &p);
+    int rc = make_plan(ctx, idx, idx->n_ref, idx->max_src_size, opts, &p);
     if (rc) return rc;
     return launch_dist(ctx, idx, idx->d_selfrange, idx->d_src_off, idx->n_ref, opts, p, hits_dev,
                        hits_cap, (unsigned long long *)n_hits_dev, nullptr, (hipStream_t)stream);
@@ -237,7 +292,13 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
         return rk_fail(ctx, RK_ERR_ARG, "triangle mode needs the indexed sketches as queries (%u vs %u)",
                        n_query, idx->n_ref);
     Plan p;
-    int rc = make_plan(ctx, idx, n_query, opts, &p);
+    uint64_t max_q = idx->max_src_size;
+    if (queries) {
+        max_q = 0;
+        for (uint32_t g = 0; g < queries->n; g++)
+            max_q = std::max<uint64_t>(max_q, queries->h_off[g + 1] - queries->h_off[g]);
+    }
+    int rc = make_plan(ctx, idx, n_query, max_q, opts, &p);
     if (rc) return rc;
 
     // posting ranges of every query hash: precomputed for the self join, resolved through

@@ -14,8 +14,8 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
 #include <cstdlib>
-#include <cstring>
 
 #include "rk_internal.h"
 
@@ -105,7 +105,14 @@ __global__ void k_sum_sq(const uint32_t *upos, uint64_t U, unsigned long long *a
         v = c * c;
     }
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(acc, v);
+    __shared__ unsigned long long part[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kThreads / 64; w++) t += part[w];
+        if (t) atomicAdd(acc, t);
+    }
 }
 
 // ---- import/export of the dense .index array --------------------------------------
@@ -231,6 +238,8 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     idx->n_ref = s->n;
     idx->H = H;
     idx->hash_bits = hash_bits;
+    for (uint32_t g = 0; g < s->n; g++)
+        idx->max_src_size = std::max<uint64_t>(idx->max_src_size, s->h_off[g + 1] - s->h_off[g]);
     struct Guard { rk_index *p; ~Guard() { if (p) rk_index_free(p); } } guard{idx};
 
     RK_HIP(ctx, hipMalloc((void **)&idx->d_sizes, ((size_t)s->n + 1) * 4));
@@ -377,7 +386,7 @@ int rk_index_export(const rk_index *idx, uint32_t *postings, uint32_t *counts)
 namespace {
 struct BlobHeader {
     uint64_t magic, bytes;
-    uint64_t H, U, sum_sq;
+    uint64_t H, U, sum_sq, max_src_size;
     uint32_t n_ref, has_self;
     int32_t hash_bits, dir_bits, dir_shift, pad_;
     uint64_t off_postings, off_uhash, off_upos, off_dir, off_sizes, off_self, off_src;
@@ -392,6 +401,7 @@ void blob_layout(const rk_index *idx, BlobHeader *h)
     h->H = idx->H;
     h->U = idx->U;
     h->sum_sq = idx->sum_sq;
+    h->max_src_size = idx->max_src_size;
     h->n_ref = idx->n_ref;
     h->has_self = idx->d_selfrange ? 1 : 0;
     h->hash_bits = idx->hash_bits;
@@ -463,6 +473,7 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
     idx->H = h.H;
     idx->U = h.U;
     idx->sum_sq = h.sum_sq;
+    idx->max_src_size = h.max_src_size;
     idx->hash_bits = h.hash_bits;
     idx->dir_bits = h.dir_bits;
     idx->dir_shift = h.dir_shift;

@@ -54,8 +54,9 @@ struct rk_filter {
     rk_ctx *ctx = nullptr;
     rk_params params{};
     int32_t *d_table = nullptr;   // the full .shuf table, int32[16^half_subk]
-    uint32_t *d_bitmap = nullptr; // pre-filter, 2^bitmap_bits bits
+    uint32_t *d_bitmap = nullptr; // 64 KiB LDS filter image (bitmap [+ exact key/value table])
     int bitmap_bits = 0;
+    bool exact = false;           // image holds the exact table: survivors never leave the CU
     uint32_t n_keys = 0;          // entries with value in [dim_start, dim_end)
 };
 
@@ -77,6 +78,7 @@ struct rk_index {
     int hash_bits = 0;
     int dir_bits = 0, dir_shift = 0;
     uint64_t sum_sq = 0;
+    uint64_t max_src_size = 0;       // largest source sketch (built index only)
     uint32_t *d_postings = nullptr;  // u32[H]   (.dict order)
     uint32_t *d_uhash = nullptr;     // u32[U]   sorted distinct hashes
     uint32_t *d_upos = nullptr;      // u32[U+1] posting offsets

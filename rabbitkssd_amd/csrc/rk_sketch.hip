@@ -29,9 +29,36 @@
 
 namespace {
 
-constexpr int kSketchThreads = 512;            // 8 waves share one LDS bitmap
+constexpr int kSketchThreads = 1024;           // 16 waves share one LDS filter image
 constexpr int kWavesPerBlock = kSketchThreads / 64;
-constexpr int kBitmapBits = 19;                // 64 KiB of LDS
+// LDS filter image (one workgroup per CU):
+//   The inner 2*half_subk bases of a k-mer sit symmetrically inside it, so the dim_id of
+//   the canonical k-mer (src/sketch.cpp:508-509) is either d_f, the inner bases of the
+//   FORWARD window, or revcomp(d_f).  The hot loop therefore only cuts d_f out of the
+//   forward words and tests it against bitmaps of the SYMMETRISED selection
+//   {d : shuf[d] selected or shuf[revcomp(d)] selected}; reverse strand, canonical compare
+//   and dr_tuple are computed for the survivors only.
+//   bitmap A: 2^19 bits on the low 19 bits of d_f, bitmap B: 2^18 bits on its high 18 bits;
+//   a window survives if both bits are set.  With 4096 selected entries (8192 after
+//   symmetrising) a non-member passes with probability 2^-6 * 2^-5 = 0.05 %, the same
+//   order as the true-positive rate, so the divergent survivor loop handles ~1 window per
+//   1024-window wave step.
+//   EXACT mode (<= 4096 selected entries, the usual half_subk - drlevel == 3) adds an
+//   8192-slot open-addressing key table (32 KiB) + u16 values (16 KiB): survivors are
+//   confirmed without leaving the CU.  Otherwise they are confirmed against the .shuf
+//   table in HBM/L2.
+constexpr int kBitsA = 19, kBitsB = 18;
+constexpr uint32_t kWordsA = (1u << kBitsA) / 32, kWordsB = (1u << kBitsB) / 32;
+constexpr int kExactSlotsLog2 = 13;
+constexpr uint32_t kExactSlots = 1u << kExactSlotsLog2;
+constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
+constexpr size_t kFilterLdsBytes = (kWordsA + kWordsB) * 4 + kExactSlots * 4 + kExactSlots * 2;
+// per-wave staging of emitted keys in LDS: one global atomic + one coalesced store burst
+// per flush instead of one contended device-scope atomic per emitted hash
+constexpr uint32_t kStageCap = 96;
+constexpr size_t kStageLdsBytes = kWavesPerBlock * (kStageCap * 8 + 8);
+constexpr size_t kSketchLdsBytes = kFilterLdsBytes + kStageLdsBytes;
+static_assert(kSketchLdsBytes <= 160 * 1024, "LDS image must fit one CU");
 
 struct SketchArgs {
     const uint8_t *packed;
@@ -39,78 +66,123 @@ struct SketchArgs {
     const uint64_t *chunk_beg;     // byte offset of the chunk (multiple of 1024)
     const uint32_t *chunk_blocks;  // number of 1 KiB blocks; bit 31 = first chunk of its genome
     uint32_t n_chunks;
-    const uint32_t *bitmap;        // 2^kBitmapBits bits, index = dim_id & mask
+    const uint32_t *filter_image;  // kFilterLdsBytes, copied to LDS by every workgroup
     const int32_t *table;          // int32[16^half_subk]
-    uint64_t tupmask, domask, undomask0, undomask1;
-    int32_t kmer, out2, dim_start, dim_end, dr_shift, und1_shift;
+    uint64_t tupmask, undomask0, undomask1;
+    int32_t kmer, out2, dim_bits, hi_shift, dim_start, dim_end, dr_shift, und1_shift;
     unsigned long long *cand;
     unsigned long long cand_cap;
     unsigned long long *n_cand;
     unsigned long long *n_windows;
 };
 
-// low 64 bits of the 96-bit string w2:w1:w0 shifted right by sh (0 <= sh < 64)
+// low 64 bits of the 96-bit string w2:w1:w0 shifted right by sh (0 <= sh < 96)
 __device__ inline uint64_t ext96(uint32_t w2, uint32_t w1, uint32_t w0, int sh)
 {
     const uint64_t lo = ((uint64_t)w1 << 32) | w0;
     const uint64_t hi = ((uint64_t)w2 << 32) | w1;
     if (sh == 0) return lo;
     if (sh < 32) return (lo >> sh) | ((uint64_t)w2 << (64 - sh));
-    return hi >> (sh - 32);
+    if (sh < 64) return hi >> (sh - 32);
+    return (uint64_t)(w2 >> (sh - 64));
 }
 
-// 16 ASCII bases -> F: 2-bit codes, oldest base in the top bits (same orientation as
-// `tuple`, src/sketch.cpp:498); V: bit i set when base i is one of ACGTacgt
-// (BaseMap, src/common.h:27-37).
-__device__ inline void pack16(const uint4 w, uint32_t &F, uint32_t &V)
+// low 32 bits of the same; with a compile-time sh this is one v_alignbit_b32
+__device__ inline uint32_t ext96_lo(uint32_t w2, uint32_t w1, uint32_t w0, int sh)
+{
+    if (sh < 32) return __builtin_amdgcn_alignbit(w1, w0, sh);
+    if (sh < 64) return __builtin_amdgcn_alignbit(w2, w1, sh - 32);
+    return w2 >> (sh - 64);
+}
+
+// 16 ASCII bases -> G: 2-bit codes, base i of the lane at bits 2i (the orientation of the
+// reverse strand register `rvs_tuple`, src/sketch.cpp:499, before complementing);
+// V: bit i set when base i is one of ACGTacgt (BaseMap, src/common.h:27-37).
+__device__ inline void pack16(const uint4 w, uint32_t &G, uint32_t &V)
 {
     const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-    F = 0;
-    V = 0;
+    uint32_t y[4];
+    G = 0;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         const uint32_t x = ws[d] | 0x20202020u;  // fold case
-        // a,c,g,t = 0x61,0x63,0x67,0x74 -> 0,1,2,3
+        // a,c,g,t = 0x61,0x63,0x67,0x74 -> 0,1,2,3 in bits 1:0 of every byte
         const uint32_t t = ((x >> 1) & 0x03030303u) ^ ((x >> 2) & 0x01010101u);
-        F |= ((t * 0x40100401u) >> 24) << (24 - 8 * d);
-        // exact per-byte "is nonzero" (bit 7) for x ^ pattern; no cross-byte carries
-        uint32_t nz = 0x80808080u;
+        const uint32_t r = t | (t >> 6);
+        G |= ((r | (r >> 12)) & 0xFFu) << (8 * d);
+        // valid <=> the byte equals the letter its code stands for: one v_perm_b32 looks
+        // up "acgt"[code] for all four bytes
+        y[d] = x ^ __builtin_amdgcn_perm(0x74676361u, 0x74676361u, t);
+    }
+    V = 0xFFFFu;
+    if ((y[0] | y[1] | y[2] | y[3]) != 0) {  // some byte is not a base (N, separator, padding): rare
+        V = 0;
 #pragma unroll
-        for (int pi = 0; pi < 4; pi++) {
-            const uint32_t pat = pi == 0 ? 0x61616161u : pi == 1 ? 0x63636363u
-                               : pi == 2 ? 0x67676767u : 0x74747474u;
-            const uint32_t y = x ^ pat;
-            nz &= ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;
+        for (int d = 0; d < 4; d++) {
+            const uint32_t nz = ((y[d] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y[d];  // bit 7 <=> byte != 0, exact
+            const uint32_t f = ((~nz) >> 7) & 0x01010101u;                    // 1 per valid byte
+            V |= ((f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu) << (4 * d);
         }
-        const uint32_t f = ((~nz) >> 7) & 0x01010101u;  // 1 per valid byte
-        V |= ((f * 0x10204080u) >> 28) << (4 * d);
     }
 }
 
-// complement of the 2-bit-group reversal: base i of the lane at bits 2i (rvs_tuple
-// orientation, src/sketch.cpp:499)
-__device__ inline uint32_t revcomp32(uint32_t F)
+// 2-bit-group reversal: base i moves from bits 2i to bits 2(15-i) (the orientation of
+// `tuple`, src/sketch.cpp:498)
+__device__ inline uint32_t rev2(uint32_t G)
 {
-    const uint32_t b = __brev(F);
-    return ~(((b >> 1) & 0x55555555u) | ((b & 0x55555555u) << 1));
+    const uint32_t b = __brev(G);
+    return ((b >> 1) & 0x55555555u) | ((b & 0x55555555u) << 1);
 }
 
-template <int KS>
+// value of lane-1 (DPP wave_shr:1); lane 0 receives lane0_val
+__device__ inline uint32_t wave_shr1(uint32_t v, uint32_t lane0_val)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_val, (int)v, 0x138, 0xF, 0xF, false);
+}
+
+// KS/OUT2: compile-time kmer_size and 2*half_outctx_len (0/-1: taken from the arguments)
+template <int KS, int OUT2, bool EXACT>
 __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
 {
-    extern __shared__ uint32_t bm[];
+    extern __shared__ uint32_t lds[];
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.bitmap);
-        uint4 *dst = reinterpret_cast<uint4 *>(bm);
-        for (uint32_t i = threadIdx.x; i < (1u << kBitmapBits) / 128; i += kSketchThreads) dst[i] = src[i];
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.filter_image);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (uint32_t i = threadIdx.x; i < kFilterLdsBytes / 16; i += kSketchThreads) dst[i] = src[i];
     }
+    const uint32_t *bmA = lds;
+    const uint32_t *bmB = lds + kWordsA;
+    const uint32_t *keys = lds + kWordsA + kWordsB;
+    const uint16_t *vals = reinterpret_cast<const uint16_t *>(keys + kExactSlots);
+    unsigned long long *stage = reinterpret_cast<unsigned long long *>(lds + kFilterLdsBytes / 4) +
+                                (threadIdx.x >> 6) * (kStageCap + 1);
+    uint32_t *stage_n = reinterpret_cast<uint32_t *>(stage + kStageCap);
+    if ((threadIdx.x & 63) == 0) *stage_n = 0;
     __syncthreads();
 
     const int k = KS ? KS : a.kmer;
+    const int out2 = KS ? OUT2 : a.out2;
+    const uint32_t dim_mask = (1u << a.dim_bits) - 1;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t bm_mask = (1u << kBitmapBits) - 1;
     unsigned long long windows = 0;
+    uint32_t staged = 0;  // wave-uniform: keys in this wave's staging buffer
+
+    // wave-level flush of the staged keys (all 64 lanes call it together)
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t n = min(*(volatile uint32_t *)stage_n, kStageCap);
+        if (n) {
+            unsigned long long basep = 0;
+            if (lane == 0) basep = atomicAdd(a.n_cand, (unsigned long long)n);
+            basep = __shfl(basep, 0);
+            for (uint32_t i = lane; i < n; i += 64)
+                if (basep + i < a.cand_cap) a.cand[basep + i] = stage[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane == 0) *(volatile uint32_t *)stage_n = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    };
 
     for (uint32_t c = blockIdx.x * kWavesPerBlock + wave; c < a.n_chunks; c += gridDim.x * kWavesPerBlock) {
         const uint32_t gid = a.chunk_gid[c];
@@ -120,86 +192,112 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
         const uint8_t *base = a.packed + beg;
 
         // words of the two 16-base groups before the chunk (lanes "-2" and "-1")
-        uint32_t cF2 = 0, cF1 = 0, cV2 = 0, cV1 = 0;
+        uint32_t cG2 = 0, cG1 = 0, cV2 = 0, cV1 = 0;
         if (!(nbf >> 31)) {
             uint4 w = make_uint4(0, 0, 0, 0);
             if (lane < 2) w = *reinterpret_cast<const uint4 *>(base - 32 + 16 * lane);
-            uint32_t F, V;
-            pack16(w, F, V);
-            cF2 = __shfl(F, 0); cF1 = __shfl(F, 1);
-            cV2 = __shfl(V, 0); cV1 = __shfl(V, 1);
+            uint32_t G, V;
+            pack16(w, G, V);
+            cG2 = __builtin_amdgcn_readlane(G, 0); cG1 = __builtin_amdgcn_readlane(G, 1);
+            cV2 = __builtin_amdgcn_readlane(V, 0); cV1 = __builtin_amdgcn_readlane(V, 1);
         }
 
+        // two blocks of prefetch; the index is clamped instead of branching so the compiler
+        // keeps the loads in flight across the loop body
         uint4 cur = *reinterpret_cast<const uint4 *>(base + 16 * lane);
+        uint4 nx1 = *reinterpret_cast<const uint4 *>(base + (size_t)min(1u, nb - 1) * 1024 + 16 * lane);
         for (uint32_t b = 0; b < nb; b++) {
-            uint4 nxt = make_uint4(0, 0, 0, 0);
-            if (b + 1 < nb) nxt = *reinterpret_cast<const uint4 *>(base + (size_t)(b + 1) * 1024 + 16 * lane);
+            const uint4 nx2 = *reinterpret_cast<const uint4 *>(base + (size_t)min(b + 2, nb - 1) * 1024 + 16 * lane);
 
-            uint32_t F, V;
-            pack16(cur, F, V);
-            uint32_t F1 = __shfl_up(F, 1), F2 = __shfl_up(F, 2);
-            uint32_t V1 = __shfl_up(V, 1), V2 = __shfl_up(V, 2);
-            if (lane == 0) { F1 = cF1; F2 = cF2; V1 = cV1; V2 = cV2; }
-            if (lane == 1) { F2 = cF1; V2 = cV1; }
-            cF2 = __shfl(F, 62); cF1 = __shfl(F, 63);
-            cV2 = __shfl(V, 62); cV1 = __shfl(V, 63);
-            const uint32_t R = revcomp32(F), R1 = revcomp32(F1), R2 = revcomp32(F2);
+            uint32_t G, V;
+            uint32_t emitted = 0;  // keys this lane staged in this step
+            pack16(cur, G, V);
+            const uint32_t G1 = wave_shr1(G, cG1), G2 = wave_shr1(G1, cG2);
+            const uint32_t V1 = wave_shr1(V, cV1), V2 = wave_shr1(V1, cV2);
+            cG2 = __builtin_amdgcn_readlane(G, 62); cG1 = __builtin_amdgcn_readlane(G, 63);
+            cV2 = __builtin_amdgcn_readlane(V, 62); cV1 = __builtin_amdgcn_readlane(V, 63);
 
             // bad[j]: the window ending at base j of this lane contains an invalid base
-            uint64_t inv = (uint64_t)(~V2 & 0xFFFFu) | ((uint64_t)(~V1 & 0xFFFFu) << 16) |
-                           ((uint64_t)(~V & 0xFFFFu) << 32);
-            int covered = 1;
-            while (covered * 2 <= k) { inv |= inv << covered; covered *= 2; }
-            if (k > covered) inv |= inv << (k - covered);
-            const uint32_t bad = (uint32_t)(inv >> 32) & 0xFFFFu;
+            uint32_t bad = 0;
+            if ((V & V1 & V2) != 0xFFFFu) {
+                uint64_t inv = (uint64_t)(~V2 & 0xFFFFu) | ((uint64_t)(~V1 & 0xFFFFu) << 16) |
+                               ((uint64_t)(~V & 0xFFFFu) << 32);
+                int covered = 1;
+                while (covered * 2 <= k) { inv |= inv << covered; covered *= 2; }
+                if (k > covered) inv |= inv << (k - covered);
+                bad = (uint32_t)(inv >> 32) & 0xFFFFu;
+            }
             windows += __popc(~bad & 0xFFFFu);
 
+            // level 1 (all 16 windows, branch-free).  x = inner bases of the window ending at
+            // base j in the G orientation (= complement of the reverse strand's inner bases).
+            // The selection bitmaps are symmetric under reverse complement and stored
+            // pre-complemented, so x indexes them directly: bitmap A on the low bits.
             uint32_t maybe = 0;
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                const uint64_t tuple = ext96(F2, F1, F, 2 * (15 - j)) & a.tupmask;
-                const uint64_t rvs = ext96(R, R1, R2, 2 * (33 + j - k)) & a.tupmask;
-                const uint64_t uni = tuple < rvs ? tuple : rvs;                 // :508
-                const uint32_t dim = (uint32_t)((uni & a.domask) >> a.out2);    // :509
-                const uint32_t ix = dim & bm_mask;
-                maybe |= ((bm[ix >> 5] >> (ix & 31)) & 1u) << j;
+                const uint32_t x = ext96_lo(G, G1, G2, 2 * (33 + j - k) + out2) & dim_mask;
+                const uint32_t ia = x & ((1u << kBitsA) - 1);
+                maybe |= ((bmA[ia >> 5] >> (ia & 31)) & 1u) << j;
             }
             maybe &= ~bad;
 
-            while (maybe) {  // ~1 window in 16^drlevel gets here
+            // level 2 (1.6 % of the windows): bitmap B on the high bits, then the full
+            // reference arithmetic for the ~0.05 % that pass both
+            while (maybe) {
                 const int j = __ffs((int)maybe) - 1;
                 maybe &= maybe - 1;
-                const uint64_t tuple = ext96(F2, F1, F, 2 * (15 - j)) & a.tupmask;
-                const uint64_t rvs = ext96(R, R1, R2, 2 * (33 + j - k)) & a.tupmask;
-                const uint64_t uni = tuple < rvs ? tuple : rvs;
-                const uint32_t dim = (uint32_t)((uni & a.domask) >> a.out2);
-                const int32_t v = a.table[dim];
+                const int sh = 2 * (33 + j - k) + out2;  // 2..94
+                const uint32_t wa = sh < 32 ? G2 : (sh < 64 ? G1 : G);
+                const uint32_t wb = sh < 32 ? G1 : (sh < 64 ? G : 0u);
+                const uint32_t x = __builtin_amdgcn_alignbit(wb, wa, sh & 31) & dim_mask;
+                const uint32_t ib = x >> a.hi_shift;
+                if (!((bmB[ib >> 5] >> (ib & 31)) & 1u)) continue;
+                const uint32_t F = rev2(G), F1 = rev2(G1), F2 = rev2(G2);   // forward strand words
+                const uint64_t tuple = ext96(F2, F1, F, 2 * (15 - j)) & a.tupmask;          // :498
+                const uint64_t rvs = ext96(~G, ~G1, ~G2, 2 * (33 + j - k)) & a.tupmask;    // :499
+                const uint64_t uni = tuple < rvs ? tuple : rvs;                            // :508
+                const uint32_t dim = (uint32_t)(uni >> out2) & dim_mask;                   // :509
+                int32_t v = -1;
+                if (EXACT) {
+                    uint32_t slot = (dim * 0x9E3779B1u) >> (32 - kExactSlotsLog2);
+                    for (;;) {
+                        const uint32_t kk = keys[slot];
+                        if (kk == dim) { v = (int32_t)vals[slot] + a.dim_start; break; }
+                        if (kk == kEmptyKey) break;
+                        slot = (slot + 1) & (kExactSlots - 1);
+                    }
+                } else {
+                    v = a.table[dim];
+                }
                 if (v >= a.dim_start && v < a.dim_end) {                        // :341,:516
                     const uint64_t pf = (uint64_t)(v - a.dim_start);            // :519-521
                     const uint64_t dr = (((uni & a.undomask0) | ((uni & a.undomask1) << a.und1_shift)) >>
                                          a.dr_shift) | pf;                      // :524
-                    const unsigned long long slot = atomicAdd(a.n_cand, 1ULL);
-                    if (slot < a.cand_cap) a.cand[slot] = ((unsigned long long)gid << 32) | (uint32_t)dr;
+                    const unsigned long long key = ((unsigned long long)gid << 32) | (uint32_t)dr;
+                    const uint32_t sl = atomicAdd(stage_n, 1u);
+                    emitted++;
+                    if (sl < kStageCap) stage[sl] = key;
+                    else {  // staging full inside one block (low-complexity sequence): go direct
+                        const unsigned long long slot = atomicAdd(a.n_cand, 1ULL);
+                        if (slot < a.cand_cap) a.cand[slot] = key;
+                    }
                 }
             }
-            cur = nxt;
+            for (uint32_t lvl = 1; ; lvl++) {  // wave-uniform count of staged keys, no LDS round trip
+                const unsigned long long m = __ballot(emitted >= lvl);
+                if (!m) break;
+                staged += __popcll(m);
+            }
+            cur = nx1;
+            nx1 = nx2;
+            if (staged >= kStageCap / 2) { flush(); staged = 0; }
         }
+        flush();
+        staged = 0;
     }
     for (int o = 32; o > 0; o >>= 1) windows += __shfl_down(windows, o);
     if (lane == 0 && windows) atomicAdd(a.n_windows, windows);
-}
-
-__global__ void k_build_bitmap(const int32_t *table, uint64_t n, int32_t dim_start, int32_t dim_end,
-                               uint32_t *bitmap, uint32_t mask, uint32_t *n_keys)
-{
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const int32_t v = table[t];
-    if (v >= dim_start && v < dim_end) {
-        const uint32_t ix = (uint32_t)t & mask;
-        atomicOr(&bitmap[ix >> 5], 1u << (ix & 31));
-        atomicAdd(n_keys, 1u);
-    }
 }
 
 __global__ void k_split_keys(const unsigned long long *ukeys, uint64_t n, uint32_t *hashes)
@@ -225,17 +323,15 @@ __global__ void k_genome_offsets(const unsigned long long *ukeys, uint64_t n, ui
 inline unsigned blocks_for(uint64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 
 typedef void (*sketch_kernel_t)(SketchArgs);
-sketch_kernel_t pick_kernel(int kmer)
+sketch_kernel_t pick_kernel(int kmer, int out2, bool exact)
 {
-    switch (kmer) {
-    case 16: return rk_sketch_kernel<16>;
-    case 20: return rk_sketch_kernel<20>;
-    default: return rk_sketch_kernel<0>;
-    }
+    if (kmer == 20 && out2 == 8) return exact ? rk_sketch_kernel<20, 8, true> : rk_sketch_kernel<20, 8, false>;   // K10 S6
+    if (kmer == 20 && out2 == 6) return exact ? rk_sketch_kernel<20, 6, true> : rk_sketch_kernel<20, 6, false>;   // K10 S7
+    if (kmer == 16 && out2 == 6) return exact ? rk_sketch_kernel<16, 6, true> : rk_sketch_kernel<16, 6, false>;   // K8 S5
+    return exact ? rk_sketch_kernel<0, 0, true> : rk_sketch_kernel<0, 0, false>;
 }
 
 }  // namespace
-
 extern "C" {
 
 int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_dim, rk_filter **out)
@@ -248,27 +344,64 @@ int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_di
         return rk_fail(ctx, RK_ERR_ARG, "bad kssd parameters");
     RK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = 1ULL << (4 * p->half_subk);
+    // selected entries (value in [dim_start, dim_end)), src/sketch.cpp:338-345
+    std::vector<uint32_t> sel_key;
+    std::vector<uint32_t> sel_val;
+    for (uint64_t t = 0; t < n; t++) {
+        const int32_t v = shuffled_dim[t];
+        if (v >= p->dim_start && v < p->dim_end) {
+            sel_key.push_back((uint32_t)t);
+            sel_val.push_back((uint32_t)(v - p->dim_start));
+        }
+    }
+    const bool exact = sel_key.size() <= kExactSlots / 2 && (p->dim_end - p->dim_start) <= 65536;
+    std::vector<uint32_t> image(kFilterLdsBytes / 4, 0);
+    const int dim_bits = 4 * p->half_subk;
+    const int hi_shift = std::max(0, dim_bits - kBitsB);
+    auto revcomp_dim = [&](uint32_t d) {  // reverse complement of the 2*half_subk inner bases
+        uint32_t r = 0;
+        for (int i = 0; i < dim_bits / 2; i++) r |= ((~(d >> (2 * i))) & 3u) << (dim_bits - 2 - 2 * i);
+        return r;
+    };
+    const uint32_t dmask = (uint32_t)((1ULL << dim_bits) - 1);
+    auto set_bits = [&](uint32_t dd) {
+        // the kernel indexes with the COMPLEMENT of the reverse strand's inner bases.  The
+        // shuffle is a random permutation, so both bit fields of a selected index are uniform
+        const uint32_t d = ~dd & dmask;
+        const uint32_t ia = d & ((1u << kBitsA) - 1), ib = d >> hi_shift;
+        image[ia >> 5] |= 1u << (ia & 31);
+        image[kWordsA + (ib >> 5)] |= 1u << (ib & 31);
+    };
+    for (uint32_t key : sel_key) {
+        set_bits(key);
+        set_bits(revcomp_dim(key));
+    }
+    if (exact) {
+        uint32_t *keys = image.data() + kWordsA + kWordsB;
+        uint16_t *vals = reinterpret_cast<uint16_t *>(keys + kExactSlots);
+        for (uint32_t i = 0; i < kExactSlots; i++) keys[i] = kEmptyKey;
+        for (size_t i = 0; i < sel_key.size(); i++) {
+            uint32_t slot = (sel_key[i] * 0x9E3779B1u) >> (32 - kExactSlotsLog2);
+            while (keys[slot] != kEmptyKey) slot = (slot + 1) & (kExactSlots - 1);
+            keys[slot] = sel_key[i];
+            vals[slot] = (uint16_t)sel_val[i];
+        }
+    }
     DevBuf<int32_t> table;
-    DevBuf<uint32_t> bitmap, nkeys;
+    DevBuf<uint32_t> d_image;
     RK_HIP(ctx, table.alloc(n));
-    RK_HIP(ctx, bitmap.alloc((1u << kBitmapBits) / 32));
-    RK_HIP(ctx, nkeys.alloc(1));
+    RK_HIP(ctx, d_image.alloc(kFilterLdsBytes / 4));
     RK_HIP(ctx, hipMemcpy(table.p, shuffled_dim, n * 4, hipMemcpyHostToDevice));
-    RK_HIP(ctx, hipMemset(bitmap.p, 0, (1u << kBitmapBits) / 8));
-    RK_HIP(ctx, hipMemset(nkeys.p, 0, 4));
-    hipLaunchKernelGGL(k_build_bitmap, dim3(blocks_for(n)), dim3(256), 0, 0, table.p, n, p->dim_start,
-                       p->dim_end, bitmap.p, (1u << kBitmapBits) - 1, nkeys.p);
-    RK_HIP(ctx, hipGetLastError());
-    uint32_t nk = 0;
-    RK_HIP(ctx, hipMemcpy(&nk, nkeys.p, 4, hipMemcpyDeviceToHost));
+    RK_HIP(ctx, hipMemcpy(d_image.p, image.data(), kFilterLdsBytes, hipMemcpyHostToDevice));
     rk_filter *f = new (std::nothrow) rk_filter;
     if (!f) return RK_ERR_NOMEM;
     f->ctx = ctx;
     f->params = *p;
     f->d_table = table.release();
-    f->d_bitmap = bitmap.release();
-    f->bitmap_bits = kBitmapBits;
-    f->n_keys = nk;
+    f->d_bitmap = d_image.release();
+    f->bitmap_bits = kBitsA;
+    f->exact = exact;
+    f->n_keys = (uint32_t)sel_key.size();
     *out = f;
     return RK_OK;
 }
@@ -376,7 +509,7 @@ int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_
         total_blocks += (gend[g] - gbeg[g] + 1023) >> 10;
         total_len += gend[g] - gbeg[g];
     }
-    // aim for >= 16 chunks per CU so 256 CUs x 16 waves stay busy, 16..256 blocks each
+    // aim for >= 4 rounds of 16 chunks per CU (256 CUs x 16 waves), 16..256 blocks each
     uint64_t cb = total_blocks / ((uint64_t)ctx->num_cu * 16 * 4 + 1);
     cb = std::min<uint64_t>(256, std::max<uint64_t>(16, cb));
     std::vector<uint32_t> c_gid, c_blocks;
@@ -406,8 +539,8 @@ int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_
 
     // candidate capacity: expected survivors = windows / 16^drlevel; x2 + slack, exact retry
     uint64_t cap = 2 * (total_len >> (4 * P.drlevel)) + (uint64_t)n_genomes * 64 + 65536;
-    const size_t lds = (1u << kBitmapBits) / 8;
-    sketch_kernel_t kern = pick_kernel((int)P.kmer_size);
+    const size_t lds = kSketchLdsBytes;
+    sketch_kernel_t kern = pick_kernel((int)P.kmer_size, 2 * P.half_outctx_len, f->exact);
     RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
     DevBuf<unsigned long long> cand;
@@ -423,10 +556,11 @@ int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_
             a.chunk_beg = d_beg.p;
             a.chunk_blocks = d_blocks.p;
             a.n_chunks = n_chunks;
-            a.bitmap = f->d_bitmap;
+            a.filter_image = f->d_bitmap;
             a.table = f->d_table;
             a.tupmask = P.tupmask;
-            a.domask = P.domask;
+            a.dim_bits = 4 * P.half_subk;
+            a.hi_shift = std::max(0, 4 * P.half_subk - kBitsB);
             a.undomask0 = P.undomask0;
             a.undomask1 = P.undomask1;
             a.kmer = (int32_t)P.kmer_size;
@@ -440,7 +574,9 @@ int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_
             a.n_cand = d_counters.p;
             a.n_windows = d_counters.p + 1;
             const uint32_t want = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
-            const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu * 2 * 8);
+            // persistent: one workgroup per CU (the 156 KiB LDS image admits only one), each
+            // striding over the chunk table, so the filter image is staged once per CU
+            const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kSketchThreads), lds, stream, a);
             RK_HIP(ctx, hipGetLastError());
         }

@@ -137,6 +137,32 @@ def test_ref_vs_query_random_and_tiled_reference(ctx):
         assert_hits_equal(mine, want)
 
 
+def test_large_query_sketch_uses_32bit_counters(ctx):
+    # a query with >= 65536 hashes (3 Gb genome scale) forces the u32 LDS counter row;
+    # the same data through the u16 path (small queries) must agree on the shared rows
+    bits = 22
+    rn, rh, roff = synth.clade_sketches(2000, 500, bits, seed=12)
+    rng = np.random.default_rng(13)
+    big = np.unique(np.concatenate([rng.integers(0, 1 << bits, size=90000, dtype=np.uint64).astype(np.uint32),
+                                    rh[: int(roff[40])]]))
+    small = rh[int(roff[7]):int(roff[8])]
+    qh = np.concatenate([big, small])
+    qoff = np.array([0, len(big), len(big) + len(small)], dtype=np.uint64)
+    assert len(big) >= 65536
+    postings, counts = ok.index_build32(rh, roff, bits)
+    sizes = np.diff(roff).astype(np.uint32)
+    idx = ctx.index_build(ctx.sketches_from_host(rh, roff), bits)
+    want, wdense = ok.index_dist32(counts, bits, postings, sizes, qh, qoff, 0, 1, 20, 0.2, want_dense=True)
+    mine, dense = ctx.dist_rows(idx, ctx.sketches_from_host(qh, qoff), 0, 1, 20, 0.2, want_dense=True)
+    assert np.array_equal(dense, wdense)
+    assert wdense.max() >= 500
+    assert_hits_equal(mine, want)
+    # small query alone -> u16 path
+    q2 = ctx.sketches_from_host(small, np.array([0, len(small)], dtype=np.uint64))
+    mine2, dense2 = ctx.dist_rows(idx, q2, 0, 1, 20, 0.2, want_dense=True)
+    assert np.array_equal(dense2[0], wdense[1])
+
+
 def test_edge_cases_empty_inputs(ctx):
     off = np.array([0, 0, 3, 3], dtype=np.uint64)
     h = np.array([1, 5, 9], dtype=np.uint32)

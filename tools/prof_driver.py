@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Tiny drivers for rocprofv3 runs (kernel-trace or --pmc): one leg only, few launches.
+    python3 tools/prof_driver.py sketch [n_genomes] [length]
+    python3 tools/prof_driver.py dist [n_genomes] [steps]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from rabbitkssd_amd import capi, synth  # noqa: E402
+
+
+def sketch(n_genomes=128, length=5_000_000, steps=3):
+    from oracle import oracle as ok  # .shuf generator only
+    ctx = capi.Context(0)
+    flt = ctx.filter(capi.params_init(10, 6, 3), ok.shuffle_table(10, 6, 3))
+    stride = (length + 1023) // 1024 * 1024
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    packed = torch.zeros(n_genomes * stride, dtype=torch.uint8, device="cuda")
+    view = packed.view(n_genomes, stride)
+    for i in range(n_genomes):
+        view[i, :length] = lut[torch.randint(0, 4, (length,), generator=g, device="cuda")]
+    gbeg = np.arange(n_genomes, dtype=np.uint64) * stride
+    gend = gbeg + np.uint64(length)
+    torch.cuda.synchronize()
+    for _ in range(steps):
+        t0 = time.time()
+        sk = ctx.sketch_packed_dev(flt, packed.data_ptr(), packed.numel(), gbeg, gend, 0)
+        torch.cuda.synchronize()
+        print("sketch pass %.3f ms, %d windows, %d hashes" % ((time.time() - t0) * 1e3, sk.windows, sk.total))
+
+
+def dist(n_genomes=10000, steps=5):
+    ctx = capi.Context(0)
+    names, hashes, off = synth.clade_sketches(n_genomes, 1220, 28)
+    index = ctx.index_build(ctx.sketches_from_host(hashes, off), 28)
+    hits = torch.empty((1 << 20) * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    counters = torch.zeros(steps, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(steps):
+        ctx.dist_rows_dev(index, 1, 0, 20, 0.05, hits.data_ptr(), 1 << 20, counters.data_ptr() + 8 * i)
+    torch.cuda.synchronize()
+    print("dist %.3f ms/step, hits %d" % ((time.time() - t0) * 1e3 / steps, int(counters[0].item())))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1]
+    args = [int(x) for x in sys.argv[2:]]
+    {"sketch": sketch, "dist": dist}[which](*args)
