@@ -2,14 +2,16 @@
 // Replaces the row loops of index_tridist (src/dist.cpp:174-258) and index_dist
 // (src/dist.cpp:560-692).
 //
-// One workgroup per (query row, reference tile).  The counter row of the reference
-// (`int intersectionArr[tid][numRef]`, src/dist.cpp:167) lives in LDS; the postings of the
-// row's hashes are streamed from HBM by 8-lane groups (a posting list averages a few
-// entries, so 8 lanes x 4 B covers most lists in one 32-byte request) and scattered into
-// the LDS row with ds_add_u32.  The epilogue re-reads the LDS row, evaluates the
-// Jaccard/Mash (or containment/AafD) formula in FP64 only where a pair can pass the
-// threshold, and appends hit records with one wave-aggregated atomic per wave.
-// Integer/index work: HBM/LDS-bound, no MFMA.
+// One workgroup per (run of consecutive query rows, reference tile).  The counter row of the
+// reference (`int intersectionArr[tid][numRef]`, src/dist.cpp:167) lives in LDS, two 16-bit
+// counters per word when no count can overflow.  Per row: the posting ranges of the row's
+// hashes are staged in LDS (the next row's are prefetched into registers meanwhile), the
+// posting lists are gathered from HBM/L2 by 8-lane groups with 10 independent gathers in
+// flight per lane and scattered into the LDS row with ds_add_u32.  The epilogue scans the row
+// 16 B per lane, compacts the non-zero cells into an LDS list and evaluates the
+// Jaccard/Mash (or containment/AafD) formula in FP64 one cell per lane; reported pairs are
+// staged in LDS and flushed with one device-scope atomic per workgroup.
+// Integer/index work: bound by VALU issue, LDS atomics and gather latency -- no MFMA.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -20,9 +22,12 @@
 namespace {
 
 constexpr int kDistThreads = 256;
-constexpr int kRangeChunk = 512;   // posting ranges staged in LDS per pass (4 KiB)
-constexpr int kUnroll = 4;         // independent posting gathers in flight per lane
-constexpr int kRowsPerXcdChunk = 16;
+constexpr uint32_t kRangeChunkDefault = 640;  // posting ranges staged in LDS per pass (5 KiB)
+constexpr int kUnroll = 10;        // independent posting gathers in flight per lane
+constexpr int kPrefetch = 5;       // uint2 ranges per thread prefetched for the next row
+constexpr int kRunsPerXcdChunk = 4;    // consecutive runs (16 rows) kept on one XCD
+constexpr uint32_t kStageHitsDefault = 48;    // reported pairs staged in LDS per workgroup
+constexpr uint32_t kCandCapDefault = 256;     // non-zero cells of one row compacted in LDS
 
 struct DistArgs {
     const uint2 *ranges;      // per query element: [x,y) slice of postings
@@ -31,7 +36,8 @@ struct DistArgs {
     const uint32_t *ref_sizes;
     uint32_t n_query, n_ref;
     uint32_t row_first, row_step, n_rows;
-    uint32_t tile_cols, cnt_words;
+    uint32_t tile_cols, cnt_words, rows_per_wg;
+    uint32_t range_chunk, cand_cap, stage_hits;  // LDS carve-up (entries)
     int triangle, metric, kmer_size, dense_mode;
     double max_dist;
     rk_hit *hits;
@@ -68,126 +74,253 @@ __device__ inline void rk_distance(int common, int size0, int size1, int metric,
 // U16: two 16-bit counters per LDS word.  Valid when no count can reach 65536, i.e. the
 // largest query sketch has < 65536 hashes (a count never exceeds |S_q|); halves the LDS row
 // and doubles the resident rows per CU.
-template <bool U16>
+//
+// One workgroup handles kRowsPerWg consecutive row slots (strains of one clade share their
+// posting lists: the second row finds them in this CU's L1/L2) and stages the reported
+// pairs in LDS, so the contended device-scope atomic on the hit counter is paid once per
+// workgroup instead of once per reporting wave.
+template <bool U16, int kGroup, bool FILTER>
 __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
 {
-    extern __shared__ uint32_t lds[];
+    // one dynamic LDS region (16-byte aligned base):
+    // counter row | staged ranges | non-zero cell list | staged hits | scalars
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *cnt = lds;
     uint2 *srange = reinterpret_cast<uint2 *>(lds + a.cnt_words);
+    uint2 *cand = srange + a.range_chunk;  // non-zero cells of the current row: (col, common)
+    rk_hit *stage = reinterpret_cast<rk_hit *>(cand + a.cand_cap);
+    unsigned long long &s_base = *reinterpret_cast<unsigned long long *>(stage + a.stage_hits);
+    uint32_t &s_total = *(reinterpret_cast<uint32_t *>(stage + a.stage_hits) + 2);
+    uint32_t &s_cursor = *(reinterpret_cast<uint32_t *>(stage + a.stage_hits) + 3);
+    const uint32_t kRangeChunk = a.range_chunk, kCandCap = a.cand_cap, kStageHits = a.stage_hits;
     const uint32_t tid = threadIdx.x;
 
-    // blockIdx.x -> row slot.  Workgroups are dealt round-robin over the 8 XCDs, so slots
-    // b, b+8, ... share an L2: give each XCD runs of 16 consecutive rows (strains of one
-    // clade share their posting lists) while keeping heavy (early) rows spread over all XCDs.
+    // blockIdx.x -> run of row slots.  Workgroups are dealt round-robin over the 8 XCDs, so
+    // blocks b, b+8, ... share an L2: consecutive runs of one XCD are adjacent rows, while
+    // heavy (early) rows stay spread over all XCDs.
     const uint32_t xcd = blockIdx.x & 7, s8 = blockIdx.x >> 3;
-    const uint32_t slot = ((s8 / kRowsPerXcdChunk) * 8 + xcd) * kRowsPerXcdChunk + s8 % kRowsPerXcdChunk;
-    if (slot >= a.n_rows) return;
-    const uint32_t row = a.row_first + slot * a.row_step;
+    const uint32_t run = ((s8 / kRunsPerXcdChunk) * 8 + xcd) * kRunsPerXcdChunk + s8 % kRunsPerXcdChunk;
+    const uint32_t slot0 = run * a.rows_per_wg;
+    if (slot0 >= a.n_rows) return;
     const uint32_t col0 = blockIdx.y * a.tile_cols;
     const uint32_t col1 = min(a.n_ref, col0 + a.tile_cols);
     const uint32_t ncol = col1 - col0;
-    // tile entirely at or below the diagonal: nothing to report (uniform exit)
-    if (a.triangle && col1 <= row + 1 && !a.common_dense) return;
+    if (tid == 0) s_cursor = 0;
 
-    for (uint32_t i = tid; i < a.cnt_words; i += kDistThreads) cnt[i] = 0;  // memset row, :179
-
-    const uint64_t e0 = a.q_off[row], e1 = a.q_off[row + 1];
-    const uint32_t grp = tid >> 3, sub = tid & 7;
+    const uint32_t grp = tid / kGroup, sub = tid % kGroup;
+    constexpr uint32_t kGroups = kDistThreads / kGroup;
     const bool tri_filter = a.triangle && !a.common_dense;
-    const uint32_t lo_id = tri_filter ? row + 1 : 0;  // ids below are not needed (j > i)
+    constexpr uint32_t kPerWord = U16 ? 2 : 1;
+    const uint4 *c4 = reinterpret_cast<const uint4 *>(cnt);
 
-    auto bump = [&](uint32_t id) {
-        const uint32_t c = id - col0;
-        if (c < ncol && id >= lo_id) {
-            if (U16) atomicAdd(&cnt[c >> 1], (c & 1) ? 0x10000u : 1u);
-            else atomicAdd(&cnt[c], 1u);
+    // ranges of the NEXT row's first chunk are fetched into registers while the current row is
+    // processed, so only the first row of a run pays the HBM round trip for its ranges
+    uint2 pre[kPrefetch];
+    bool have_pre = false;
+    const uint32_t slot_end = min(a.n_rows, slot0 + a.rows_per_wg);
+
+    for (uint32_t slot = slot0; slot < slot_end; slot++) {
+        const uint32_t row = a.row_first + slot * a.row_step;
+        // tile entirely at or below the diagonal: nothing to report (uniform skip)
+        if (a.triangle && col1 <= row + 1 && !a.common_dense) { have_pre = false; continue; }
+
+        __syncthreads();  // previous row's epilogue is done with the LDS row and lists
+        {   // memset row (src/dist.cpp:179), 16 B per lane
+            uint4 *z4 = reinterpret_cast<uint4 *>(cnt);
+            for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
         }
-    };
+        if (tid == 0) s_total = 0;
 
-    for (uint64_t cb = e0; cb < e1; cb += kRangeChunk) {  // :194-203
-        const uint32_t n = (uint32_t)min<uint64_t>(kRangeChunk, e1 - cb);
-        __syncthreads();  // previous chunk fully consumed (and the row zeroed)
-        for (uint32_t i = tid; i < n; i += kDistThreads) srange[i] = a.ranges[cb + i];
+        const uint64_t e0 = a.q_off[row], e1 = a.q_off[row + 1];
+        const uint32_t first_n = (uint32_t)min<uint64_t>(kRangeChunk, e1 - e0);
+        if (have_pre) {
+#pragma unroll
+            for (int u = 0; u < kPrefetch; u++) {
+                const uint32_t i = tid + kDistThreads * u;
+                if (i < first_n) srange[i] = pre[u];
+            }
+        } else {
+            for (uint32_t i = tid; i < first_n; i += kDistThreads) srange[i] = a.ranges[e0 + i];
+        }
+        have_pre = false;
+        if (slot + 1 < slot_end) {
+            const uint32_t rown = row + a.row_step;
+            if (!(a.triangle && col1 <= rown + 1 && !a.common_dense)) {
+                const uint64_t f0 = a.q_off[rown], f1 = a.q_off[rown + 1];
+                const uint32_t nn = (uint32_t)min<uint64_t>(kRangeChunk, f1 - f0);
+#pragma unroll
+                for (int u = 0; u < kPrefetch; u++) {
+                    const uint32_t i = tid + kDistThreads * u;
+                    pre[u] = i < nn ? a.ranges[f0 + i] : make_uint2(0, 0);
+                }
+                have_pre = true;
+            }
+        }
+
+        const uint32_t lo_id = tri_filter ? row + 1 : 0;  // ids below are not needed (j > i)
+        // FILTER=false: single reference tile and ranges that already exclude ids <= row
+        // (the self-join ranges of rk_index_build), so every posting lands in the row
+        auto bump = [&](uint32_t id) {
+            const uint32_t c = id - col0;
+            if (!FILTER || (c < ncol && id >= lo_id)) {
+                if (U16) atomicAdd(&cnt[c >> 1], (c & 1) ? 0x10000u : 1u);
+                else atomicAdd(&cnt[c], 1u);
+            }
+        };
+        // walks the posting lists of the n ranges staged in LDS (src/dist.cpp:194-203):
+        // kGroup lanes per list, kUnroll independent gathers in flight per lane
+        auto gather = [&](uint32_t n) {
+            for (uint32_t base = 0; base < n; base += kGroups * kUnroll) {
+                uint2 rg[kUnroll];
+                uint32_t id[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) {
+                    const uint32_t i = base + grp + kGroups * u;
+                    rg[u] = i < n ? srange[i] : make_uint2(0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) {
+                    const uint32_t k = rg[u].x + sub;
+                    id[u] = k < rg[u].y ? a.postings[k] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++)
+                    if (id[u] != 0xFFFFFFFFu) bump(id[u]);
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++)  // tails of lists longer than the group
+                    for (uint32_t k = rg[u].x + sub + kGroup; k < rg[u].y; k += kGroup) bump(a.postings[k]);
+            }
+        };
+
+        __syncthreads();  // row zeroed, first chunk staged
+        gather(first_n);
+        for (uint64_t cb = e0 + kRangeChunk; cb < e1; cb += kRangeChunk) {  // sketches larger than one chunk
+            const uint32_t n = (uint32_t)min<uint64_t>(kRangeChunk, e1 - cb);
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += kDistThreads) srange[i] = a.ranges[cb + i];
+            __syncthreads();
+            gather(n);
+        }
         __syncthreads();
-        for (uint32_t base = 0; base < n; base += (kDistThreads / 8) * kUnroll) {
-            uint2 rg[kUnroll];
-            uint32_t id[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                const uint32_t i = base + grp + (kDistThreads / 8) * u;
-                rg[u] = i < n ? srange[i] : make_uint2(0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++) {  // first 8 postings of 4 lists: 4 gathers in flight
-                const uint32_t k = rg[u].x + sub;
-                id[u] = k < rg[u].y ? a.postings[k] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++)
-                if (id[u] != 0xFFFFFFFFu) bump(id[u]);
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++)  // tails of lists longer than 8
-                for (uint32_t k = rg[u].x + sub + 8; k < rg[u].y; k += 8) bump(a.postings[k]);
+
+        if (a.common_dense) {
+            int32_t *dst = a.common_dense + (size_t)row * a.n_ref + col0;
+            for (uint32_t i = tid; i < ncol; i += kDistThreads)
+                dst[i] = (int32_t)(U16 ? (cnt[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu : cnt[i]);
         }
-    }
-    __syncthreads();
 
-    auto count_at = [&](uint32_t c) -> uint32_t {
-        return U16 ? (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu : cnt[c];
-    };
+        // ---- epilogue (src/dist.cpp:207-255 / :600-682)
+        const int qsize = (int)(e1 - e0);
+        const uint32_t jbeg = a.triangle ? max(col0, row + 1) : col0;  // :207 / :600
 
-    if (a.common_dense) {
-        int32_t *dst = a.common_dense + (size_t)row * a.n_ref + col0;
-        for (uint32_t i = tid; i < ncol; i += kDistThreads) dst[i] = (int32_t)count_at(i);
-    }
-
-    const int qsize = (int)(e1 - e0);
-    const uint32_t jbeg = a.triangle ? max(col0, row + 1) : col0;  // :207 / :600
-    const uint32_t lane = tid & 63;
-    for (uint32_t base = jbeg - (jbeg % kDistThreads); base < col1; base += kDistThreads) {
-        const uint32_t j = base + tid;
-        bool pass = false;
-        int common = 0, size0 = 0, size1 = 0;
-        double jorc = 0.0, dist = 1.0;
-        if (j >= jbeg && j < col1) {
-            common = (int)count_at(j - col0);
-            // common == 0 gives dist == 1.0 exactly in both metrics; in sparse mode the
-            // threshold excludes 1.0, so the pair cannot be reported
-            if (a.dense_mode || common) {
-                const int rs = (int)a.ref_sizes[j];
-                size0 = a.triangle ? qsize : rs;  // :215-216 / :607-608
-                size1 = a.triangle ? rs : qsize;
-                rk_distance(common, size0, size1, a.metric, a.kmer_size, jorc, dist);
-                pass = a.triangle ? (dist < a.max_dist) : (dist <= a.max_dist);  // :232 / :624
+        // evaluates one (row, j) cell; returns true when it is reported
+        auto evaluate = [&](uint32_t j, int common, rk_hit &hrec) -> bool {
+            const int rs = (int)a.ref_sizes[j];
+            const int size0 = a.triangle ? qsize : rs;  // :215-216 / :607-608
+            const int size1 = a.triangle ? rs : qsize;
+            double jorc, dist;
+            rk_distance(common, size0, size1, a.metric, a.kmer_size, jorc, dist);
+            hrec.row = row;
+            hrec.col = j;
+            hrec.common = common;
+            hrec.size0 = size0;
+            hrec.size1 = size1;
+            hrec.pad_ = 0;
+            hrec.jorc = jorc;
+            hrec.dist = dist;
+            return a.triangle ? (dist < a.max_dist) : (dist <= a.max_dist);  // :232 / :624
+        };
+        auto stage_hit = [&](const rk_hit &hrec) {
+            const uint32_t sl = atomicAdd(&s_cursor, 1u);
+            if (sl < kStageHits) stage[sl] = hrec;
+            else {  // staging full: rare, pay the device-scope atomic per hit
+                const unsigned long long at = atomicAdd(a.n_hits, 1ULL);
+                if (at < a.cap) a.hits[at] = hrec;
             }
-        }
-        const unsigned long long m = __ballot(pass);
-        if (m) {
-            unsigned long long slot_h = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if ((int)lane == leader) slot_h = atomicAdd(a.n_hits, (unsigned long long)__popcll(m));
-            slot_h = __shfl(slot_h, leader);
-            if (pass) {
-                slot_h += __popcll(m & ((1ULL << lane) - 1));
-                if (slot_h < a.cap) {
-                    rk_hit h;
-                    h.row = row;
-                    h.col = j;
-                    h.common = common;
-                    h.size0 = size0;
-                    h.size1 = size1;
-                    h.pad_ = 0;
-                    h.jorc = jorc;
-                    h.dist = dist;
-                    a.hits[slot_h] = h;
+        };
+
+        if (!a.dense_mode) {
+            // Sparse mode: the threshold excludes distance 1.0 (== common 0), so only cells
+            // that share a hash can be reported.  Scan the LDS row 16 B per lane skipping
+            // all-zero quads, compact the non-zero cells into an LDS list, then evaluate the
+            // list one cell per lane (FP64 divide + log run in parallel, not serialised on
+            // the lane that happened to own a clade's adjacent columns).
+            const uint32_t q_first = ((jbeg - col0) / kPerWord) / 4;
+            const uint32_t q_end = ((ncol + kPerWord - 1) / kPerWord + 3) / 4;
+            for (uint32_t q = q_first + tid; q < q_end; q += kDistThreads) {
+                const uint4 v = c4[q];
+                if ((v.x | v.y | v.z | v.w) == 0) continue;
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int wi = 0; wi < 4; wi++) {
+                    if (w[wi] == 0) continue;
+#pragma unroll
+                    for (uint32_t h = 0; h < kPerWord; h++) {
+                        const uint32_t j = col0 + (q * 4 + wi) * kPerWord + h;
+                        const uint32_t common = U16 ? (w[wi] >> (16 * h)) & 0xFFFFu : w[wi];
+                        if (common == 0 || j < jbeg || j >= col1) continue;
+                        const uint32_t sl = atomicAdd(&s_total, 1u);
+                        if (sl < kCandCap) cand[sl] = make_uint2(j, common);
+                        else {  // list full: evaluate in place (slow, only for very dense rows)
+                            rk_hit hrec;
+                            if (evaluate(j, (int)common, hrec)) stage_hit(hrec);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t n_cand = min(s_total, (uint32_t)kCandCap);
+            for (uint32_t i = tid; i < n_cand; i += kDistThreads) {
+                const uint2 cj = cand[i];
+                rk_hit hrec;
+                if (evaluate(cj.x, (int)cj.y, hrec)) stage_hit(hrec);
+            }
+        } else {
+            // Dense mode: every cell of [jbeg, col1) can be reported.  One column per lane;
+            // pass 0 counts this row's reports, one atomic reserves their slots, pass 1
+            // re-evaluates and writes them.
+            for (int pass_no = 0; pass_no < 2; pass_no++) {
+                uint32_t mine = 0;
+                for (uint32_t j = jbeg + tid; j < col1; j += kDistThreads) {
+                    const uint32_t c = j - col0;
+                    const int common = (int)(U16 ? (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu : cnt[c]);
+                    rk_hit hrec;
+                    if (!evaluate(j, common, hrec)) continue;
+                    if (pass_no == 0) { mine++; continue; }
+                    const unsigned long long at = s_base + atomicAdd(&s_total, 1u);
+                    if (at < a.cap) a.hits[at] = hrec;
+                }
+                if (pass_no == 0) {
+                    if (mine) atomicAdd(&s_total, mine);
+                    __syncthreads();
+                    const uint32_t total = s_total;
+                    __syncthreads();
+                    if (total == 0) break;  // uniform
+                    if (tid == 0) { s_base = atomicAdd(a.n_hits, (unsigned long long)total); s_total = 0; }
+                    __syncthreads();
                 }
             }
         }
     }
+
+    // flush the staged hits of this workgroup: one device-scope atomic, coalesced 8-byte stores
+    __syncthreads();
+    const uint32_t n_st = min(s_cursor, (uint32_t)kStageHits);
+    if (n_st == 0) return;
+    if (tid == 0) s_base = atomicAdd(a.n_hits, (unsigned long long)n_st);
+    __syncthreads();
+    const unsigned long long at0 = s_base;
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(stage);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.hits);
+    constexpr uint32_t kW = sizeof(rk_hit) / 8;
+    for (uint32_t i = tid; i < n_st * kW; i += kDistThreads)
+        if (at0 + i / kW < a.cap) dst[at0 * kW + i] = src[i];
 }
 
 struct Plan {
     uint32_t n_rows, tile_cols, n_tiles, cnt_words;
+    uint32_t range_chunk, cand_cap, stage_hits, rows_per_wg;
+    int group;
     size_t lds_bytes;
     int dense_mode;
     bool u16;
@@ -203,7 +336,18 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // counter row in LDS; tile the reference range when it does not fit.  40 KiB rows let
     // four workgroups share a CU, which hides the posting-gather latency.
     p->u16 = max_query_size < 65536;
-    const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - kRangeChunk * sizeof(uint2);
+    auto envu = [](const char *name, uint32_t dflt) {
+        const char *v = getenv(name);
+        return v && atoi(v) > 0 ? (uint32_t)atoi(v) : dflt;
+    };
+    p->range_chunk = std::min<uint32_t>((envu("RK_DIST_RANGE_CHUNK", kRangeChunkDefault) + 1) & ~1u,
+                                        kPrefetch * kDistThreads);
+    p->cand_cap = (envu("RK_DIST_CAND_CAP", kCandCapDefault) + 1) & ~1u;
+    p->stage_hits = envu("RK_DIST_STAGE_HITS", kStageHitsDefault);
+    p->rows_per_wg = envu("RK_DIST_ROWS", 2);
+    p->group = (int)envu("RK_DIST_GROUP", 8);
+    const size_t fixed = (size_t)(p->range_chunk + p->cand_cap) * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
+    const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - fixed;
     const uint32_t max_cols = (uint32_t)(p->u16 ? lds_cap / 2 : lds_cap / 4) & ~63u;
     uint32_t tile = idx->n_ref ? idx->n_ref : 1;
     if (tile > max_cols) {
@@ -212,8 +356,8 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     }
     p->tile_cols = tile;
     p->n_tiles = idx->n_ref ? (idx->n_ref + tile - 1) / tile : 1;
-    p->cnt_words = ((p->u16 ? (tile + 1) / 2 : tile) + 1) & ~1u;  // keeps srange 8-byte aligned
-    p->lds_bytes = (size_t)p->cnt_words * 4 + kRangeChunk * sizeof(uint2);
+    p->cnt_words = ((p->u16 ? (tile + 1) / 2 : tile) + 3) & ~3u;  // whole 16-byte quads
+    p->lds_bytes = (size_t)p->cnt_words * 4 + fixed;
     // does a pair with distance exactly 1.0 (common == 0) pass the threshold?
     p->dense_mode = o->triangle ? (1.0 < o->max_dist) : (1.0 <= o->max_dist);
     return RK_OK;
@@ -245,12 +389,27 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.cap = cap;
     a.n_hits = n_hits_dev;
     a.common_dense = dense_dev;
-    void (*kern)(DistArgs) = p.u16 ? rk_dist_kernel<true> : rk_dist_kernel<false>;
+    a.rows_per_wg = p.rows_per_wg;
+    a.range_chunk = p.range_chunk;
+    a.cand_cap = p.cand_cap;
+    a.stage_hits = p.stage_hits;
+    // postings need no range check when there is one tile and the ranges are the index's own
+    // "later genomes" slices
+    const bool filter = !(p.n_tiles == 1 && ranges == idx->d_selfrange && o->triangle && !dense_dev);
+    void (*kern)(DistArgs);
+    if (p.group == 4) {
+        if (filter) kern = p.u16 ? rk_dist_kernel<true, 4, true> : rk_dist_kernel<false, 4, true>;
+        else kern = p.u16 ? rk_dist_kernel<true, 4, false> : rk_dist_kernel<false, 4, false>;
+    } else {
+        if (filter) kern = p.u16 ? rk_dist_kernel<true, 8, true> : rk_dist_kernel<false, 8, true>;
+        else kern = p.u16 ? rk_dist_kernel<true, 8, false> : rk_dist_kernel<false, 8, false>;
+    }
     if (p.lds_bytes > 48 * 1024)
         RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)p.lds_bytes));
-    const uint32_t per = 8 * kRowsPerXcdChunk;  // grid padded to whole XCD chunks
-    const uint32_t gx = (p.n_rows + per - 1) / per * per;
+    const uint32_t runs = (p.n_rows + a.rows_per_wg - 1) / a.rows_per_wg;
+    const uint32_t per = 8 * kRunsPerXcdChunk;  // grid padded to whole XCD chunks
+    const uint32_t gx = (runs + per - 1) / per * per;
     hipLaunchKernelGGL(kern, dim3(gx, p.n_tiles), dim3(kDistThreads), p.lds_bytes, stream, a);
     RK_HIP(ctx, hipGetLastError());
     return RK_OK;
