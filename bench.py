@@ -143,7 +143,7 @@ def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
-    from rabbitkssd_amd import capi, synth
+    from rabbitkssd_amd import capi, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -162,7 +162,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream().cuda_stream
 
-    n_genomes = args.genomes if args.scaling == "strong" else int(round(args.genomes * math.sqrt(world)))
+    n_genomes = args.genomes if args.scaling == "strong" else shard.weak_scaling_genomes(args.genomes, world)
     n_pairs = n_genomes * (n_genomes - 1) // 2
 
     # ---- setup (untimed): rank 0 generates the sketches and builds the index on its GPU; the
@@ -178,18 +178,17 @@ def main():
         nbytes = index.blob_bytes
     t_bcast = 0.0
     if world > 1:
-        size_t = torch.tensor([nbytes if rank == 0 else 0], dtype=torch.int64, device=dev)
-        dist.broadcast(size_t, 0)
-        nbytes = int(size_t.item())
-        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        blob = None
         if rank == 0:
+            blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             index.pack_dev(blob.data_ptr(), nbytes, stream)
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.time()
-        dist.broadcast(blob, 0)
+        blob = shard.broadcast_blob(blob, 0, dev, dist)   # ONE RCCL broadcast of the whole index
         torch.cuda.synchronize()
         t_bcast = time.time() - t0
+        nbytes = blob.numel()
         if rank != 0:
             index = ctx.index_unpack_dev(blob.data_ptr(), nbytes, stream)
         del blob
@@ -238,7 +237,7 @@ def main():
     # algorithmic bytes of one launch on this rank: 12 B per query hash (hash +
     # two index offsets) + 4 B per posting streamed (T = sum c_h^2) + 4 B per count cell
     # produced.  Rank 0 holds 1/world of the rows (interleaved -> ~1/world of each term).
-    b_alg = (12.0 * H + 4.0 * T + 4.0 * n_pairs) / world
+    b_alg = (12.0 * H + 4.0 * T) / world + 4.0 * shard.rank_pairs(n_genomes, 0, world)
     achieved = b_alg / (kernel_ms * 1e-3) / 1e9
     out = {
         "metric": "genome-pairs/sec alldist (10k bacteria, L3K10)",

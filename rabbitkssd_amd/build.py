@@ -13,6 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "librabbitkssd.so")
+TOOL = os.path.join(HERE, "rabbit_kssd")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
@@ -47,6 +48,12 @@ def build(force=False, verbose=False):
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
     if force or jobs or _newer(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    # host tool (C++ above the C ABI): rabbit_kssd with the reference's command line
+    host_src = os.path.join(HERE, "host", "rabbit_kssd.cpp")
+    host_deps = [host_src, os.path.join(HERE, "host", "formats.hpp"), os.path.join(ROOT, "include", "rabbitkssd.h"), LIB]
+    if force or _newer(TOOL, host_deps):
+        run([HIPCC, "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), host_src, "-o", TOOL,
+             "-L" + HERE, "-lrabbitkssd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     return LIB
 
 

@@ -1,0 +1,309 @@
+// formats.hpp -- host-side file formats and record reader of the rabbit_kssd tool
+// (drop-in surface of RabbitKSSD: .shuf, .sketch, .sketch.dict, .sketch.index, FASTA/Q input).
+// Written from the format description; citations are file:line into
+// the reference tree.  Host code only: no arithmetic of the hot path lives here.
+#pragma once
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+namespace rkhost {
+
+struct SketchInfo {  // sketchInfo_t, src/sketch.h:27-34 (20 bytes on disk)
+    int32_t id = 0, half_k = 0, half_subk = 0, drlevel = 0, genomeNumber = 0;
+};
+
+struct SketchSet {  // in-memory form of a .sketch file (32-bit hash layout)
+    SketchInfo info;
+    std::vector<std::string> names;
+    std::vector<uint32_t> hashes;  // CSR values
+    std::vector<uint64_t> off{0};  // CSR offsets, names.size()+1
+    size_t size() const { return names.size(); }
+};
+
+inline bool ends_with(const std::string &s, const std::string &suf)
+{
+    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+// src/sketch.cpp:163-169: a file is a sketch iff the text after the last '.' is "sketch"
+inline bool is_sketch_file(const std::string &f)
+{
+    auto p = f.find_last_of('.');
+    return p != std::string::npos && f.substr(p + 1) == "sketch";
+}
+
+inline bool exist_file(const std::string &f)
+{
+    if (FILE *fp = fopen(f.c_str(), "r")) { fclose(fp); return true; }
+    return false;
+}
+
+// ---- .shuf (src/shuffle.cpp:8-23, :25-104) -------------------------------------------
+struct Shuf {
+    int32_t id = 0, k = 0, subk = 0, drlevel = 0;
+    std::vector<int32_t> table;
+};
+
+inline bool read_shuf(const std::string &path, Shuf &out, std::string &err)
+{
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (!fp) { err = "cannot read shuffle file: " + path; return false; }
+    int32_t hdr[4];
+    if (fread(hdr, sizeof(hdr), 1, fp) != 1 || hdr[2] < 1 || hdr[2] >= 8) {
+        fclose(fp);
+        err = "error read dim_shuffle header: " + path;
+        return false;
+    }
+    out.id = hdr[0]; out.k = hdr[1]; out.subk = hdr[2]; out.drlevel = hdr[3];
+    const size_t n = (size_t)1 << (4 * out.subk);
+    out.table.resize(n);
+    const size_t r = fread(out.table.data(), 4, n, fp);
+    fclose(fp);
+    if (r != n) { err = "error read shuffled_dim: " + path; return false; }
+    return true;
+}
+
+// Fisher-Yates driven by glibc srand()/rand(), seeds 23 then id (src/shuffle.cpp:50-54,76-104)
+inline bool write_shuf(const std::string &path, int k, int subk, int drlevel, std::string &err)
+{
+    if (k < subk) { err = "half_k should be larger than sub_k"; return false; }       // :26
+    if (subk >= 8) { err = "subk should be smaller than 8"; return false; }           // :30
+    const int n = 1 << (4 * subk);
+    if (n > RAND_MAX) { err = "shuffling array length must be less than RAND_MAX"; return false; }
+    if ((1 << (4 * (subk - drlevel))) < 256)
+        fprintf(stderr, "Warning: dimension after reduction is smaller than the suggested minimal\n");  // :36-38
+    std::vector<int32_t> t(n);
+    for (int i = 0; i < n; i++) t[i] = i;
+    const int id = (k << 8) + (subk << 4) + drlevel;
+    for (unsigned seed : {23u, (unsigned)id}) {
+        srand(seed);
+        for (int i = n - 1; i > 0; i--) {
+            const int j = rand() % (i + 1);
+            std::swap(t[i], t[j]);
+        }
+    }
+    FILE *fp = fopen(path.c_str(), "wb");
+    if (!fp) { err = "error open shuffle file " + path; return false; }
+    const int32_t hdr[4] = {id, k, subk, drlevel};
+    fwrite(hdr, sizeof(hdr), 1, fp);
+    fwrite(t.data(), 4, (size_t)n, fp);
+    fclose(fp);
+    return true;
+}
+
+// ---- .sketch (src/sketch.cpp:1024-1154) -------------------------------------------------
+inline bool save_sketches(const std::string &path, SketchSet &s, std::string &err)
+{
+    s.info.genomeNumber = (int32_t)s.size();
+    s.info.id = (s.info.half_k << 8) + (s.info.half_subk << 4) + s.info.drlevel;  // :1029
+    FILE *fp = fopen(path.c_str(), "wb");
+    if (!fp) { err = "cannot write " + path; return false; }
+    fwrite(&s.info, sizeof(SketchInfo), 1, fp);
+    std::vector<int32_t> len(s.size()), cnt(s.size());
+    for (size_t i = 0; i < s.size(); i++) {
+        len[i] = (int32_t)s.names[i].size();
+        cnt[i] = (int32_t)(s.off[i + 1] - s.off[i]);
+    }
+    fwrite(len.data(), 4, s.size(), fp);
+    fwrite(cnt.data(), 4, s.size(), fp);
+    for (size_t i = 0; i < s.size(); i++) {
+        fwrite(s.names[i].data(), 1, s.names[i].size(), fp);
+        fwrite(s.hashes.data() + s.off[i], 4, (size_t)cnt[i], fp);
+    }
+    if (fclose(fp)) { err = "write error on " + path; return false; }
+    return true;
+}
+
+inline bool read_sketches(const std::string &path, SketchSet &s, std::string &err)
+{
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (!fp) { err = "cannot open the file: " + path; return false; }
+    s = SketchSet();
+    if (fread(&s.info, sizeof(SketchInfo), 1, fp) != 1 || s.info.genomeNumber < 0) {
+        fclose(fp); err = "mismatched read sketch_info: " + path; return false;
+    }
+    if (s.info.half_k - s.info.drlevel > 8) {
+        fclose(fp);
+        err = "64-bit hash sketches (half_k - drlevel > 8) are not supported by this build: " + path;
+        return false;
+    }
+    const size_t n = (size_t)s.info.genomeNumber;
+    std::vector<int32_t> len(n), cnt(n);
+    if (fread(len.data(), 4, n, fp) != n || fread(cnt.data(), 4, n, fp) != n) {
+        fclose(fp); err = "mismatched read genome_name_size, hash_set_size: " + path; return false;
+    }
+    uint64_t tot = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (len[i] < 0 || cnt[i] < 0) { fclose(fp); err = "corrupt sketch file: " + path; return false; }
+        tot += (uint64_t)cnt[i];
+    }
+    s.names.resize(n);
+    s.hashes.resize(tot);
+    s.off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; i++) {
+        s.names[i].resize((size_t)len[i]);
+        if (len[i] && fread(&s.names[i][0], 1, (size_t)len[i], fp) != (size_t)len[i]) {
+            fclose(fp); err = "the read nameLength is not equal to the saved nameLength: " + path; return false;
+        }
+        if (cnt[i] && fread(s.hashes.data() + s.off[i], 4, (size_t)cnt[i], fp) != (size_t)cnt[i]) {
+            fclose(fp); err = "the read hashNumber is not equal to the saved hashNumber: " + path; return false;
+        }
+        s.off[i + 1] = s.off[i] + (uint64_t)cnt[i];
+    }
+    fclose(fp);
+    return true;
+}
+
+// ---- .dict / .index, 32-bit layout (src/sketch.cpp:991-1011, src/dist.cpp:86-129) -------
+inline bool write_index(const std::string &dict, const std::string &index, const std::vector<uint32_t> &postings,
+                        const std::vector<uint32_t> &counts, std::string &err)
+{
+    FILE *fd = fopen(dict.c_str(), "wb");
+    if (!fd) { err = "cannot write " + dict; return false; }
+    fwrite(postings.data(), 4, postings.size(), fd);
+    if (fclose(fd)) { err = "write error on " + dict; return false; }
+    FILE *fi = fopen(index.c_str(), "wb");
+    if (!fi) { err = "cannot write " + index; return false; }
+    const uint64_t hash_size = counts.size(), total = postings.size();
+    fwrite(&hash_size, 8, 1, fi);
+    fwrite(&total, 8, 1, fi);
+    fwrite(counts.data(), 4, counts.size(), fi);
+    if (fclose(fi)) { err = "write error on " + index; return false; }
+    return true;
+}
+
+inline bool read_index(const std::string &dict, const std::string &index, std::vector<uint32_t> &postings,
+                       std::vector<uint32_t> &counts, std::string &err)
+{
+    FILE *fi = fopen(index.c_str(), "rb");
+    if (!fi) { err = "cannot open the index sketch file: " + index; return false; }
+    uint64_t hash_size = 0, total = 0;
+    if (fread(&hash_size, 8, 1, fi) != 1 || fread(&total, 8, 1, fi) != 1 || hash_size > (1ULL << 32)) {
+        fclose(fi); err = "error read hash_size, total_index: " + index; return false;
+    }
+    counts.resize(hash_size);
+    if (fread(counts.data(), 4, hash_size, fi) != hash_size) { fclose(fi); err = "error read sketch_size_arr: " + index; return false; }
+    fclose(fi);
+    FILE *fd = fopen(dict.c_str(), "rb");
+    if (!fd) { err = "cannot open the dictionary sketch file: " + dict; return false; }
+    postings.resize(total);
+    if (fread(postings.data(), 4, total, fd) != total) { fclose(fd); err = "error read index_arr: " + dict; return false; }
+    fclose(fd);
+    return true;
+}
+
+// ---- FASTA/FASTQ record reader with kseq_read semantics (src/kseq.h:176-215) -------------
+// Sequence bytes of every record are appended to `seq` (newlines dropped, a trailing '\r'
+// of a line dropped once the record holds more than one byte); rec_off gets one more entry
+// per record.  Returns false when the file cannot be opened.
+class RecordReader {
+  public:
+    static bool read_file(const std::string &path, std::vector<uint8_t> &seq, std::vector<uint64_t> &rec_off)
+    {
+        gzFile fp = gzopen(path.c_str(), "r");  // reads plain text too (src/sketch.cpp:462)
+        if (!fp) return false;
+        std::vector<uint8_t> buf;
+        size_t n = 0;
+        for (;;) {
+            if (buf.size() - n < (1u << 20)) buf.resize(buf.size() ? buf.size() * 2 : (1u << 22));
+            const int r = gzread(fp, buf.data() + n, (unsigned)std::min<size_t>(buf.size() - n, 1u << 30));
+            if (r <= 0) break;
+            n += (size_t)r;
+        }
+        gzclose(fp);
+        parse(buf.data(), n, seq, rec_off);
+        return true;
+    }
+
+    static void parse(const uint8_t *b, size_t n, std::vector<uint8_t> &seq, std::vector<uint64_t> &rec_off)
+    {
+        size_t pos = 0;
+        int last_char = 0;
+        if (rec_off.empty()) rec_off.push_back(seq.size());
+        for (;;) {
+            if (last_char == 0) {  // jump to the next header line, :180-184
+                while (pos < n && b[pos] != '>' && b[pos] != '@') pos++;
+                if (pos >= n) return;
+                last_char = b[pos++];
+            }
+            if (pos >= n) return;  // name read fails at EOF, :186
+            int c = 0;
+            while (pos < n && !is_space(b[pos])) pos++;  // name
+            if (pos < n) c = b[pos++];
+            if (c != '\n') {  // comment up to end of line, :187
+                while (pos < n && b[pos] != '\n') pos++;
+                if (pos < n) pos++;
+            }
+            const size_t start = seq.size();
+            int stop = -1;
+            while (pos < n) {  // :192-196
+                const int ch = b[pos++];
+                if (ch == '>' || ch == '+' || ch == '@') { stop = ch; break; }
+                if (ch == '\n') continue;
+                seq.push_back((uint8_t)ch);
+                if (pos >= n) break;  // ks_getuntil2 at EOF returns before the '\r' rule
+                size_t e = pos;
+                while (e < n && b[e] != '\n') e++;
+                seq.insert(seq.end(), b + pos, b + e);
+                pos = e < n ? e + 1 : n;
+                if (seq.size() - start > 1 && seq.back() == '\r') seq.pop_back();  // :140
+            }
+            if (stop == '>' || stop == '@') last_char = stop;  // :197
+            if (stop != '+') {  // FASTA record, :204
+                rec_off.push_back(seq.size());
+                if (stop < 0 && pos >= n) {
+                    // EOF: the next call finds no name and ends the file
+                    return;
+                }
+                continue;
+            }
+            // FASTQ: skip the rest of the '+' line, then read quality lines, :209-214
+            while (pos < n && b[pos] != '\n') pos++;
+            if (pos >= n) { seq.resize(start); return; }  // -2: no quality string
+            pos++;
+            const size_t want = seq.size() - start;
+            size_t got = 0;
+            while (pos < n && got < want) {
+                size_t e = pos;
+                while (e < n && b[e] != '\n') e++;
+                size_t l = e - pos;
+                got += l;
+                if (l && got > 1 && b[e - 1] == '\r') got--;
+                pos = e < n ? e + 1 : n;
+            }
+            last_char = 0;
+            if (got != want) { seq.resize(start); return; }  // -2: truncated quality
+            rec_off.push_back(seq.size());
+        }
+    }
+
+  private:
+    static bool is_space(int c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+};
+
+// first byte of a file (list-type sniffing, src/sketch.cpp:52-94)
+inline int first_byte(const std::string &path)
+{
+    std::ifstream ifs(path);
+    std::string line;
+    std::getline(ifs, line);
+    return line.empty() ? -1 : (unsigned char)line[0];
+}
+
+inline std::vector<std::string> read_list(const std::string &path)
+{
+    std::vector<std::string> v;
+    std::ifstream ifs(path);
+    std::string line;
+    while (std::getline(ifs, line)) v.push_back(line);
+    return v;
+}
+
+}  // namespace rkhost

@@ -1,0 +1,510 @@
+// rabbit_kssd.cpp -- host tool with RabbitKSSD's command line (src/main.cpp:34-145) for the
+// hot-path subcommands, built on the C ABI of librabbitkssd.so (include/rabbitkssd.h).
+//
+//   shuffle  -k -s -l -o                     (host only, src/shuffle.cpp:25-104)
+//   sketch   -i list -o out [-L shuf] [-q]   (GPU: rk_sketch_batch [+ rk_index_build])
+//   alldist  -i sketch|list -o out [-D -M -L]            (GPU: rk_index_build, rk_dist_rows)
+//   dist     -r ref -q qry -o out [-D -M -N -L]          (GPU: rk_dist_rows [+ rk_topn_rows])
+//   info     -i sketch -o out [-F]           (host only, src/subCommand.cpp:70-147)
+//   merge    -i list -o out                  (host only, src/subCommand.cpp:796-892)
+//   union / sub / convert: outside the hot path of this build -> explicit error.
+// Errors follow the reference: a message on stderr and exit(1).  There is no CPU fallback:
+// without a GPU the GPU subcommands fail at rk_ctx_create.
+#include <sys/stat.h>
+#include <sys/time.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdarg>
+#include <iostream>
+#include <map>
+#include <thread>
+
+#include "formats.hpp"
+#include "rabbitkssd.h"
+
+using namespace rkhost;
+using std::cerr;
+using std::endl;
+using std::string;
+using std::vector;
+
+static double get_sec()
+{
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);
+    return (double)tv.tv_sec + (double)tv.tv_usec / 1e6;
+}
+
+[[noreturn]] static void die(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "ERROR: ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+    exit(1);
+}
+
+struct Gpu {
+    rk_ctx *ctx = nullptr;
+    explicit Gpu(int device)
+    {
+        int rc = rk_ctx_create(device, &ctx);
+        if (rc) die("no usable GPU (rk_ctx_create(%d) = %d): this build has no CPU path", device, rc);
+    }
+    ~Gpu() { rk_ctx_destroy(ctx); }
+    void check(int rc, const char *what) const
+    {
+        if (rc) die("%s failed (%d): %s", what, rc, rk_last_error(ctx));
+    }
+};
+
+// ---- tiny option parser -----------------------------------------------------------------
+struct Args {
+    std::map<string, string> kv;
+    std::map<string, bool> seen;
+    bool has(const string &k) const { return seen.count(k) != 0; }
+    string str(const string &k, const string &d) const { auto it = kv.find(k); return it == kv.end() ? d : it->second; }
+    int num(const string &k, int d) const { auto it = kv.find(k); return it == kv.end() ? d : atoi(it->second.c_str()); }
+    double real(const string &k, double d) const { auto it = kv.find(k); return it == kv.end() ? d : atof(it->second.c_str()); }
+};
+
+// spec: {"-k","--halfk"} -> canonical "k"; flags take no value
+static Args parse_args(int argc, char **argv, int first, const std::map<string, string> &alias,
+                       const std::vector<string> &flags)
+{
+    Args a;
+    for (int i = first; i < argc; i++) {
+        string t = argv[i], val;
+        bool has_val = false;
+        auto eq = t.find('=');
+        if (t.rfind("--", 0) == 0 && eq != string::npos) { val = t.substr(eq + 1); t = t.substr(0, eq); has_val = true; }
+        auto it = alias.find(t);
+        if (it == alias.end()) die("unknown option %s", argv[i]);
+        const string key = it->second;
+        a.seen[key] = true;
+        if (std::find(flags.begin(), flags.end(), key) != flags.end()) { a.kv[key] = "1"; continue; }
+        if (!has_val) {
+            if (i + 1 >= argc) die("option %s needs a value", argv[i]);
+            val = argv[++i];
+        }
+        a.kv[key] = val;
+    }
+    return a;
+}
+
+// ---- sketching --------------------------------------------------------------------------
+// Replaces sketchFastaFile (src/sketch.cpp:318-593): genomes keep list order and hashes are
+// sorted (the reference's order is unordered_set / OpenMP completion order; every consumer
+// treats them as sets).
+static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf &shuf, int threads,
+                        SketchSet &out, const string &out_path_in)
+{
+    const double t0 = get_sec();
+    rk_params P;
+    if (rk_params_init(shuf.k, shuf.subk, shuf.drlevel, &P))
+        die("the half_subk - drlevel should at least 3 (half_subk=%d drlevel=%d), half_k >= half_subk, half_subk < 8",
+            shuf.subk, shuf.drlevel);  // src/common.cpp:37
+    if (rk_hash_bits(&P) > 32) die("half_k - drlevel > 8 (64-bit hashes) is not supported by this build");
+    rk_filter *flt = nullptr;
+    gpu.check(rk_filter_create(gpu.ctx, &P, shuf.table.data(), &flt), "rk_filter_create");
+
+    const vector<string> files = read_list(list);
+    cerr << "the total fileNumber is: " << files.size() << endl;
+    out = SketchSet();
+    out.info.half_k = shuf.k;
+    out.info.half_subk = shuf.subk;
+    out.info.drlevel = shuf.drlevel;
+    out.names = files;
+    out.off.assign(1, 0);
+
+    // batches of ~1.5 GiB of sequence: parse on host threads, sketch on the GPU
+    const uint64_t batch_bytes = 1536ull << 20;
+    size_t next = 0;
+    uint64_t total_windows = 0;
+    while (next < files.size()) {
+        vector<vector<uint8_t>> seqs;
+        vector<vector<uint64_t>> offs;
+        size_t first = next;
+        uint64_t bytes = 0;
+        while (next < files.size() && (bytes < batch_bytes || next == first)) {
+            struct stat st;
+            if (stat(files[next].c_str(), &st)) die("cannot open the genome file: %s", files[next].c_str());
+            bytes += (uint64_t)st.st_size;
+            next++;
+        }
+        const size_t nb = next - first;
+        seqs.resize(nb);
+        offs.resize(nb);
+        std::vector<std::thread> pool;
+        std::vector<int> ok(nb, 1);
+        const int nt = std::max(1, std::min<int>(threads, (int)nb));
+        for (int t = 0; t < nt; t++)
+            pool.emplace_back([&, t]() {
+                for (size_t i = (size_t)t; i < nb; i += (size_t)nt)
+                    ok[i] = RecordReader::read_file(files[first + i], seqs[i], offs[i]) ? 1 : 0;
+            });
+        for (auto &th : pool) th.join();
+        vector<uint8_t> seq;
+        vector<uint64_t> rec_off{0}, genome_rec{0};
+        for (size_t i = 0; i < nb; i++) {
+            if (!ok[i]) die("cannot open the genome file: %s", files[first + i].c_str());
+            const uint64_t base = seq.size();
+            seq.insert(seq.end(), seqs[i].begin(), seqs[i].end());
+            for (size_t r = 1; r < offs[i].size(); r++) rec_off.push_back(base + offs[i][r]);
+            genome_rec.push_back(rec_off.size() - 1);
+            vector<uint8_t>().swap(seqs[i]);
+        }
+        rk_sketches *sk = nullptr;
+        gpu.check(rk_sketch_batch(gpu.ctx, flt, seq.data(), rec_off.data(), rec_off.size() - 1, genome_rec.data(),
+                                  (uint32_t)nb, &sk), "rk_sketch_batch");
+        vector<uint64_t> off(nb + 1);
+        vector<uint32_t> h(rk_sketches_total(sk));
+        gpu.check(rk_sketches_download(sk, h.data(), off.data()), "rk_sketches_download");
+        total_windows += rk_sketches_windows(sk);
+        rk_sketches_free(sk);
+        const uint64_t b0 = out.hashes.size();
+        out.hashes.insert(out.hashes.end(), h.begin(), h.end());
+        for (size_t i = 1; i <= nb; i++) out.off.push_back(b0 + off[i]);
+        cerr << "finshed sketching: " << next << " genomes" << endl;
+    }
+    rk_filter_free(flt);
+
+    string out_path = out_path_in;
+    if (!is_sketch_file(out_path)) out_path += ".sketch";  // src/sketch.cpp:570-572
+    string err;
+    if (!save_sketches(out_path, out, err)) die("%s", err.c_str());
+    cerr << "save the sketches into: " << out_path << endl;
+    cerr << "===================time of sketching " << files.size() << " genomes (" << total_windows
+         << " k-mers) is: " << get_sec() - t0 << endl;
+    (void)is_query;
+}
+
+// builds the index on the GPU and, when asked, writes <sketch>.dict/.index (transSketches,
+// src/sketch.cpp:894-1021)
+static rk_index *build_index(Gpu &gpu, const SketchSet &s, const string &sketch_path, bool write_files)
+{
+    const double t0 = get_sec();
+    const int bits = 4 * (s.info.half_k - s.info.drlevel);
+    rk_sketches *sk = nullptr;
+    gpu.check(rk_sketches_from_host(gpu.ctx, s.hashes.data(), s.off.data(), (uint32_t)s.size(), &sk),
+              "rk_sketches_from_host");
+    rk_index *idx = nullptr;
+    gpu.check(rk_index_build(gpu.ctx, sk, bits, &idx), "rk_index_build");
+    rk_sketches_free(sk);
+    if (write_files) {
+        vector<uint32_t> postings(rk_index_total(idx)), counts((size_t)1 << bits);
+        gpu.check(rk_index_export(idx, postings.data(), counts.data()), "rk_index_export");
+        string err;
+        if (!write_index(sketch_path + ".dict", sketch_path + ".index", postings, counts, err)) die("%s", err.c_str());
+    }
+    cerr << "===============the time of transSketches is: " << get_sec() - t0 << endl;
+    return idx;
+}
+
+// writes the distance text exactly as src/dist.cpp:233,291 / :642,725 do; above 4 GiB the
+// rows are kept as sub-files in <out>.dir with an <out>.index map (src/dist.cpp:276-336)
+static void write_hits(const string &out, const rk_hit *hits, uint64_t n, bool alldist, const vector<string> &rows,
+                       const vector<string> &cols)
+{
+    const double t0 = get_sec();
+    const uint64_t max_size = 1ULL << 32;
+    auto line = [&](const rk_hit &h, char *buf, size_t cap) {
+        const string &a = alldist ? cols[h.col] : rows[h.row];
+        const string &b = alldist ? rows[h.row] : cols[h.col];
+        if (a.size() + b.size() + 128 > cap) die("genome name too long");
+        return rk_format_hit(buf, cap, a.c_str(), b.c_str(), &h);
+    };
+    vector<char> buf(1 << 16);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; i++) total += (uint64_t)line(hits[i], buf.data(), buf.size());
+    if (total <= max_size) {
+        FILE *fp = fopen(out.c_str(), "w");
+        if (!fp) die("cannot write %s", out.c_str());
+        cerr << "-----save the output distance file: " << out << endl;
+        fprintf(fp, " genome0\tgenome1\tcommon|size0|size1\tjaccard\tmashD\n");
+        for (uint64_t i = 0; i < n; i++) {
+            const int l = line(hits[i], buf.data(), buf.size());
+            fwrite(buf.data(), 1, (size_t)l, fp);
+        }
+        fclose(fp);
+    } else {
+        const string dir = out + ".dir";
+        if (mkdir(dir.c_str(), 0777) && errno != EEXIST) die("cannot create %s", dir.c_str());
+        cerr << "-----the output distance file is too big to merge into one single file, saving the result into directory: "
+             << dir << endl;
+        FILE *fidx = fopen((out + ".index").c_str(), "w");
+        if (!fidx) die("cannot write %s.index", out.c_str());
+        fprintf(fidx, "genomeName\tdistFileName\n");
+        const uint64_t per_file = 1ULL << 30;
+        uint64_t i = 0;
+        int shard = 0;
+        while (i < n) {
+            const string name = dir + '/' + out + '.' + std::to_string(shard++);
+            FILE *fp = fopen(name.c_str(), "w");
+            if (!fp) die("cannot write %s", name.c_str());
+            uint64_t written = 0;
+            while (i < n && written < per_file) {
+                const uint32_t row = hits[i].row;
+                fprintf(fidx, "%s\t%s\n", rows[row].c_str(), name.c_str());
+                for (; i < n && hits[i].row == row; i++) {
+                    const int l = line(hits[i], buf.data(), buf.size());
+                    fwrite(buf.data(), 1, (size_t)l, fp);
+                    written += (uint64_t)l;
+                }
+            }
+            fclose(fp);
+        }
+        fclose(fidx);
+    }
+    cerr << "===================time of merge the subFiles into final files is: " << get_sec() - t0 << endl;
+}
+
+static void load_or_sketch(Gpu &gpu, const string &input, bool is_query, const Args &a, int threads, SketchSet &s,
+                           string &sketch_path)
+{
+    string err;
+    if (is_sketch_file(input)) {
+        sketch_path = input;
+        if (!read_sketches(input, s, err)) die("readSketches(), %s", err.c_str());
+        return;
+    }
+    // list of FASTA files (src/subCommand.cpp:174-181): sketch into <list>.sketch
+    const vector<string> files = read_list(input);
+    if (files.empty()) die("cannot open the inputFile or empty list: %s", input.c_str());
+    for (const string &f : files) {
+        const int c = first_byte(f);
+        if (c == '@') die("FASTQ input lists are not supported by this build (FASTA only)");
+        if (c != '>') die("the input file list for sketching must be list of fasta and fastq file");
+    }
+    Shuf shuf;
+    const string shuf_file = a.str("L", "shuf_file/L3K10.shuf");
+    cerr << "---read the shuffle file: " << shuf_file << endl;
+    if (!read_shuf(shuf_file, shuf, err)) die("read_shuffle_dim(), %s", err.c_str());
+    sketch_path = input + ".sketch";
+    sketch_list(gpu, input, is_query, shuf, threads, s, sketch_path);
+}
+
+static int cmd_shuffle(const Args &a)
+{
+    const string out = a.str("o", "result.out");
+    cerr << "-----generate the shuffle file: " << out << endl;
+    string err;
+    if (!write_shuf(out, a.num("k", 10), a.num("s", 6), a.num("l", 3), err)) die("write_shuffle_dim_file(), %s", err.c_str());
+    return 0;
+}
+
+static int cmd_sketch(const Args &a)
+{
+    if (!a.has("i") || !a.has("o")) die("sketch needs -i and -o");
+    const string in = a.str("i", ""), out = a.str("o", "");
+    const bool is_query = a.has("q");
+    const int threads = a.num("t", (int)std::thread::hardware_concurrency());
+    Gpu gpu(a.num("device", 0));
+    string err;
+    if (is_sketch_file(in)) {  // src/main.cpp:189-214: copy, and (re)build the index unless -q
+        SketchSet s;
+        if (!read_sketches(in, s, err)) die("readSketches(), %s", err.c_str());
+        if (!save_sketches(out, s, err)) die("%s", err.c_str());
+        if (!is_query) rk_index_free(build_index(gpu, s, out, true));
+        return 0;
+    }
+    Shuf shuf;
+    const string shuf_file = a.str("L", "shuf_file/L3K10.shuf");
+    cerr << "---read the shuffle file: " << shuf_file << endl;
+    if (!read_shuf(shuf_file, shuf, err)) die("read_shuffle_dim(), %s", err.c_str());
+    const vector<string> files = read_list(in);
+    for (const string &f : files) {
+        const bool gz = ends_with(f, ".gz");
+        const int c = gz ? '>' : first_byte(f);
+        if (c == '@' || ends_with(f, ".fq.gz") || ends_with(f, ".fastq.gz"))
+            die("FASTQ input lists are not supported by this build (FASTA only)");
+        if (c != '>') die("command_sketch(), the input file list for sketching must be list of fasta and fastq file in normal format or gz format");
+    }
+    SketchSet s;
+    string out_path = out;
+    sketch_list(gpu, in, is_query, shuf, threads, s, out_path);
+    if (!is_sketch_file(out_path)) out_path += ".sketch";
+    if (!is_query) rk_index_free(build_index(gpu, s, out_path, true));
+    return 0;
+}
+
+static int cmd_alldist(const Args &a)
+{
+    if (!a.has("i")) die("alldist needs -i");
+    const double max_dist = a.real("D", 1.0);
+    if (max_dist < 0.0) die("command_alldist(), maxDist must be > 0\nUse -D to set the maxDist");
+    const string out = a.str("o", "result.out");
+    const int metric = a.num("M", 0);
+    const int threads = a.num("t", (int)std::thread::hardware_concurrency());
+    Gpu gpu(a.num("device", 0));
+    const double t0 = get_sec();
+    SketchSet s;
+    string sketch_path;
+    load_or_sketch(gpu, a.str("i", ""), false, a, threads, s, sketch_path);
+    // the .dict/.index pair is (re)written only if missing (src/subCommand.cpp:165-169); the
+    // device index is always rebuilt from the sketches: faster than reading the 2^bits array
+    const bool missing = !exist_file(sketch_path + ".index") || !exist_file(sketch_path + ".dict");
+    rk_index *idx = build_index(gpu, s, sketch_path, missing);
+    cerr << "===================time of read sketches and build the index is " << get_sec() - t0 << endl;
+    const double t1 = get_sec();
+    rk_dist_opts o{};
+    o.triangle = 1;
+    o.metric = metric;
+    o.kmer_size = 2 * s.info.half_k;
+    o.max_dist = max_dist;
+    rk_hit *hits = nullptr;
+    uint64_t n = 0;
+    cerr << "=====total: " << s.size() << endl;
+    gpu.check(rk_dist_rows(gpu.ctx, idx, nullptr, &o, &hits, &n, nullptr), "rk_dist_rows");
+    cerr << "===================time of multiple threads distance computing and save the subFile is: " << get_sec() - t1 << endl;
+    write_hits(out, hits, n, true, s.names, s.names);
+    rk_free_host(hits);
+    rk_index_free(idx);
+    return 0;
+}
+
+static int cmd_dist(const Args &a)
+{
+    if (!a.has("r") || !a.has("q")) die("dist needs -r and -q");
+    const double max_dist = a.real("D", 1.0);
+    if (max_dist < 0.0) die("command_dist(), maxDist must be > 0\nUse -D to set the maxDist");
+    const int max_neighbor = a.num("N", 1);
+    if (max_neighbor < 0) die("command_dist(), maxNeighbor must be > 0\nUse -N to set the maxNeighbor");
+    const bool is_neighbor = a.has("N");
+    const string out = a.str("o", "result.out");
+    const int metric = a.num("M", 0);
+    const int threads = a.num("t", (int)std::thread::hardware_concurrency());
+    Gpu gpu(a.num("device", 0));
+    SketchSet ref, qry;
+    string ref_path, qry_path;
+    load_or_sketch(gpu, a.str("r", ""), false, a, threads, ref, ref_path);
+    cerr << "the ref_sketch size is: " << ref.size() << endl;
+    load_or_sketch(gpu, a.str("q", ""), true, a, threads, qry, qry_path);
+    if (qry.info.id != ref.info.id)  // src/subCommand.cpp:297-301
+        die("command_dist(), the sketch infos between reference and query files are not match\n"
+            "try to use the same shuffle file to generate sketches of the reference and query datasets");
+    const bool missing = !exist_file(ref_path + ".index") || !exist_file(ref_path + ".dict");
+    rk_index *idx = build_index(gpu, ref, ref_path, missing);
+    rk_sketches *qs = nullptr;
+    gpu.check(rk_sketches_from_host(gpu.ctx, qry.hashes.data(), qry.off.data(), (uint32_t)qry.size(), &qs),
+              "rk_sketches_from_host");
+    const double t1 = get_sec();
+    rk_dist_opts o{};
+    o.triangle = 0;
+    o.metric = metric;
+    o.kmer_size = 2 * ref.info.half_k;
+    o.max_dist = max_dist;
+    rk_hit *hits = nullptr;
+    uint64_t n = 0;
+    cerr << "=====total: " << qry.size() << endl;
+    gpu.check(rk_dist_rows(gpu.ctx, idx, qs, &o, &hits, &n, nullptr), "rk_dist_rows");
+    if (is_neighbor) rk_topn_rows(hits, &n, (uint64_t)max_neighbor);
+    cerr << "===================time of multiple threads distance computing and save the subFile is: " << get_sec() - t1 << endl;
+    write_hits(out, hits, n, false, qry.names, ref.names);
+    rk_free_host(hits);
+    rk_sketches_free(qs);
+    rk_index_free(idx);
+    return 0;
+}
+
+static int cmd_info(const Args &a)
+{
+    if (!a.has("i")) die("info needs -i");
+    SketchSet s;
+    string err;
+    if (!read_sketches(a.str("i", ""), s, err)) die("command_info(), %s", err.c_str());
+    cerr << "the number of genome is: " << s.size() << endl;
+    FILE *fp = fopen(a.str("o", "result.out").c_str(), "w+");
+    if (!fp) die("cannot write %s", a.str("o", "result.out").c_str());
+    fprintf(fp, "the number of sketches are: %d\n", (int)s.size());  // src/subCommand.cpp:93
+    for (size_t i = 0; i < s.size(); i++) {
+        const uint64_t cnt = s.off[i + 1] - s.off[i];
+        fprintf(fp, "%s\t%d\n", s.names[i].c_str(), (int)cnt);
+        if (a.has("F")) {
+            for (uint64_t j = 0; j < cnt; j++) {
+                fprintf(fp, "%u\t", s.hashes[s.off[i] + j]);
+                if (j % 10 == 9) fprintf(fp, "\n");
+            }
+            fprintf(fp, "\n");
+        }
+    }
+    fclose(fp);
+    return 0;
+}
+
+static int cmd_merge(const Args &a)
+{
+    if (!a.has("i") || !a.has("o")) die("merge needs -i and -o");
+    SketchSet all;
+    string err;
+    bool first = true;
+    for (const string &f : read_list(a.str("i", ""))) {
+        if (!is_sketch_file(f)) die("command_merge(), the file: %s is not a sketch file in the list file: %s", f.c_str(), a.str("i", "").c_str());
+        SketchSet s;
+        if (!read_sketches(f, s, err)) die("command_merge(), %s", err.c_str());
+        if (first) { all.info = s.info; first = false; }
+        else if (s.info.id != all.info.id) die("command_merge(), mismatched sketch parameters in %s", f.c_str());
+        const uint64_t b0 = all.hashes.size();
+        all.names.insert(all.names.end(), s.names.begin(), s.names.end());
+        all.hashes.insert(all.hashes.end(), s.hashes.begin(), s.hashes.end());
+        for (size_t i = 1; i < s.off.size(); i++) all.off.push_back(b0 + s.off[i]);
+    }
+    string out = a.str("o", "");
+    if (!is_sketch_file(out)) out += ".sketch";
+    if (!save_sketches(out, all, err)) die("%s", err.c_str());
+    return 0;
+}
+
+// test helper: record reader parity (prints records, bases and an FNV-1a hash of the bytes)
+static int cmd_parse(int argc, char **argv)
+{
+    for (int i = 2; i < argc; i++) {
+        vector<uint8_t> seq;
+        vector<uint64_t> off;
+        if (!RecordReader::read_file(argv[i], seq, off)) die("cannot open %s", argv[i]);
+        uint64_t h = 1469598103934665603ULL;
+        for (uint8_t c : seq) { h ^= c; h *= 1099511628211ULL; }
+        printf("%s\t%zu\t%zu\t%016llx", argv[i], off.size() - 1, seq.size(), (unsigned long long)h);
+        for (size_t r = 1; r < off.size(); r++) printf("\t%llu", (unsigned long long)off[r]);
+        printf("\n");
+    }
+    return 0;
+}
+
+static int usage()
+{
+    cerr << "rabbit_kssd (MI355X build, " << rk_version() << ")\n"
+            "subcommands: shuffle sketch alldist dist info merge   [union sub convert: not in this build]\n"
+            "  shuffle -k K -s S -l L -o out.shuf\n"
+            "  sketch  -i genomes.list -o out[.sketch] [-L file.shuf] [-t T] [-q] [--device N]\n"
+            "  alldist -i in.sketch|genomes.list -o out [-D maxDist] [-M 0|1] [-L file.shuf] [--device N]\n"
+            "  dist    -r ref.sketch|list -q qry.sketch|list -o out [-D maxDist] [-N n] [-M 0|1] [--device N]\n"
+            "  info    -i in.sketch -o out [-F]\n"
+            "  merge   -i sketches.list -o out.sketch\n";
+    return 1;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return usage();
+    const string sub = argv[1];
+    const std::map<string, string> alias = {
+        {"-k", "k"}, {"--halfk", "k"}, {"-s", "s"}, {"--subk", "s"}, {"-l", "l"}, {"--reduction", "l"},
+        {"-o", "o"}, {"--output", "o"}, {"-i", "i"}, {"--input", "i"}, {"-L", "L"}, {"-t", "t"}, {"--threads", "t"},
+        {"-n", "n"}, {"--leastNumKmer", "n"}, {"-Q", "Q"}, {"--leastQuality", "Q"}, {"-D", "D"}, {"--maxDist", "D"},
+        {"-M", "M"}, {"--metric", "M"}, {"-N", "N"}, {"--neighborN_max", "N"}, {"-r", "r"}, {"--reference", "r"},
+        {"-F", "F"}, {"--Fined", "F"}, {"--device", "device"}, {"--query", "q"}, {"-q", "q"}};
+    if (sub == "_parse") return cmd_parse(argc, argv);
+    if (sub == "shuffle") { cerr << "-----run the subcommand: shuffle" << endl; return cmd_shuffle(parse_args(argc, argv, 2, alias, {})); }
+    if (sub == "sketch") { cerr << "-----run the subcommand: sketch" << endl; return cmd_sketch(parse_args(argc, argv, 2, alias, {"q"})); }
+    if (sub == "alldist") { cerr << "-----run the subcommand: alldist" << endl; return cmd_alldist(parse_args(argc, argv, 2, alias, {})); }
+    if (sub == "dist") { cerr << "-----run the subcommand: dist" << endl; return cmd_dist(parse_args(argc, argv, 2, alias, {})); }
+    if (sub == "info") { cerr << "-----run the subcommand: info" << endl; return cmd_info(parse_args(argc, argv, 2, alias, {"F"})); }
+    if (sub == "merge") { cerr << "-----run the subcommand: merge" << endl; return cmd_merge(parse_args(argc, argv, 2, alias, {})); }
+    if (sub == "union" || sub == "sub" || sub == "convert")
+        die("subcommand '%s' is outside the hot path of this build (SURVEY.md section 8f); use the reference binary", sub.c_str());
+    return usage();
+}

@@ -1,0 +1,150 @@
+"""The C++ host tool rabbitkssd_amd/rabbit_kssd (reference command line above the C ABI).
+CPU tests cover the host-only parts (formats, record reader, shuffle); GPU tests run the
+sketch/alldist/dist subcommands end to end against the golden fixtures."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from oracle import oracle as ok
+
+TOOL = os.path.join(ROOT, "rabbitkssd_amd", "rabbit_kssd")
+
+
+def run(args, cwd=None, check=True):
+    p = subprocess.run([TOOL] + [str(a) for a in args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if check and p.returncode != 0:
+        raise AssertionError("rabbit_kssd %s failed:\n%s" % (args, p.stderr.decode()))
+    return p
+
+
+def test_tool_is_built():
+    assert os.path.exists(TOOL), "python -m rabbitkssd_amd.build"
+
+
+def test_shuffle_matches_reference_md5(tmp_path):
+    for case in json.load(open(os.path.join(GOLDEN, "shuf.json"))):
+        out = tmp_path / "x.shuf"
+        run(["shuffle", "-k", case["k"], "-s", case["s"], "-l", case["l"], "-o", out])
+        assert hashlib.md5(out.read_bytes()).hexdigest() == case["md5"]
+    assert run(["shuffle", "-k", 5, "-s", 6, "-l", 3, "-o", tmp_path / "bad"], check=False).returncode == 1
+
+
+def test_record_reader_matches_oracle_kseq_restatement():
+    d = os.path.join(GOLDEN, "sketch")
+    files = sorted(f for f in os.listdir(d) if f.endswith((".fa", ".fq")))
+    out = run(["_parse"] + [os.path.join(d, f) for f in files]).stdout.decode().strip().split("\n")
+    for line, f in zip(out, files):
+        cols = line.split("\t")
+        seq, off = ok.read_fasta(os.path.join(d, f))
+        h = 1469598103934665603
+        for c in seq.tobytes():
+            h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        assert int(cols[1]) == len(off) - 1 and int(cols[2]) == len(seq), f
+        assert cols[3] == "%016x" % h, f
+        assert [int(x) for x in cols[4:]] == [int(x) for x in off[1:]], f
+
+
+def test_record_reader_edge_cases(tmp_path):
+    cases = {
+        "empty.fa": b"",
+        "header_only.fa": b">x",
+        "header_nl.fa": b">x\n",
+        "one_base.fa": b">x\nA",
+        "cr_only.fa": b">x\nA\r\nC\r\n",
+        "blank_lines.fa": b"\n\n>a desc\n\nACGT\n\nAC\n>b\n>c\nTT",
+        "leading_junk.fa": b"junk\n>a\nACGT\n",
+        "fq.fq": b"@r\nACGT\n+\nIIII\n@r2\nAC\n+r2\nII\n",
+        "gt_in_seq.fa": b">a\nAC\n>\nGG\n",
+    }
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        cols = run(["_parse", p]).stdout.decode().strip().split("\t")
+        seq, off = ok.parse_fasta_bytes(data)
+        assert int(cols[1]) == len(off) - 1, name
+        assert int(cols[2]) == len(seq), name
+        assert [int(x) for x in cols[4:]] == [int(x) for x in off[1:]], name
+
+
+def test_info_and_merge(tmp_path):
+    src = os.path.join(GOLDEN, "dist", "qry.sketch")
+    info, names, h, off = ok.read_sketches32(src)
+    run(["info", "-i", src, "-o", tmp_path / "i.txt", "-F"])
+    lines = (tmp_path / "i.txt").read_text().split("\n")
+    assert lines[0] == "the number of sketches are: %d" % len(names)   # src/subCommand.cpp:93
+    assert lines[1] == "%s\t%d" % (names[0], off[1] - off[0])
+    assert lines[2].split("\t")[:3] == [str(x) for x in h[:3]]
+    lst = tmp_path / "m.list"
+    lst.write_text(src + "\n" + src + "\n")
+    run(["merge", "-i", lst, "-o", tmp_path / "m.sketch"])
+    info2, names2, h2, off2 = ok.read_sketches32(str(tmp_path / "m.sketch"))
+    assert names2 == names + names and np.array_equal(h2, np.concatenate([h, h]))
+    assert info2.genomeNumber == 2 * len(names) and info2.id == info.id
+
+
+def test_out_of_scope_subcommands_fail_loudly():
+    for sub in ("union", "sub", "convert"):
+        p = run([sub], check=False)
+        assert p.returncode == 1 and b"outside the hot path" in p.stderr
+
+
+# --------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_cli_sketch_alldist_dist_end_to_end(tmp_path):
+    d = os.path.join(GOLDEN, "sketch")
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    k, s, l = exp["half_k"], exp["half_subk"], exp["drlevel"]
+    shuf = tmp_path / "t.shuf"
+    run(["shuffle", "-k", k, "-s", s, "-l", l, "-o", shuf])
+    files = sorted(exp["files"])
+    lst = tmp_path / "g.list"
+    lst.write_text("".join(os.path.join(d, f) + "\n" for f in files))
+    run(["sketch", "-i", lst, "-L", shuf, "-o", tmp_path / "g"], cwd=tmp_path)
+    info, names, h, off = ok.read_sketches32(str(tmp_path / "g.sketch"))
+    assert (info.half_k, info.half_subk, info.drlevel, info.genomeNumber) == (k, s, l, len(files))
+    assert names == [os.path.join(d, f) for f in files]
+    for i, f in enumerate(files):
+        assert h[int(off[i]):int(off[i + 1])].tolist() == exp["files"][f]["hashes"], f
+    # .dict/.index written by the tool == transSketches layout
+    bits = 4 * (k - l)
+    postings, counts = ok.index_build32(h, off, bits)
+    p2, c2 = ok.read_index32(str(tmp_path / "g.sketch.dict"), str(tmp_path / "g.sketch.index"))
+    assert np.array_equal(p2, postings) and np.array_equal(c2, counts)
+    assert os.path.getsize(tmp_path / "g.sketch.index") == 16 + 4 * (1 << bits)
+    # alldist from the sketch file and straight from the list give the same text as the oracle
+    want_hits, _ = ok.index_dist32(counts, bits, postings, np.diff(off).astype(np.uint32), h, off, 1, 0, 2 * k, 0.2)
+    want = sorted(ok.alldist_text(names, want_hits))
+    run(["alldist", "-i", tmp_path / "g.sketch", "-D", 0.2, "-o", "a.out"], cwd=tmp_path)
+    got = (tmp_path / "a.out").read_text().split("\n")
+    assert got[0] == " genome0\tgenome1\tcommon|size0|size1\tjaccard\tmashD"
+    assert sorted(x + "\n" for x in got[1:] if x) == want
+    run(["alldist", "-i", lst, "-L", shuf, "-D", 0.2, "-o", "b.out"], cwd=tmp_path)
+    assert sorted(x + "\n" for x in (tmp_path / "b.out").read_text().split("\n")[1:] if x) == want
+
+
+@pytest.mark.gpu
+def test_cli_dist_matches_reference_text(tmp_path):
+    d = os.path.join(GOLDEN, "dist")
+    man = json.load(open(os.path.join(d, "manifest.json")))
+    ref = tmp_path / "ref.sketch"
+    ref.write_bytes(open(os.path.join(d, "ref.sketch"), "rb").read())
+    for case in man["cases"]:
+        want = open(os.path.join(d, case["file"])).read().split("\n")[:-1]
+        if case["cmd"] == "alldist":
+            run(["alldist", "-i", ref, "-D", case["max_dist"], "-M", case["metric"], "-o", "o.txt"], cwd=tmp_path)
+            got = (tmp_path / "o.txt").read_text().split("\n")
+            assert sorted(x for x in got[1:] if x) == want, case["file"]
+        else:
+            args = ["dist", "-r", ref, "-q", os.path.join(d, "qry.sketch"), "-D", case["max_dist"], "-M",
+                    case["metric"], "-o", "o.txt"]
+            if case["max_neighbor"]:
+                args += ["-N", case["max_neighbor"]]
+            run(args, cwd=tmp_path)
+            got = (tmp_path / "o.txt").read_text().split("\n")
+            assert [x for x in got[1:] if x] == want, case["file"]   # same order as the reference at -t 1
+    assert os.path.exists(str(ref) + ".dict") and os.path.exists(str(ref) + ".index")
