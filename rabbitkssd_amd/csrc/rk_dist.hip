@@ -25,7 +25,7 @@ constexpr int kDistThreads = 256;
 constexpr uint32_t kRangeChunkDefault = 640;  // posting ranges staged in LDS per pass (5 KiB)
 constexpr int kUnroll = 10;        // independent posting gathers in flight per lane
 constexpr int kPrefetch = 5;       // uint2 ranges per thread prefetched for the next row
-constexpr int kRunsPerXcdChunk = 4;    // consecutive runs (16 rows) kept on one XCD
+constexpr uint32_t kRowsPerXcdChunk = 16;  // consecutive rows kept on one XCD (their L2 shares a clade's postings)
 constexpr uint32_t kStageHitsDefault = 48;    // reported pairs staged in LDS per workgroup
 constexpr uint32_t kCandCapDefault = 256;     // non-zero cells of one row compacted in LDS
 
@@ -36,7 +36,7 @@ struct DistArgs {
     const uint32_t *ref_sizes;
     uint32_t n_query, n_ref;
     uint32_t row_first, row_step, n_rows;
-    uint32_t tile_cols, cnt_words, rows_per_wg;
+    uint32_t tile_cols, cnt_words, rows_per_wg, runs_per_chunk;
     uint32_t range_chunk, cand_cap, stage_hits;  // LDS carve-up (entries)
     int triangle, metric, kmer_size, dense_mode;
     double max_dist;
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
     // blocks b, b+8, ... share an L2: consecutive runs of one XCD are adjacent rows, while
     // heavy (early) rows stay spread over all XCDs.
     const uint32_t xcd = blockIdx.x & 7, s8 = blockIdx.x >> 3;
-    const uint32_t run = ((s8 / kRunsPerXcdChunk) * 8 + xcd) * kRunsPerXcdChunk + s8 % kRunsPerXcdChunk;
+    const uint32_t rpc = a.runs_per_chunk;
+    const uint32_t run = ((s8 / rpc) * 8 + xcd) * rpc + s8 % rpc;
     const uint32_t slot0 = run * a.rows_per_wg;
     if (slot0 >= a.n_rows) return;
     const uint32_t col0 = blockIdx.y * a.tile_cols;
@@ -317,6 +318,12 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
         if (at0 + i / kW < a.cap) dst[at0 * kW + i] = src[i];
 }
 
+inline uint32_t envu_chunk()
+{
+    const char *v = getenv("RK_DIST_XCD_ROWS");
+    return v && atoi(v) > 0 ? (uint32_t)atoi(v) : kRowsPerXcdChunk;
+}
+
 struct Plan {
     uint32_t n_rows, tile_cols, n_tiles, cnt_words;
     uint32_t range_chunk, cand_cap, stage_hits, rows_per_wg;
@@ -390,6 +397,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.n_hits = n_hits_dev;
     a.common_dense = dense_dev;
     a.rows_per_wg = p.rows_per_wg;
+    a.runs_per_chunk = std::max<uint32_t>(1, envu_chunk() / p.rows_per_wg);
     a.range_chunk = p.range_chunk;
     a.cand_cap = p.cand_cap;
     a.stage_hits = p.stage_hits;
@@ -408,7 +416,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
         RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)p.lds_bytes));
     const uint32_t runs = (p.n_rows + a.rows_per_wg - 1) / a.rows_per_wg;
-    const uint32_t per = 8 * kRunsPerXcdChunk;  // grid padded to whole XCD chunks
+    const uint32_t per = 8 * a.runs_per_chunk;  // grid padded to whole XCD chunks
     const uint32_t gx = (runs + per - 1) / per * per;
     hipLaunchKernelGGL(kern, dim3(gx, p.n_tiles), dim3(kDistThreads), p.lds_bytes, stream, a);
     RK_HIP(ctx, hipGetLastError());

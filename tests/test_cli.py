@@ -101,7 +101,9 @@ def test_cli_sketch_alldist_dist_end_to_end(tmp_path):
     k, s, l = exp["half_k"], exp["half_subk"], exp["drlevel"]
     shuf = tmp_path / "t.shuf"
     run(["shuffle", "-k", k, "-s", s, "-l", l, "-o", shuf])
-    files = sorted(exp["files"])
+    # FASTA files only: like the reference (isFastaList, src/sketch.cpp:68-80) the tool rejects
+    # a list that mixes FASTA and FASTQ
+    files = sorted(f for f in exp["files"] if f.endswith(".fa"))
     lst = tmp_path / "g.list"
     lst.write_text("".join(os.path.join(d, f) + "\n" for f in files))
     run(["sketch", "-i", lst, "-L", shuf, "-o", tmp_path / "g"], cwd=tmp_path)
