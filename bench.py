@@ -176,6 +176,14 @@ def main():
         torch.cuda.synchronize()
         t_index_build = time.time() - t0
         nbytes = index.blob_bytes
+        # PCIe-inclusive reference point (never `value`): host sketches -> upload -> index build ->
+        # distance kernel -> hits back on the host
+        t0 = time.time()
+        sk2 = ctx.sketches_from_host(hashes, off)
+        idx2 = ctx.index_build(sk2, HASH_BITS)
+        host_hits, _ = ctx.dist_rows(idx2, None, 1, 0, KMER, MAX_DIST)
+        t_host_inclusive = time.time() - t0
+        del sk2, idx2
     t_bcast = 0.0
     if world > 1:
         blob = None
@@ -263,7 +271,10 @@ def main():
                      "kernel": "rk_dist_kernel", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": b_alg},
         "setup": {"index_build_ms": t_index_build * 1e3, "index_blob_bytes": int(nbytes),
-                  "rccl_broadcast_ms": t_bcast * 1e3},
+                  "rccl_broadcast_ms": t_bcast * 1e3,
+                  "host_inclusive_ms": t_host_inclusive * 1e3,
+                  "host_inclusive_note": "host sketches -> H2D -> rk_index_build -> rk_dist_rows -> %d hits on the "
+                                         "host (PCIe-inclusive, whole dataset, one pass; not `value`)" % len(host_hits)},
     }
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and world == 1:
