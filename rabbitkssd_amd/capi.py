@@ -52,6 +52,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("librabbitkssd.so is not built (python -m rabbitkssd_amd.build); "
                               "there is no CPU fallback")
+        # When the process also uses PyTorch-ROCm (tests and bench.py do, for device tensors and
+        # torch.distributed), torch must load ITS HIP runtime first: both libraries then share
+        # one libamdhip64.  The other order leaves torch without devices.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.rk_last_error.restype = C.c_char_p
         L.rk_version.restype = C.c_char_p
