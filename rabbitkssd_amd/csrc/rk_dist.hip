@@ -22,33 +22,35 @@
 namespace {
 
 constexpr int kDistThreads = 256;
-constexpr uint32_t kRangeChunkDefault = 640;  // posting ranges staged in LDS per pass (5 KiB)
-constexpr int kUnroll = 10;        // independent posting gathers in flight per lane
-constexpr int kPrefetch = 5;       // uint2 ranges per thread prefetched for the next row
-constexpr uint32_t kRowsPerXcdChunk = 16;  // consecutive rows kept on one XCD (their L2 shares a clade's postings)
-constexpr uint32_t kStageHitsDefault = 48;    // reported pairs staged in LDS per workgroup
-constexpr uint32_t kCandCapDefault = 256;     // non-zero cells of one row compacted in LDS
+constexpr int kGroup = 8;                      // lanes per posting list
+constexpr uint32_t kRowsPerXcdChunk = 16;      // consecutive rows kept on one XCD (their L2 shares a clade's postings)
+constexpr uint32_t kStageHitsDefault = 48;     // reported pairs staged in LDS per workgroup
+constexpr uint32_t kCandCapDefault = 256;      // non-zero cells of one row compacted in LDS
 
 struct DistArgs {
-    const uint2 *ranges;      // per query element: [x,y) slice of postings
-    const uint64_t *q_off;    // u64[n_query+1]
+    const uint2 *ranges;        // posting slices [x,y) of the query hashes, rows back to back
+    const uint64_t *range_off;  // u64[n_query+1] offsets of each row's slices in `ranges`
+    const uint64_t *size_off;   // u64[n_query+1] offsets whose differences are the sketch sizes
     const uint32_t *postings;
     const uint32_t *ref_sizes;
     uint32_t n_query, n_ref;
     uint32_t row_first, row_step, n_rows;
     uint32_t tile_cols, cnt_words, rows_per_wg, runs_per_chunk;
-    uint32_t range_chunk, cand_cap, stage_hits;  // LDS carve-up (entries)
+    uint32_t cand_cap, stage_hits;  // LDS carve-up (entries)
     int triangle, metric, kmer_size, dense_mode;
     double max_dist;
+    double min_jorc;            // conservative lower bound on jaccard/containment of a reportable pair
     rk_hit *hits;
     unsigned long long cap;
     unsigned long long *n_hits;
-    int32_t *common_dense;    // optional [n_query, n_ref]
+    int32_t *common_dense;      // optional [n_query, n_ref]
 };
 
 // D3/D4: src/dist.cpp:218-231 and :238-250, FP64, same operation order.
-__device__ inline void rk_distance(int common, int size0, int size1, int metric, int kmer_size,
-                                   double &jorc, double &dist)
+// noinline: one copy of the FP64 divide + log sequence (~600 instructions) instead of one per call
+// site keeps the kernel inside the instruction cache
+__device__ __noinline__ void rk_distance(int common, int size0, int size1, int metric, int kmer_size,
+                                         double &jorc, double &dist)
 {
     if (!metric) {
         const int denom = size0 + size1 - common;
@@ -71,29 +73,38 @@ __device__ inline void rk_distance(int common, int size0, int size1, int metric,
     }
 }
 
+// value held by lane (lane & 0x18) | J of the same half-wave: broadcast inside 8-lane groups
+// (ds_swizzle bit mode: and_mask 0x18, or_mask J; LDS crossbar only, no memory, no index VALU)
+template <int J> __device__ inline uint32_t group_bcast(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x18 | (J << 5));
+}
+
 // U16: two 16-bit counters per LDS word.  Valid when no count can reach 65536, i.e. the
 // largest query sketch has < 65536 hashes (a count never exceeds |S_q|); halves the LDS row
 // and doubles the resident rows per CU.
+// FILTER=false: single reference tile and slices that already exclude ids <= row (the
+// self-join slices of rk_index_build), so every posting lands in the row unchecked.
 //
-// One workgroup handles kRowsPerWg consecutive row slots (strains of one clade share their
+// One workgroup handles rows_per_wg consecutive row slots (strains of one clade share their
 // posting lists: the second row finds them in this CU's L1/L2) and stages the reported
 // pairs in LDS, so the contended device-scope atomic on the hit counter is paid once per
 // workgroup instead of once per reporting wave.
-template <bool U16, int kGroup, bool FILTER>
+template <bool U16, bool FILTER>
 __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
 {
     // one dynamic LDS region (16-byte aligned base):
-    // counter row | staged ranges | non-zero cell list | staged hits | scalars
+    // counter row | non-zero cell list | staged hits | scalars
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *cnt = lds;
-    uint2 *srange = reinterpret_cast<uint2 *>(lds + a.cnt_words);
-    uint2 *cand = srange + a.range_chunk;  // non-zero cells of the current row: (col, common)
+    uint2 *cand = reinterpret_cast<uint2 *>(lds + a.cnt_words);  // (col, common) of the current row
     rk_hit *stage = reinterpret_cast<rk_hit *>(cand + a.cand_cap);
     unsigned long long &s_base = *reinterpret_cast<unsigned long long *>(stage + a.stage_hits);
     uint32_t &s_total = *(reinterpret_cast<uint32_t *>(stage + a.stage_hits) + 2);
     uint32_t &s_cursor = *(reinterpret_cast<uint32_t *>(stage + a.stage_hits) + 3);
-    const uint32_t kRangeChunk = a.range_chunk, kCandCap = a.cand_cap, kStageHits = a.stage_hits;
+    const uint32_t kCandCap = a.cand_cap, kStageHits = a.stage_hits;
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
 
     // blockIdx.x -> run of row slots.  Workgroups are dealt round-robin over the 8 XCDs, so
     // blocks b, b+8, ... share an L2: consecutive runs of one XCD are adjacent rows, while
@@ -108,110 +119,73 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
     const uint32_t ncol = col1 - col0;
     if (tid == 0) s_cursor = 0;
 
-    const uint32_t grp = tid / kGroup, sub = tid % kGroup;
-    constexpr uint32_t kGroups = kDistThreads / kGroup;
+    const uint32_t sub = lane % kGroup;
     const bool tri_filter = a.triangle && !a.common_dense;
     constexpr uint32_t kPerWord = U16 ? 2 : 1;
     const uint4 *c4 = reinterpret_cast<const uint4 *>(cnt);
-
-    // ranges of the NEXT row's first chunk are fetched into registers while the current row is
-    // processed, so only the first row of a run pays the HBM round trip for its ranges
-    uint2 pre[kPrefetch];
-    bool have_pre = false;
     const uint32_t slot_end = min(a.n_rows, slot0 + a.rows_per_wg);
 
-    for (uint32_t slot = slot0; slot < slot_end; slot++) {
-        const uint32_t row = a.row_first + slot * a.row_step;
-        // tile entirely at or below the diagonal: nothing to report (uniform skip)
-        if (a.triangle && col1 <= row + 1 && !a.common_dense) { have_pre = false; continue; }
+    auto row_of = [&](uint32_t slot) { return a.row_first + slot * a.row_step; };
+    auto skipped = [&](uint32_t row) { return a.triangle && col1 <= row + 1 && !a.common_dense; };
 
-        __syncthreads();  // previous row's epilogue is done with the LDS row and lists
-        {   // memset row (src/dist.cpp:179), 16 B per lane
-            uint4 *z4 = reinterpret_cast<uint4 *>(cnt);
-            for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
+    // ---- the run's work as one stream of batches -----------------------------------------
+    // A batch = up to 256 posting slices of one row, one slice per thread, loaded straight
+    // from HBM into a register pair (no LDS staging, no barrier).  Every row has at least one
+    // (possibly empty) batch so that it flows through the pipeline and gets its epilogue.
+    struct Cursor {
+        uint32_t slot;      // row slot of the batch, slot_end = exhausted
+        uint32_t b, nb;     // batch index / batches of that row
+        uint64_t e0, e1;    // the row's slice range in `ranges`
+    };
+    auto open_row = [&](Cursor &c) {  // c.slot points at a candidate row: skip tiles below the diagonal
+        while (c.slot < slot_end && skipped(row_of(c.slot))) c.slot++;
+        c.b = 0;
+        if (c.slot < slot_end) {
+            c.e0 = a.range_off[row_of(c.slot)];
+            c.e1 = a.range_off[row_of(c.slot) + 1];
+            c.nb = max(1u, (uint32_t)((c.e1 - c.e0 + kDistThreads - 1) / kDistThreads));
         }
-        if (tid == 0) s_total = 0;
+    };
+    auto advance = [&](Cursor &c) {
+        if (++c.b >= c.nb) { c.slot++; open_row(c); }
+    };
+    auto load_ranges = [&](const Cursor &c) -> uint2 {
+        if (c.slot >= slot_end) return make_uint2(0, 0);
+        const uint64_t e = c.e0 + (uint64_t)c.b * kDistThreads + tid;
+        return e < c.e1 ? a.ranges[e] : make_uint2(0, 0);
+    };
 
-        const uint64_t e0 = a.q_off[row], e1 = a.q_off[row + 1];
-        const uint32_t first_n = (uint32_t)min<uint64_t>(kRangeChunk, e1 - e0);
-        if (have_pre) {
-#pragma unroll
-            for (int u = 0; u < kPrefetch; u++) {
-                const uint32_t i = tid + kDistThreads * u;
-                if (i < first_n) srange[i] = pre[u];
-            }
-        } else {
-            for (uint32_t i = tid; i < first_n; i += kDistThreads) srange[i] = a.ranges[e0 + i];
-        }
-        have_pre = false;
-        if (slot + 1 < slot_end) {
-            const uint32_t rown = row + a.row_step;
-            if (!(a.triangle && col1 <= rown + 1 && !a.common_dense)) {
-                const uint64_t f0 = a.q_off[rown], f1 = a.q_off[rown + 1];
-                const uint32_t nn = (uint32_t)min<uint64_t>(kRangeChunk, f1 - f0);
-#pragma unroll
-                for (int u = 0; u < kPrefetch; u++) {
-                    const uint32_t i = tid + kDistThreads * u;
-                    pre[u] = i < nn ? a.ranges[f0 + i] : make_uint2(0, 0);
-                }
-                have_pre = true;
-            }
-        }
-
-        const uint32_t lo_id = tri_filter ? row + 1 : 0;  // ids below are not needed (j > i)
-        // FILTER=false: single reference tile and ranges that already exclude ids <= row
-        // (the self-join ranges of rk_index_build), so every posting lands in the row
-        auto bump = [&](uint32_t id) {
-            const uint32_t c = id - col0;
-            if (!FILTER || (c < ncol && id >= lo_id)) {
-                if (U16) atomicAdd(&cnt[c >> 1], (c & 1) ? 0x10000u : 1u);
-                else atomicAdd(&cnt[c], 1u);
-            }
+    struct Gathered {  // head postings of the 8 slices a lane's group walks in one batch
+        uint32_t id[kGroup];
+        bool ok[kGroup];
+    };
+    // a wave walks its 64 slices in 8 steps; in step j the 8-lane group g handles the slice
+    // held by lane 8g+j (ds_swizzle broadcast inside the group), 8 gathers in flight per lane
+    auto gather = [&](const uint2 rg, Gathered &g) {
+        auto step = [&](int j, uint32_t rx, uint32_t ry) {
+            const uint32_t k = rx + sub;
+            g.ok[j] = k < ry;
+            g.id[j] = a.postings[g.ok[j] ? k : 0];  // unconditional load, index 0 is always mapped
         };
-        // walks the posting lists of the n ranges staged in LDS (src/dist.cpp:194-203):
-        // kGroup lanes per list, kUnroll independent gathers in flight per lane
-        auto gather = [&](uint32_t n) {
-            for (uint32_t base = 0; base < n; base += kGroups * kUnroll) {
-                uint2 rg[kUnroll];
-                uint32_t id[kUnroll];
-#pragma unroll
-                for (int u = 0; u < kUnroll; u++) {
-                    const uint32_t i = base + grp + kGroups * u;
-                    rg[u] = i < n ? srange[i] : make_uint2(0, 0);
-                }
-#pragma unroll
-                for (int u = 0; u < kUnroll; u++) {
-                    const uint32_t k = rg[u].x + sub;
-                    id[u] = k < rg[u].y ? a.postings[k] : 0xFFFFFFFFu;
-                }
-#pragma unroll
-                for (int u = 0; u < kUnroll; u++)
-                    if (id[u] != 0xFFFFFFFFu) bump(id[u]);
-#pragma unroll
-                for (int u = 0; u < kUnroll; u++)  // tails of lists longer than the group
-                    for (uint32_t k = rg[u].x + sub + kGroup; k < rg[u].y; k += kGroup) bump(a.postings[k]);
-            }
-        };
+        step(0, group_bcast<0>(rg.x), group_bcast<0>(rg.y));
+        step(1, group_bcast<1>(rg.x), group_bcast<1>(rg.y));
+        step(2, group_bcast<2>(rg.x), group_bcast<2>(rg.y));
+        step(3, group_bcast<3>(rg.x), group_bcast<3>(rg.y));
+        step(4, group_bcast<4>(rg.x), group_bcast<4>(rg.y));
+        step(5, group_bcast<5>(rg.x), group_bcast<5>(rg.y));
+        step(6, group_bcast<6>(rg.x), group_bcast<6>(rg.y));
+        step(7, group_bcast<7>(rg.x), group_bcast<7>(rg.y));
+        static_assert(kGroup == 8, "the step list above is written for 8-lane groups");
+    };
 
-        __syncthreads();  // row zeroed, first chunk staged
-        gather(first_n);
-        for (uint64_t cb = e0 + kRangeChunk; cb < e1; cb += kRangeChunk) {  // sketches larger than one chunk
-            const uint32_t n = (uint32_t)min<uint64_t>(kRangeChunk, e1 - cb);
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += kDistThreads) srange[i] = a.ranges[cb + i];
-            __syncthreads();
-            gather(n);
-        }
-        __syncthreads();
-
+    // ---- epilogue of one row (src/dist.cpp:207-255 / :600-682) ---------------------------
+    auto epilogue = [&](uint32_t row) {
         if (a.common_dense) {
             int32_t *dst = a.common_dense + (size_t)row * a.n_ref + col0;
             for (uint32_t i = tid; i < ncol; i += kDistThreads)
                 dst[i] = (int32_t)(U16 ? (cnt[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu : cnt[i]);
         }
-
-        // ---- epilogue (src/dist.cpp:207-255 / :600-682)
-        const int qsize = (int)(e1 - e0);
+        const int qsize = (int)(a.size_off[row + 1] - a.size_off[row]);
         const uint32_t jbeg = a.triangle ? max(col0, row + 1) : col0;  // :207 / :600
 
         // evaluates one (row, j) cell; returns true when it is reported
@@ -219,6 +193,10 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
             const int rs = (int)a.ref_sizes[j];
             const int size0 = a.triangle ? qsize : rs;  // :215-216 / :607-608
             const int size1 = a.triangle ? rs : qsize;
+            // cheap exact-safe reject before the FP64 divide + log: the distance is monotone in
+            // jaccard/containment and min_jorc sits strictly below the value at the threshold
+            const int denom = a.metric ? min(size0, size1) : size0 + size1 - common;
+            if ((double)common < a.min_jorc * (double)denom) return false;
             double jorc, dist;
             rk_distance(common, size0, size1, a.metric, a.kmer_size, jorc, dist);
             hrec.row = row;
@@ -270,7 +248,7 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
                 }
             }
             __syncthreads();
-            const uint32_t n_cand = min(s_total, (uint32_t)kCandCap);
+            const uint32_t n_cand = min(s_total, kCandCap);
             for (uint32_t i = tid; i < n_cand; i += kDistThreads) {
                 const uint2 cj = cand[i];
                 rk_hit hrec;
@@ -302,11 +280,64 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
                 }
             }
         }
+    };
+
+    // ---- main loop: the slices of the NEXT batch (same or next row) are always in flight while
+    // the current batch is gathered and scattered.  (A deeper pipeline that also kept the
+    // posting gathers one batch ahead measured slower: more live registers, same issue load.)
+    Cursor cur_c{slot0, 0, 0, 0, 0};
+    open_row(cur_c);
+    if (cur_c.slot >= slot_end) return;  // nothing to do in this tile (uniform)
+    Cursor nxt_c = cur_c;
+    uint2 pre = load_ranges(cur_c);
+    uint32_t cur_slot = 0xFFFFFFFFu;     // row whose counters are live in LDS
+
+    while (cur_c.slot < slot_end) {
+        const uint2 rg = pre;
+        advance(nxt_c);
+        pre = load_ranges(nxt_c);                            // slices of the next batch
+
+        if (cur_c.slot != cur_slot) {                        // first batch of a new row
+            if (cur_slot != 0xFFFFFFFFu) {
+                __syncthreads();                             // all scatters of the previous row done
+                epilogue(row_of(cur_slot));
+            }
+            __syncthreads();                                 // epilogue done with the LDS row / lists
+            uint4 *z4 = reinterpret_cast<uint4 *>(cnt);      // memset row (src/dist.cpp:179)
+            for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
+            if (tid == 0) s_total = 0;
+            __syncthreads();
+            cur_slot = cur_c.slot;
+        }
+        const uint32_t row = row_of(cur_slot);
+        const uint32_t lo_id = tri_filter ? row + 1 : 0;     // ids below are not needed (j > i)
+        auto bump = [&](uint32_t id, bool valid) {           // scatter, src/dist.cpp:199-202
+            const uint32_t c = id - col0;
+            if (valid && (!FILTER || (c < ncol && id >= lo_id))) {
+                if (U16) atomicAdd(&cnt[c >> 1], (c & 1) ? 0x10000u : 1u);
+                else atomicAdd(&cnt[c], 1u);
+            }
+        };
+        Gathered g;
+        gather(rg, g);
+#pragma unroll
+        for (int j = 0; j < kGroup; j++) bump(g.id[j], g.ok[j]);
+        // lists longer than the group (1.7 % at 10,000 genomes): the whole wave streams the rest
+        unsigned long long longs = __ballot(rg.y - rg.x > (uint32_t)kGroup);
+        while (longs) {
+            const int L = __ffsll((long long)longs) - 1;
+            longs &= longs - 1;
+            const uint32_t sx = __builtin_amdgcn_readlane(rg.x, L), sy = __builtin_amdgcn_readlane(rg.y, L);
+            for (uint32_t k = sx + kGroup + lane; k < sy; k += 64) bump(a.postings[k], true);
+        }
+        advance(cur_c);
     }
+    __syncthreads();
+    epilogue(row_of(cur_slot));
 
     // flush the staged hits of this workgroup: one device-scope atomic, coalesced 8-byte stores
     __syncthreads();
-    const uint32_t n_st = min(s_cursor, (uint32_t)kStageHits);
+    const uint32_t n_st = min(s_cursor, kStageHits);
     if (n_st == 0) return;
     if (tid == 0) s_base = atomicAdd(a.n_hits, (unsigned long long)n_st);
     __syncthreads();
@@ -326,8 +357,7 @@ inline uint32_t envu_chunk()
 
 struct Plan {
     uint32_t n_rows, tile_cols, n_tiles, cnt_words;
-    uint32_t range_chunk, cand_cap, stage_hits, rows_per_wg;
-    int group;
+    uint32_t cand_cap, stage_hits, rows_per_wg;
     size_t lds_bytes;
     int dense_mode;
     bool u16;
@@ -347,13 +377,10 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
         const char *v = getenv(name);
         return v && atoi(v) > 0 ? (uint32_t)atoi(v) : dflt;
     };
-    p->range_chunk = std::min<uint32_t>((envu("RK_DIST_RANGE_CHUNK", kRangeChunkDefault) + 1) & ~1u,
-                                        kPrefetch * kDistThreads);
     p->cand_cap = (envu("RK_DIST_CAND_CAP", kCandCapDefault) + 1) & ~1u;
     p->stage_hits = envu("RK_DIST_STAGE_HITS", kStageHitsDefault);
     p->rows_per_wg = envu("RK_DIST_ROWS", 2);
-    p->group = (int)envu("RK_DIST_GROUP", 8);
-    const size_t fixed = (size_t)(p->range_chunk + p->cand_cap) * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
+    const size_t fixed = (size_t)p->cand_cap * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
     const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - fixed;
     const uint32_t max_cols = (uint32_t)(p->u16 ? lds_cap / 2 : lds_cap / 4) & ~63u;
     uint32_t tile = idx->n_ref ? idx->n_ref : 1;
@@ -370,14 +397,15 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     return RK_OK;
 }
 
-int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uint64_t *q_off,
-                uint32_t n_query, const rk_dist_opts *o, const Plan &p, rk_hit *hits_dev,
+int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uint64_t *range_off,
+                const uint64_t *size_off, uint32_t n_query, const rk_dist_opts *o, const Plan &p, rk_hit *hits_dev,
                 uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev, hipStream_t stream)
 {
     if (!p.n_rows || !idx->n_ref) return RK_OK;
     DistArgs a;
     a.ranges = ranges;
-    a.q_off = q_off;
+    a.range_off = range_off;
+    a.size_off = size_off;
     a.postings = idx->d_postings;
     a.ref_sizes = idx->d_sizes;
     a.n_query = n_query;
@@ -392,26 +420,27 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.kmer_size = o->kmer_size;
     a.dense_mode = p.dense_mode;
     a.max_dist = o->max_dist;
+    // distance < D  <=>  jaccard > t/(2-t), t = exp(-k D)   (containment: c > t); 1e-6 relative slack
+    // keeps the reject conservative, the exact formula still decides.  Disabled in dense mode.
+    a.min_jorc = 0.0;
+    if (!p.dense_mode && o->max_dist > 0.0) {
+        const double t = exp(-(double)o->kmer_size * o->max_dist);
+        a.min_jorc = (o->metric ? t : t / (2.0 - t)) * (1.0 - 1e-6);
+    }
     a.hits = hits_dev;
     a.cap = cap;
     a.n_hits = n_hits_dev;
     a.common_dense = dense_dev;
     a.rows_per_wg = p.rows_per_wg;
     a.runs_per_chunk = std::max<uint32_t>(1, envu_chunk() / p.rows_per_wg);
-    a.range_chunk = p.range_chunk;
     a.cand_cap = p.cand_cap;
     a.stage_hits = p.stage_hits;
     // postings need no range check when there is one tile and the ranges are the index's own
     // "later genomes" slices
     const bool filter = !(p.n_tiles == 1 && ranges == idx->d_selfrange && o->triangle && !dense_dev);
     void (*kern)(DistArgs);
-    if (p.group == 4) {
-        if (filter) kern = p.u16 ? rk_dist_kernel<true, 4, true> : rk_dist_kernel<false, 4, true>;
-        else kern = p.u16 ? rk_dist_kernel<true, 4, false> : rk_dist_kernel<false, 4, false>;
-    } else {
-        if (filter) kern = p.u16 ? rk_dist_kernel<true, 8, true> : rk_dist_kernel<false, 8, true>;
-        else kern = p.u16 ? rk_dist_kernel<true, 8, false> : rk_dist_kernel<false, 8, false>;
-    }
+    if (filter) kern = p.u16 ? rk_dist_kernel<true, true> : rk_dist_kernel<false, true>;
+    else kern = p.u16 ? rk_dist_kernel<true, false> : rk_dist_kernel<false, false>;
     if (p.lds_bytes > 48 * 1024)
         RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)p.lds_bytes));
@@ -440,7 +469,7 @@ int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *querie
     Plan p;
     int rc = make_plan(ctx, idx, idx->n_ref, idx->max_src_size, opts, &p);
     if (rc) return rc;
-    return launch_dist(ctx, idx, idx->d_selfrange, idx->d_src_off, idx->n_ref, opts, p, hits_dev,
+    return launch_dist(ctx, idx, idx->d_selfrange, idx->d_self_off, idx->d_src_off, idx->n_ref, opts, p, hits_dev,
                        hits_cap, (unsigned long long *)n_hits_dev, nullptr, (hipStream_t)stream);
 }
 
@@ -471,7 +500,8 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
     // posting ranges of every query hash: precomputed for the self join, resolved through
     // the prefix directory otherwise (or when full counter rows are requested)
     const uint2 *ranges = idx->d_selfrange;
-    const uint64_t *q_off = idx->d_src_off;
+    const uint64_t *range_off = idx->d_self_off;
+    const uint64_t *size_off = idx->d_src_off;
     DevBuf<uint2> resolved;
     if (!self || common_dense) {
         const rk_sketches *qs = queries;
@@ -484,7 +514,7 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
         rc = rk_resolve_ranges(ctx, idx, qh, qn, resolved.p, 0);
         if (rc) return rc;
         ranges = resolved.p;
-        q_off = qs->d_off;
+        range_off = size_off = qs->d_off;
     }
 
     DevBuf<int32_t> dense;
@@ -512,7 +542,7 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
             return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu hit records on the device",
                            (unsigned long long)cap);
         RK_HIP(ctx, hipMemset(counter.p, 0, 8));
-        rc = launch_dist(ctx, idx, ranges, q_off, n_query, opts, p, hits.p, cap, counter.p,
+        rc = launch_dist(ctx, idx, ranges, range_off, size_off, n_query, opts, p, hits.p, cap, counter.p,
                          common_dense ? dense.p : nullptr, 0);
         if (rc) return rc;
         unsigned long long n = 0;

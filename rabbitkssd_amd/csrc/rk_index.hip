@@ -81,6 +81,30 @@ __global__ void k_postings_selfrange(const uint32_t *sorted_e, const uint32_t *g
     selfrange[e] = make_uint2((uint32_t)k + 1, upos[g + 1]);
 }
 
+// ---- drop the empty "later genomes" slices (26 % of the elements at 10,000 genomes) ---------
+__global__ void k_self_flags(const uint2 *self, uint64_t n, uint32_t *flags)
+{
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) flags[e] = self[e].y > self[e].x ? 1u : 0u;
+}
+
+// rank = exclusive scan of flags
+__global__ void k_self_compact(const uint2 *self, const uint32_t *flags, const uint32_t *rank, uint64_t n,
+                               uint2 *out)
+{
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && flags[e]) out[rank[e]] = self[e];
+}
+
+__global__ void k_self_off(const uint64_t *off, const uint32_t *rank, uint32_t n_genomes, uint64_t H,
+                           uint64_t n_self, uint64_t *self_off)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_genomes) return;
+    const uint64_t e = off[g];
+    self_off[g] = e < H ? rank[e] : n_self;
+}
+
 __global__ void k_dir(const uint32_t *uhash, uint64_t U, int shift, uint32_t n_buckets,
                       uint32_t *dir)
 {
@@ -211,6 +235,7 @@ void rk_index_free(rk_index *idx)
     (void)hipFree(idx->d_dir);
     (void)hipFree(idx->d_sizes);
     (void)hipFree(idx->d_selfrange);
+    (void)hipFree(idx->d_self_off);
     (void)hipFree(idx->d_src_off);
     delete idx;
 }
@@ -290,6 +315,33 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         RK_HIP(ctx, hipMemset(idx->d_upos, 0, 8));
     }
     RK_HIP(ctx, hipGetLastError());
+    // compact away the empty slices; flags/rank reuse the sort scratch
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_self_off, ((size_t)s->n + 1) * 8));
+    if (H) {
+        uint32_t *sflags = flags.p, *srank = keys_sorted.p;
+        hipLaunchKernelGGL(k_self_flags, dim3(blocks_for(H)), dim3(kThreads), 0, 0, idx->d_selfrange, H, sflags);
+        size_t tb = 0;
+        RK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, sflags, srank, 0u, H, rocprim::plus<uint32_t>()));
+        DevBuf<char> tmp3;
+        RK_HIP(ctx, tmp3.alloc(tb));
+        RK_HIP(ctx, rocprim::exclusive_scan(tmp3.p, tb, sflags, srank, 0u, H, rocprim::plus<uint32_t>()));
+        uint32_t last_rank = 0, last_flag = 0;
+        RK_HIP(ctx, hipMemcpy(&last_rank, srank + (H - 1), 4, hipMemcpyDeviceToHost));
+        RK_HIP(ctx, hipMemcpy(&last_flag, sflags + (H - 1), 4, hipMemcpyDeviceToHost));
+        idx->n_self = (uint64_t)last_rank + last_flag;
+        DevBuf<uint2> compact;
+        RK_HIP(ctx, compact.alloc(idx->n_self));
+        hipLaunchKernelGGL(k_self_compact, dim3(blocks_for(H)), dim3(kThreads), 0, 0, idx->d_selfrange, sflags,
+                           srank, H, compact.p);
+        hipLaunchKernelGGL(k_self_off, dim3(blocks_for((uint64_t)s->n + 1)), dim3(kThreads), 0, 0, s->d_off, srank,
+                           s->n, H, idx->n_self, idx->d_self_off);
+        RK_HIP(ctx, hipGetLastError());
+        RK_HIP(ctx, hipDeviceSynchronize());
+        (void)hipFree(idx->d_selfrange);
+        idx->d_selfrange = compact.release();
+    } else {
+        RK_HIP(ctx, hipMemset(idx->d_self_off, 0, ((size_t)s->n + 1) * 8));
+    }
     int rc = finish_index(ctx, idx);
     if (rc) return rc;
     RK_HIP(ctx, hipDeviceSynchronize());
@@ -386,10 +438,10 @@ int rk_index_export(const rk_index *idx, uint32_t *postings, uint32_t *counts)
 namespace {
 struct BlobHeader {
     uint64_t magic, bytes;
-    uint64_t H, U, sum_sq, max_src_size;
+    uint64_t H, U, sum_sq, max_src_size, n_self;
     uint32_t n_ref, has_self;
     int32_t hash_bits, dir_bits, dir_shift, pad_;
-    uint64_t off_postings, off_uhash, off_upos, off_dir, off_sizes, off_self, off_src;
+    uint64_t off_postings, off_uhash, off_upos, off_dir, off_sizes, off_self, off_selfoff, off_src;
 };
 constexpr uint64_t kBlobMagic = 0x31584449444b5352ULL;  // "RSKDIDX1"
 inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ULL; }
@@ -402,6 +454,7 @@ void blob_layout(const rk_index *idx, BlobHeader *h)
     h->U = idx->U;
     h->sum_sq = idx->sum_sq;
     h->max_src_size = idx->max_src_size;
+    h->n_self = idx->n_self;
     h->n_ref = idx->n_ref;
     h->has_self = idx->d_selfrange ? 1 : 0;
     h->hash_bits = idx->hash_bits;
@@ -414,8 +467,9 @@ void blob_layout(const rk_index *idx, BlobHeader *h)
     h->off_dir = p;      p = al256(p + ((1ULL << idx->dir_bits) + 1) * 4);
     h->off_sizes = p;    p = al256(p + ((uint64_t)idx->n_ref + 1) * 4);
     if (h->has_self) {
-        h->off_self = p; p = al256(p + (idx->H + 1) * sizeof(uint2));
-        h->off_src = p;  p = al256(p + ((uint64_t)idx->n_ref + 1) * 8);
+        h->off_self = p;    p = al256(p + (idx->n_self + 1) * sizeof(uint2));
+        h->off_selfoff = p; p = al256(p + ((uint64_t)idx->n_ref + 1) * 8);
+        h->off_src = p;     p = al256(p + ((uint64_t)idx->n_ref + 1) * 8);
     }
     h->bytes = p;
 }
@@ -448,7 +502,8 @@ int rk_index_pack_dev(const rk_index *idx, void *blob_dev, uint64_t blob_cap, vo
     RK_HIP(ctx, hipMemcpyAsync(b + h.off_dir, idx->d_dir, ((1ULL << idx->dir_bits) + 1) * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(b + h.off_sizes, idx->d_sizes, (uint64_t)idx->n_ref * 4, hipMemcpyDeviceToDevice, st));
     if (h.has_self) {
-        RK_HIP(ctx, hipMemcpyAsync(b + h.off_self, idx->d_selfrange, idx->H * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+        RK_HIP(ctx, hipMemcpyAsync(b + h.off_self, idx->d_selfrange, idx->n_self * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+        RK_HIP(ctx, hipMemcpyAsync(b + h.off_selfoff, idx->d_self_off, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(b + h.off_src, idx->d_src_off, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
     }
     RK_HIP(ctx, hipStreamSynchronize(st));
@@ -474,6 +529,7 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
     idx->U = h.U;
     idx->sum_sq = h.sum_sq;
     idx->max_src_size = h.max_src_size;
+    idx->n_self = h.n_self;
     idx->hash_bits = h.hash_bits;
     idx->dir_bits = h.dir_bits;
     idx->dir_shift = h.dir_shift;
@@ -493,9 +549,11 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
     RK_HIP(ctx, hipMemcpyAsync(idx->d_dir, b + h.off_dir, nb * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(idx->d_sizes, b + h.off_sizes, (uint64_t)idx->n_ref * 4, hipMemcpyDeviceToDevice, st));
     if (h.has_self) {
-        RK_HIP(ctx, hipMalloc((void **)&idx->d_selfrange, (idx->H + 1) * sizeof(uint2)));
+        RK_HIP(ctx, hipMalloc((void **)&idx->d_selfrange, (idx->n_self + 1) * sizeof(uint2)));
+        RK_HIP(ctx, hipMalloc((void **)&idx->d_self_off, ((size_t)idx->n_ref + 1) * 8));
         RK_HIP(ctx, hipMalloc((void **)&idx->d_src_off, ((size_t)idx->n_ref + 1) * 8));
-        RK_HIP(ctx, hipMemcpyAsync(idx->d_selfrange, b + h.off_self, idx->H * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+        RK_HIP(ctx, hipMemcpyAsync(idx->d_selfrange, b + h.off_self, idx->n_self * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+        RK_HIP(ctx, hipMemcpyAsync(idx->d_self_off, b + h.off_selfoff, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(idx->d_src_off, b + h.off_src, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
     }
     RK_HIP(ctx, hipStreamSynchronize(st));

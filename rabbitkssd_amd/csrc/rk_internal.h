@@ -84,7 +84,10 @@ struct rk_index {
     uint32_t *d_upos = nullptr;      // u32[U+1] posting offsets
     uint32_t *d_dir = nullptr;       // u32[2^dir_bits+1] prefix directory into d_uhash
     uint32_t *d_sizes = nullptr;     // u32[n_ref] sketch sizes
-    uint2 *d_selfrange = nullptr;    // uint2[H] per source element: postings of LATER genomes
+    uint2 *d_selfrange = nullptr;    // uint2[n_self]: per source element with a non-empty slice,
+                                     // the postings of LATER genomes (rows back to back)
+    uint64_t *d_self_off = nullptr;  // u64[n_ref+1] offsets of each genome's slices in d_selfrange
+    uint64_t n_self = 0;
     uint64_t *d_src_off = nullptr;   // u64[n_ref+1] offsets of the source sketches (built only)
 };
 
