@@ -7,7 +7,8 @@
 //   dist     -r ref -q qry -o out [-D -M -N -L]          (GPU: rk_dist_rows [+ rk_topn_rows])
 //   info     -i sketch -o out [-F]           (host only, src/subCommand.cpp:70-147)
 //   merge    -i list -o out                  (host only, src/subCommand.cpp:796-892)
-//   union / sub / convert: outside the hot path of this build -> explicit error.
+//   union / sub                              (host only, src/subCommand.cpp:307-794)
+//   convert [--reverse]                      (host formats, src/sketch.cpp:1179-1365; index on GPU)
 // Errors follow the reference: a message on stderr and exit(1).  There is no CPU fallback:
 // without a GPU the GPU subcommands fail at rk_ctx_create.
 #include <sys/stat.h>
@@ -458,6 +459,151 @@ static int cmd_merge(const Args &a)
     return 0;
 }
 
+// ---- Kssd <-> RabbitKSSD conversion (src/sketch.cpp:1179-1365, src/subCommand.cpp:13-47) ------
+struct CoDstat {  // co_dstat_t, src/sketch.h:38-47 (32 bytes, natural x86-64 layout)
+    uint32_t shuf_id;
+    uint8_t koc, pad_[3];
+    int32_t kmerlen, dim_rd_len, comp_num, infile_num;
+    uint64_t all_ctx_ct;
+};
+static_assert(sizeof(CoDstat) == 32, "co_dstat_t is 32 bytes");
+static const int kPathLen = 256;  // PATHLEN, src/sketch.cpp:25
+
+static int cmd_convert(const Args &a)
+{
+    if (!a.has("i") || !a.has("o")) die("convert needs -i and -o");
+    const string in = a.str("i", ""), out_arg = a.str("o", "");
+    string err;
+    if (a.has("reverse")) {  // RabbitKSSD .sketch -> Kssd directory (:1288-1365)
+        if (!is_sketch_file(in)) die("command_convert(), need input RabbitKSSD sketch file: %s", in.c_str());
+        SketchSet s;
+        if (!read_sketches(in, s, err)) die("readSketches(), %s", err.c_str());
+        if (mkdir(out_arg.c_str(), 0777) && errno != EEXIST) die("cannot create %s", out_arg.c_str());
+        FILE *fs = fopen((out_arg + "/combco.0").c_str(), "w");
+        if (!fs) die("cannot open: %s/combco.0", out_arg.c_str());
+        fwrite(s.hashes.data(), 4, s.hashes.size(), fs);
+        fclose(fs);
+        FILE *fi = fopen((out_arg + "/combco.index.0").c_str(), "w+");
+        if (!fi) die("cannot open: %s/combco.index.0", out_arg.c_str());
+        fwrite(s.off.data(), 8, s.off.size(), fi);  // size_t prefix[infile_num+1]
+        fclose(fi);
+        CoDstat st{};
+        st.shuf_id = (uint32_t)s.info.id;
+        st.koc = 0;
+        st.kmerlen = s.info.half_k * 2;
+        st.dim_rd_len = s.info.drlevel * 2;
+        st.comp_num = 1;
+        st.infile_num = s.info.genomeNumber;
+        st.all_ctx_ct = s.hashes.size();
+        FILE *ft = fopen((out_arg + "/cofiles.stat").c_str(), "w+");
+        if (!ft) die("cannot open: %s/cofiles.stat", out_arg.c_str());
+        fwrite(&st, sizeof(st), 1, ft);
+        for (size_t i = 0; i < s.size(); i++) {
+            const uint32_t c = (uint32_t)(s.off[i + 1] - s.off[i]);
+            fwrite(&c, 4, 1, ft);
+        }
+        for (size_t i = 0; i < s.size(); i++) {
+            if (s.names[i].size() >= (size_t)kPathLen) die("genome name longer than %d bytes: %s", kPathLen - 1, s.names[i].c_str());
+            char name[kPathLen] = {0};
+            memcpy(name, s.names[i].data(), s.names[i].size());
+            fwrite(name, 1, kPathLen, ft);
+        }
+        fclose(ft);
+        return 0;
+    }
+    // Kssd directory -> .sketch (+ .dict/.index unless -q) (:1179-1285)
+    FILE *ft = fopen((in + "/cofiles.stat").c_str(), "r");
+    if (!ft) die("cannot open: %s/cofiles.stat", in.c_str());
+    CoDstat st;
+    if (fread(&st, sizeof(st), 1, ft) != 1 || st.infile_num < 0) die("convertSketch(), mismatched read cur_stat");
+    SketchSet s;
+    s.info.half_k = st.kmerlen / 2;
+    s.info.half_subk = 6;  // hard-wired by the reference, :1197
+    s.info.drlevel = st.dim_rd_len / 2;
+    if (s.info.half_k - s.info.drlevel > 8) die("64-bit hash sketches are not supported by this build");
+    const size_t n = (size_t)st.infile_num;
+    vector<uint32_t> ctx_ct(n);
+    if (fread(ctx_ct.data(), 4, n, ft) != n) die("convertSketch(), mismatched read tmp_ctx_ct");
+    s.names.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        char name[kPathLen + 1] = {0};
+        if (fread(name, 1, kPathLen, ft) == 0) cerr << "Warning: convertSketch(), the read path length is zero " << endl;
+        s.names[i] = name;
+    }
+    fclose(ft);
+    FILE *fi = fopen((in + "/combco.index.0").c_str(), "rb");
+    if (!fi) die("convertSketch(), cannot open: %s/combco.index.0", in.c_str());
+    s.off.assign(n + 1, 0);
+    if (fread(s.off.data(), 8, n + 1, fi) != n + 1) die("convertSketch(), mismatched read cbdcoindex");
+    fclose(fi);
+    FILE *fs = fopen((in + "/combco.0").c_str(), "rb");
+    if (!fs) die("cannot open: %s/combco.0", in.c_str());
+    s.hashes.resize(s.off[n]);
+    if (st.all_ctx_ct != s.off[n] || fread(s.hashes.data(), 4, s.hashes.size(), fs) != s.hashes.size())
+        die("the total hash number is not match to the state info, exit");
+    fclose(fs);
+    for (size_t i = 0; i < n; i++)
+        if (s.off[i + 1] < s.off[i]) die("convertSketch(), corrupt combco.index.0");
+    string out = out_arg;
+    if (!is_sketch_file(out)) out += ".sketch";
+    if (!save_sketches(out, s, err)) die("%s", err.c_str());
+    if (!a.has("q")) {
+        Gpu gpu(a.num("device", 0));
+        rk_index_free(build_index(gpu, s, out, true));
+    }
+    return 0;
+}
+
+// ---- set algebra on sketch files (src/subCommand.cpp:307-794); host only ------------------
+static int cmd_union(const Args &a)
+{
+    if (!a.has("i") || !a.has("o")) die("union needs -i and -o");
+    const string in = a.str("i", "");
+    if (!is_sketch_file(in)) die("command_union, %s is not sketch file, need input sketch file", in.c_str());
+    SketchSet s;
+    string err;
+    if (!read_sketches(in, s, err)) die("command_union(), %s", err.c_str());
+    cerr << "the total genome number in sketch file is: " << s.size() << endl;
+    SketchSet u;
+    u.info = s.info;
+    u.hashes = s.hashes;  // ascending hash order == the reference's bitmap walk (:493-520)
+    std::sort(u.hashes.begin(), u.hashes.end());
+    u.hashes.erase(std::unique(u.hashes.begin(), u.hashes.end()), u.hashes.end());
+    u.names = {in + " merged sketches"};  // :372
+    u.off = {0, u.hashes.size()};
+    if (!save_sketches(a.str("o", ""), u, err)) die("%s", err.c_str());
+    return 0;
+}
+
+static int cmd_sub(const Args &a)
+{
+    if (!a.has("rs") || !a.has("qs") || !a.has("o")) die("sub needs --rs, --qs and -o");
+    const string rs = a.str("rs", ""), qs = a.str("qs", "");
+    if (!is_sketch_file(rs)) die("command_sub(), %s is not sketch file, need input sketch file", rs.c_str());
+    if (!is_sketch_file(qs)) die("command_sub(): %s is not sketch file, need input sketch file", qs.c_str());
+    SketchSet ref, qry;
+    string err;
+    if (!read_sketches(rs, ref, err)) die("command_sub(), %s", err.c_str());
+    if (!read_sketches(qs, qry, err)) die("command_sub(), %s", err.c_str());
+    if (qry.info.id != ref.info.id)
+        die("command_sub(): the sketch infos between subtraction reference and query sketches are not same");
+    vector<uint64_t> dict(((size_t)1 << 32) / 64, 0);  // one bit per hash value, MSB first (:575-583)
+    for (uint32_t h : ref.hashes) dict[h / 64] |= 0x8000000000000000ULL >> (h % 64);
+    SketchSet out;
+    out.info = qry.info;
+    out.names = qry.names;
+    out.off.assign(1, 0);
+    for (size_t i = 0; i < qry.size(); i++) {
+        for (uint64_t e = qry.off[i]; e < qry.off[i + 1]; e++) {
+            const uint32_t h = qry.hashes[e];
+            if (!(dict[h / 64] & (0x8000000000000000ULL >> (h % 64)))) out.hashes.push_back(h);
+        }
+        out.off.push_back(out.hashes.size());
+    }
+    if (!save_sketches(a.str("o", ""), out, err)) die("%s", err.c_str());
+    return 0;
+}
+
 // test helper: record reader parity (prints records, bases and an FNV-1a hash of the bytes)
 static int cmd_parse(int argc, char **argv)
 {
@@ -477,13 +623,16 @@ static int cmd_parse(int argc, char **argv)
 static int usage()
 {
     cerr << "rabbit_kssd (MI355X build, " << rk_version() << ")\n"
-            "subcommands: shuffle sketch alldist dist info merge   [union sub convert: not in this build]\n"
+            "subcommands: shuffle sketch alldist dist union sub convert merge info\n"
             "  shuffle -k K -s S -l L -o out.shuf\n"
             "  sketch  -i genomes.list -o out[.sketch] [-L file.shuf] [-t T] [-q] [--device N]\n"
             "  alldist -i in.sketch|genomes.list -o out [-D maxDist] [-M 0|1] [-L file.shuf] [--device N]\n"
             "  dist    -r ref.sketch|list -q qry.sketch|list -o out [-D maxDist] [-N n] [-M 0|1] [--device N]\n"
             "  info    -i in.sketch -o out [-F]\n"
-            "  merge   -i sketches.list -o out.sketch\n";
+            "  merge   -i sketches.list -o out.sketch\n"
+            "  union   -i in.sketch -o out.sketch\n"
+            "  sub     --rs ref.sketch --qs qry.sketch -o out.sketch\n"
+            "  convert -i kssd_dir -o out[.sketch] [-q]   |   convert --reverse -i in.sketch -o kssd_dir\n";
     return 1;
 }
 
@@ -496,7 +645,8 @@ int main(int argc, char **argv)
         {"-o", "o"}, {"--output", "o"}, {"-i", "i"}, {"--input", "i"}, {"-L", "L"}, {"-t", "t"}, {"--threads", "t"},
         {"-n", "n"}, {"--leastNumKmer", "n"}, {"-Q", "Q"}, {"--leastQuality", "Q"}, {"-D", "D"}, {"--maxDist", "D"},
         {"-M", "M"}, {"--metric", "M"}, {"-N", "N"}, {"--neighborN_max", "N"}, {"-r", "r"}, {"--reference", "r"},
-        {"-F", "F"}, {"--Fined", "F"}, {"--device", "device"}, {"--query", "q"}, {"-q", "q"}};
+        {"-F", "F"}, {"--Fined", "F"}, {"--device", "device"}, {"--query", "q"}, {"-q", "q"},
+        {"--reverse", "reverse"}, {"--rs", "rs"}, {"--qs", "qs"}};
     if (sub == "_parse") return cmd_parse(argc, argv);
     if (sub == "shuffle") { cerr << "-----run the subcommand: shuffle" << endl; return cmd_shuffle(parse_args(argc, argv, 2, alias, {})); }
     if (sub == "sketch") { cerr << "-----run the subcommand: sketch" << endl; return cmd_sketch(parse_args(argc, argv, 2, alias, {"q"})); }
@@ -504,7 +654,8 @@ int main(int argc, char **argv)
     if (sub == "dist") { cerr << "-----run the subcommand: dist" << endl; return cmd_dist(parse_args(argc, argv, 2, alias, {})); }
     if (sub == "info") { cerr << "-----run the subcommand: info" << endl; return cmd_info(parse_args(argc, argv, 2, alias, {"F"})); }
     if (sub == "merge") { cerr << "-----run the subcommand: merge" << endl; return cmd_merge(parse_args(argc, argv, 2, alias, {})); }
-    if (sub == "union" || sub == "sub" || sub == "convert")
-        die("subcommand '%s' is outside the hot path of this build (SURVEY.md section 8f); use the reference binary", sub.c_str());
+    if (sub == "convert") { cerr << "-----run the subcommand: convert" << endl; return cmd_convert(parse_args(argc, argv, 2, alias, {"q", "reverse"})); }
+    if (sub == "union") { cerr << "-----run the subcommand: union" << endl; return cmd_union(parse_args(argc, argv, 2, alias, {})); }
+    if (sub == "sub") { cerr << "-----run the subcommand: sub" << endl; return cmd_sub(parse_args(argc, argv, 2, alias, {})); }
     return usage();
 }

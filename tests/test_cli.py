@@ -87,10 +87,48 @@ def test_info_and_merge(tmp_path):
     assert info2.genomeNumber == 2 * len(names) and info2.id == info.id
 
 
-def test_out_of_scope_subcommands_fail_loudly():
-    for sub in ("union", "sub", "convert"):
-        p = run([sub], check=False)
-        assert p.returncode == 1 and b"outside the hot path" in p.stderr
+def test_union_and_sub_set_algebra(tmp_path):
+    # src/subCommand.cpp:307-794: union = one sketch with the ascending union of all hashes,
+    # sub = query sketches minus every hash present in any reference sketch (order kept)
+    d = os.path.join(GOLDEN, "dist")
+    _, rnames, rh, roff = ok.read_sketches32(os.path.join(d, "ref.sketch"))
+    _, qnames, qh, qoff = ok.read_sketches32(os.path.join(d, "qry.sketch"))
+    run(["union", "-i", os.path.join(d, "ref.sketch"), "-o", tmp_path / "u.sketch"])
+    info, names, h, off = ok.read_sketches32(str(tmp_path / "u.sketch"))
+    assert info.genomeNumber == 1 and names == [os.path.join(d, "ref.sketch") + " merged sketches"]
+    assert np.array_equal(h, np.unique(rh))
+    run(["sub", "--rs", os.path.join(d, "ref.sketch"), "--qs", os.path.join(d, "qry.sketch"), "-o", tmp_path / "s.sketch"])
+    info, names, h, off = ok.read_sketches32(str(tmp_path / "s.sketch"))
+    assert names == qnames
+    refset = set(rh.tolist())
+    for i in range(len(qnames)):
+        want = [x for x in qh[int(qoff[i]):int(qoff[i + 1])].tolist() if x not in refset]
+        assert h[int(off[i]):int(off[i + 1])].tolist() == want
+
+
+def test_convert_to_kssd_layout_and_back(tmp_path):
+    # SURVEY Appendix A.5 / src/sketch.cpp:1288-1365
+    src = os.path.join(GOLDEN, "dist", "qry.sketch")
+    info, names, h, off = ok.read_sketches32(src)
+    kd = tmp_path / "kssd"
+    run(["convert", "--reverse", "-i", src, "-o", kd])
+    stat = (kd / "cofiles.stat").read_bytes()
+    n = len(names)
+    assert len(stat) == 32 + 4 * n + 256 * n
+    shuf_id, = np.frombuffer(stat[0:4], "<u4")
+    kmerlen, dim_rd_len, comp_num, infile_num = np.frombuffer(stat[8:24], "<i4")
+    all_ctx, = np.frombuffer(stat[24:32], "<u8")
+    assert (shuf_id, stat[4], kmerlen, dim_rd_len, comp_num, infile_num, all_ctx) == (
+        info.id, 0, 2 * info.half_k, 2 * info.drlevel, 1, n, len(h))
+    assert np.array_equal(np.frombuffer(stat[32:32 + 4 * n], "<u4"), np.diff(off))
+    assert stat[32 + 4 * n:32 + 4 * n + 256].rstrip(b"\0").decode() == names[0]
+    assert np.array_equal(np.frombuffer((kd / "combco.index.0").read_bytes(), "<u8"), off)
+    assert np.array_equal(np.frombuffer((kd / "combco.0").read_bytes(), "<u4"), h)
+    # and back (query mode: no index, so no GPU needed); half_subk comes back as 6 (:1197)
+    run(["convert", "-q", "-i", kd, "-o", tmp_path / "back"])
+    info2, names2, h2, off2 = ok.read_sketches32(str(tmp_path / "back.sketch"))
+    assert names2 == names and np.array_equal(h2, h) and np.array_equal(off2, off)
+    assert (info2.half_k, info2.half_subk, info2.drlevel) == (info.half_k, 6, info.drlevel)
 
 
 # --------------------------------------------------------------------------- GPU
