@@ -9,6 +9,7 @@
  *   rk_filter_create       <- shuffled_map construction  src/sketch.cpp:336-345
  *   rk_sketch_batch        <- per-genome loop of sketchFastaFile
  *                                                        src/sketch.cpp:455-566 (and :173-238)
+ *   rk_sketch_batch_ex     <- per-file loop of sketchFastqFile   src/sketch.cpp:741-866
  *   rk_index_build         <- transSketches (32-bit)     src/sketch.cpp:970-1017
  *   rk_index_import/export <- .dict/.index load/store    src/dist.cpp:86-129, src/sketch.cpp:991-1011
  *   rk_dist_rows           <- row loop of index_tridist  src/dist.cpp:174-258
@@ -111,6 +112,16 @@ int rk_sketch_batch(rk_ctx *ctx, const rk_filter *f, const uint8_t *seq, const u
 int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_dev,
                          uint64_t packed_bytes, const uint64_t *gbeg, const uint64_t *gend,
                          uint32_t n_genomes, void *stream, rk_sketches **out);
+/* FASTQ variant of both (sketchFastqFile, src/sketch.cpp:596-890): qual (optional) holds one quality
+ * character per base of seq, a base with quality < least_qual is invalid (src/sketch.cpp:785);
+ * a hash is kept only if it occurred at least min_count times (leastNumKmer, :828-845).
+ * rk_sketch_batch == rk_sketch_batch_ex(qual = NULL, least_qual = 0, min_count = 1). */
+int rk_sketch_batch_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *seq, const uint8_t *qual,
+                       int least_qual, uint32_t min_count, const uint64_t *rec_off, uint64_t n_rec,
+                       const uint64_t *genome_rec, uint32_t n_genomes, rk_sketches **out);
+int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_dev,
+                            uint64_t packed_bytes, const uint64_t *gbeg, const uint64_t *gend,
+                            uint32_t n_genomes, uint32_t min_count, void *stream, rk_sketches **out);
 /* host helpers for the packed layout: sizes first, then fill a caller buffer */
 int rk_pack_layout(const uint64_t *rec_off, uint64_t n_rec, const uint64_t *genome_rec,
                    uint32_t n_genomes, uint64_t *gbeg, uint64_t *gend, uint64_t *packed_bytes);

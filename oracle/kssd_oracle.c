@@ -181,12 +181,29 @@ static int64_t ms_kseq_read(mstream_t *ms, int *last_char, kstr_t *seq, kstr_t *
     return (int64_t)seq->l;
 }
 
+static int parse_mem(const uint8_t *buf, uint64_t n, uint8_t **seq_out, uint8_t **qual_out,
+                     uint64_t **rec_off_out, uint64_t *n_rec_out);
+
 int ok_parse_fasta_mem(const uint8_t *buf, uint64_t n, uint8_t **seq_out, uint64_t **rec_off_out,
                        uint64_t *n_rec_out)
 {
+    return parse_mem(buf, n, seq_out, NULL, rec_off_out, n_rec_out);
+}
+
+/* same, also returning the per-base quality characters (FASTQ, src/sketch.cpp:775-776);
+ * records without a quality string (FASTA) get '~' so they pass every gate */
+int ok_parse_fastq_mem(const uint8_t *buf, uint64_t n, uint8_t **seq_out, uint8_t **qual_out,
+                       uint64_t **rec_off_out, uint64_t *n_rec_out)
+{
+    return parse_mem(buf, n, seq_out, qual_out, rec_off_out, n_rec_out);
+}
+
+static int parse_mem(const uint8_t *buf, uint64_t n, uint8_t **seq_out, uint8_t **qual_out,
+                     uint64_t **rec_off_out, uint64_t *n_rec_out)
+{
     mstream_t ms = {buf, n, 0};
     int last_char = 0;
-    kstr_t seq = {0, 0, 0}, qual = {0, 0, 0}, all = {0, 0, 0};
+    kstr_t seq = {0, 0, 0}, qual = {0, 0, 0}, all = {0, 0, 0}, allq = {0, 0, 0};
     uint64_t cap = 16, nrec = 0;
     uint64_t *off = (uint64_t *)malloc((cap + 1) * 8);
     if (!off) return -3;
@@ -203,11 +220,21 @@ int ok_parse_fasta_mem(const uint8_t *buf, uint64_t n, uint8_t **seq_out, uint64
         if (kstr_reserve(&all, all.l + (uint64_t)len + 1)) { free(off); return -3; }
         memcpy(all.s + all.l, seq.s, (size_t)len);
         all.l += (uint64_t)len;
+        if (qual_out) {
+            if (kstr_reserve(&allq, allq.l + (uint64_t)len + 1)) { free(off); return -3; }
+            if (qual.l == (uint64_t)len) memcpy(allq.s + allq.l, qual.s, (size_t)len);
+            else memset(allq.s + allq.l, '~', (size_t)len);
+            allq.l += (uint64_t)len;
+        }
         off[++nrec] = all.l;
     }
     free(seq.s);
     free(qual.s);
     if (!all.s) all.s = (uint8_t *)calloc(1, 1);
+    if (qual_out) {
+        if (!allq.s) allq.s = (uint8_t *)calloc(1, 1);
+        *qual_out = allq.s;
+    }
     *seq_out = all.s;
     *rec_off_out = off;
     *n_rec_out = nrec;
@@ -259,9 +286,21 @@ static int cmp_u64(const void *a, const void *b)
 }
 
 /* src/sketch.cpp:487-530 (identical copies :198-231).  emit==NULL only counts. */
+static uint64_t scan_records_q(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq,
+                               const uint8_t *qual, int least_qual, const uint64_t *rec_off,
+                               uint64_t n_rec, kstr_t *emit, uint64_t *n_windows, int *err);
+
 static uint64_t scan_records(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq,
                              const uint64_t *rec_off, uint64_t n_rec, kstr_t *emit,
                              uint64_t *n_windows, int *err)
+{
+    return scan_records_q(p, shuffled_dim, seq, NULL, 0, rec_off, n_rec, emit, n_windows, err);
+}
+
+/* qual != NULL adds the FASTQ gate `quality[i] >= leastQual` of src/sketch.cpp:785 */
+static uint64_t scan_records_q(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq,
+                               const uint8_t *qual, int least_qual, const uint64_t *rec_off,
+                               uint64_t n_rec, kstr_t *emit, uint64_t *n_windows, int *err)
 {
     const int rev_add_move = p->rev_add_move, out = p->half_outctx_len;
     const int kmer_size = (int)p->kmer_size, drlevel = p->drlevel;
@@ -273,7 +312,7 @@ static uint64_t scan_records(const ok_param_t *p, const int32_t *shuffled_dim, c
         int base = 1;                      /* :488 */
         for (uint64_t i = rec_off[r]; i < rec_off[r + 1]; i++) {
             int basenum = base_code(seq[i]); /* :494-495 */
-            if (basenum != -1) {
+            if (basenum != -1 && (!qual || (int)(char)qual[i] >= least_qual)) {
                 tuple = ((tuple << 2) | (uint64_t)basenum) & tupmask;                        /* :498 */
                 rvs_tuple = (rvs_tuple >> 2) + (((uint64_t)basenum ^ 3ULL) << rev_add_move); /* :499 */
                 base++;
@@ -314,6 +353,30 @@ int64_t ok_sketch_records(const ok_param_t *p, const int32_t *shuffled_dim, cons
     uint64_t u = 0;
     for (uint64_t i = 0; i < n; i++)
         if (u == 0 || h[i] != h[u - 1]) h[u++] = h[i];
+    if (!h) h = (uint64_t *)calloc(1, 8);
+    *hashes_out = h;
+    return (int64_t)u;
+}
+
+/* FASTQ variant, src/sketch.cpp:781-845: quality gate + per-hash occurrence count; a hash is
+ * kept when it occurred at least least_num times (hashValueMap[dr_tuple]++ ... >= leastNumKmer). */
+int64_t ok_sketch_records_fastq(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq,
+                                const uint8_t *qual, int least_qual, int least_num,
+                                const uint64_t *rec_off, uint64_t n_rec, uint64_t **hashes_out)
+{
+    kstr_t emit = {0, 0, 0};
+    int err = 0;
+    uint64_t n = scan_records_q(p, shuffled_dim, seq, qual, least_qual, rec_off, n_rec, &emit, NULL, &err);
+    if (err) { free(emit.s); return err; }
+    uint64_t *h = (uint64_t *)emit.s;
+    if (n) qsort(h, n, 8, cmp_u64);
+    uint64_t u = 0;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i;
+        while (j < n && h[j] == h[i]) j++;
+        if ((int64_t)(j - i) >= (int64_t)least_num) h[u++] = h[i];
+        i = j;
+    }
     if (!h) h = (uint64_t *)calloc(1, 8);
     *hashes_out = h;
     return (int64_t)u;

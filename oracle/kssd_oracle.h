@@ -74,6 +74,15 @@ int ok_read_fasta(const char *path, uint8_t **seq, uint64_t **rec_off, uint64_t 
 int ok_parse_fasta_mem(const uint8_t *buf, uint64_t n, uint8_t **seq, uint64_t **rec_off,
                        uint64_t *n_rec);
 
+/* FASTQ: also the quality characters, one per base (records without qualities get '~') */
+int ok_parse_fastq_mem(const uint8_t *buf, uint64_t n, uint8_t **seq, uint8_t **qual,
+                       uint64_t **rec_off, uint64_t *n_rec);
+/* f1: src/sketch.cpp:781-845 (sketchFastqFile): base valid iff ACGT and quality >= least_qual;
+ * hash kept iff it occurred >= least_num times.  Output sorted. */
+int64_t ok_sketch_records_fastq(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq,
+                                const uint8_t *qual, int least_qual, int least_num,
+                                const uint64_t *rec_off, uint64_t n_rec, uint64_t **hashes_out);
+
 /* S3-S5: src/sketch.cpp:487-550.  Windows never span records.  Output: sorted
  * unique dr_tuples (u64; the 32-bit path narrows them).  Returns count or <0. */
 int64_t ok_sketch_records(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq,

@@ -43,6 +43,7 @@ def lib():
     if _LIB is None:
         L = C.CDLL(build())
         L.ok_sketch_records.restype = C.c_int64
+        L.ok_sketch_records_fastq.restype = C.c_int64
         L.ok_count_windows.restype = C.c_uint64
         L.ok_index_dist32.restype = C.c_int64
         L.ok_topn_row.restype = C.c_uint32
@@ -103,6 +104,42 @@ def parse_fasta_bytes(data):
     lib().ok_free(seq)
     lib().ok_free(off)
     return s, o
+
+
+def parse_fastq_bytes(data):
+    """(seq, qual, rec_off) of a FASTQ/FASTA text; qual has one character per base."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    seq = C.POINTER(C.c_uint8)()
+    qual = C.POINTER(C.c_uint8)()
+    off = C.POINTER(C.c_uint64)()
+    n = C.c_uint64()
+    rc = lib().ok_parse_fastq_mem(_p(buf, C.c_uint8), C.c_uint64(len(buf)), C.byref(seq), C.byref(qual),
+                                  C.byref(off), C.byref(n))
+    if rc:
+        raise OSError("ok_parse_fastq_mem failed: %d" % rc)
+    o = np.ctypeslib.as_array(off, shape=(n.value + 1,)).copy()
+    m = int(o[-1])
+    s = np.ctypeslib.as_array(seq, shape=(max(m, 1),))[:m].copy()
+    q = np.ctypeslib.as_array(qual, shape=(max(m, 1),))[:m].copy()
+    for ptr in (seq, qual, off):
+        lib().ok_free(ptr)
+    return s, q, o
+
+
+def sketch_records_fastq(param, shuffled_dim, seq, qual, rec_off, least_qual=0, least_num=1):
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    qual = np.ascontiguousarray(qual, dtype=np.uint8)
+    rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+    tab = np.ascontiguousarray(shuffled_dim, dtype=np.int32)
+    out = C.POINTER(C.c_uint64)()
+    n = lib().ok_sketch_records_fastq(C.byref(param), _p(tab, C.c_int32), _p(seq, C.c_uint8),
+                                      _p(qual, C.c_uint8), int(least_qual), int(least_num),
+                                      _p(rec_off, C.c_uint64), C.c_uint64(len(rec_off) - 1), C.byref(out))
+    if n < 0:
+        raise MemoryError("ok_sketch_records_fastq failed")
+    h = np.ctypeslib.as_array(out, shape=(max(n, 1),))[:n].copy()
+    lib().ok_free(out)
+    return h
 
 
 def read_fasta(path):

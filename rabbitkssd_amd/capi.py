@@ -17,7 +17,7 @@ HIT_DTYPE = np.dtype([("row", "<u4"), ("col", "<u4"), ("common", "<i4"), ("size0
 EXPORTS = [
     "rk_device_count", "rk_ctx_create", "rk_ctx_destroy", "rk_last_error", "rk_version",
     "rk_free_host", "rk_params_init", "rk_hash_bits", "rk_filter_create", "rk_filter_free",
-    "rk_sketch_batch", "rk_sketch_packed_dev", "rk_pack_layout", "rk_pack_genomes",
+    "rk_sketch_batch", "rk_sketch_batch_ex", "rk_sketch_packed_dev", "rk_sketch_packed_dev_ex", "rk_pack_layout", "rk_pack_genomes",
     "rk_sketches_from_host", "rk_sketches_from_dev", "rk_sketches_count", "rk_sketches_total", "rk_sketches_windows",
     "rk_sketches_download", "rk_sketches_hashes_dev", "rk_sketches_off_dev", "rk_sketches_free",
     "rk_index_build", "rk_index_import", "rk_index_export", "rk_index_total",
@@ -136,6 +136,17 @@ class Context:
         self.check(lib().rk_sketch_batch(self._h, flt._h, _ptr(seq), _ptr(rec_off),
                                          C.c_uint64(len(rec_off) - 1), _ptr(genome_rec),
                                          C.c_uint32(len(genome_rec) - 1), C.byref(h)))
+        return Sketches(self, h)
+
+    def sketch_batch_fastq(self, flt, seq, qual, rec_off, genome_rec, least_qual=0, min_count=1):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        genome_rec = np.ascontiguousarray(genome_rec, dtype=np.uint64)
+        h = C.c_void_p()
+        self.check(lib().rk_sketch_batch_ex(self._h, flt._h, _ptr(seq), _ptr(qual), int(least_qual),
+                                            C.c_uint32(min_count), _ptr(rec_off), C.c_uint64(len(rec_off) - 1),
+                                            _ptr(genome_rec), C.c_uint32(len(genome_rec) - 1), C.byref(h)))
         return Sketches(self, h)
 
     def sketch_packed_dev(self, flt, packed_dev_ptr, packed_bytes, gbeg, gend, stream=0):

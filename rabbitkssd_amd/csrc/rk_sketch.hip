@@ -300,6 +300,12 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
     if (lane == 0 && windows) atomicAdd(a.n_windows, windows);
 }
 
+__global__ void k_count_flags(const unsigned int *counts, uint64_t n, uint32_t min_count, unsigned char *flags)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = counts[i] >= min_count ? 1 : 0;
+}
+
 __global__ void k_split_keys(const unsigned long long *ukeys, uint64_t n, uint32_t *hashes)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -492,6 +498,13 @@ int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_
                          uint64_t packed_bytes, const uint64_t *gbeg, const uint64_t *gend,
                          uint32_t n_genomes, void *stream_v, rk_sketches **out)
 {
+    return rk_sketch_packed_dev_ex(ctx, f, packed_dev, packed_bytes, gbeg, gend, n_genomes, 1, stream_v, out);
+}
+
+int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_dev,
+                            uint64_t packed_bytes, const uint64_t *gbeg, const uint64_t *gend,
+                            uint32_t n_genomes, uint32_t min_count, void *stream_v, rk_sketches **out)
+{
     if (!ctx || !f || !out || (!packed_dev && packed_bytes) || ((!gbeg || !gend) && n_genomes))
         return RK_ERR_ARG;
     *out = nullptr;
@@ -612,8 +625,36 @@ int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_
         DevBuf<char> tmp;
         RK_HIP(ctx, tmp.alloc(std::max(t1, t2)));
         RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, t1, cand.p, sorted.p, n_cand, 0, (unsigned)(32 + gbits), stream));
-        RK_HIP(ctx, rocprim::unique(tmp.p, t2, sorted.p, uniq.p, d_nuniq.p, n_cand,
-                                    rocprim::equal_to<unsigned long long>(), stream));
+        if (min_count <= 1) {  // set semantics (FASTA, src/sketch.cpp:526-529)
+            RK_HIP(ctx, rocprim::unique(tmp.p, t2, sorted.p, uniq.p, d_nuniq.p, n_cand,
+                                        rocprim::equal_to<unsigned long long>(), stream));
+        } else {  // FASTQ: keep a hash only if it occurred >= min_count times (src/sketch.cpp:828-845)
+            DevBuf<unsigned long long> runs;
+            DevBuf<unsigned int> counts;
+            DevBuf<unsigned char> flags;
+            RK_HIP(ctx, runs.alloc(n_cand));
+            RK_HIP(ctx, counts.alloc(n_cand));
+            RK_HIP(ctx, flags.alloc(n_cand));
+            size_t t3 = 0, t4 = 0;
+            RK_HIP(ctx, rocprim::run_length_encode(nullptr, t3, sorted.p, n_cand, runs.p, counts.p, d_nuniq.p, stream));
+            DevBuf<char> tmp3;
+            RK_HIP(ctx, tmp3.alloc(t3));
+            RK_HIP(ctx, rocprim::run_length_encode(tmp3.p, t3, sorted.p, n_cand, runs.p, counts.p, d_nuniq.p, stream));
+            unsigned long long n_runs = 0;
+            RK_HIP(ctx, hipMemcpyAsync(&n_runs, d_nuniq.p, 8, hipMemcpyDeviceToHost, stream));
+            RK_HIP(ctx, hipStreamSynchronize(stream));
+            if (n_runs) {
+                hipLaunchKernelGGL(k_count_flags, dim3(blocks_for(n_runs)), dim3(256), 0, stream, counts.p, n_runs,
+                                   min_count, flags.p);
+                RK_HIP(ctx, rocprim::select(nullptr, t4, runs.p, flags.p, uniq.p, d_nuniq.p, n_runs, stream));
+                DevBuf<char> tmp4;
+                RK_HIP(ctx, tmp4.alloc(t4));
+                RK_HIP(ctx, rocprim::select(tmp4.p, t4, runs.p, flags.p, uniq.p, d_nuniq.p, n_runs, stream));
+                RK_HIP(ctx, hipStreamSynchronize(stream));
+            } else {
+                RK_HIP(ctx, hipMemsetAsync(d_nuniq.p, 0, 8, stream));
+            }
+        }
         unsigned long long nu = 0;
         RK_HIP(ctx, hipMemcpyAsync(&nu, d_nuniq.p, 8, hipMemcpyDeviceToHost, stream));
         RK_HIP(ctx, hipStreamSynchronize(stream));
@@ -638,6 +679,13 @@ int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_
 int rk_sketch_batch(rk_ctx *ctx, const rk_filter *f, const uint8_t *seq, const uint64_t *rec_off,
                     uint64_t n_rec, const uint64_t *genome_rec, uint32_t n_genomes, rk_sketches **out)
 {
+    return rk_sketch_batch_ex(ctx, f, seq, nullptr, 0, 1, rec_off, n_rec, genome_rec, n_genomes, out);
+}
+
+int rk_sketch_batch_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *seq, const uint8_t *qual, int least_qual,
+                       uint32_t min_count, const uint64_t *rec_off, uint64_t n_rec, const uint64_t *genome_rec,
+                       uint32_t n_genomes, rk_sketches **out)
+{
     if (!ctx || !f || !rec_off || !genome_rec || !out || (!seq && rec_off[n_rec])) return RK_ERR_ARG;
     *out = nullptr;
     std::vector<uint64_t> gbeg((size_t)n_genomes + 1), gend((size_t)n_genomes + 1);
@@ -648,13 +696,29 @@ int rk_sketch_batch(rk_ctx *ctx, const rk_filter *f, const uint8_t *seq, const u
     uint8_t *h_packed = nullptr;
     RK_HIP(ctx, hipHostMalloc((void **)&h_packed, bytes, hipHostMallocDefault));
     rc = rk_pack_genomes(seq, rec_off, n_rec, genome_rec, n_genomes, gbeg.data(), h_packed, bytes);
+    if (!rc && qual) {
+        // FASTQ quality gate (src/sketch.cpp:785): a base whose quality character is below
+        // least_qual is not a base.  Applied while packing: the byte becomes 0x00, which the
+        // kernel treats exactly like any other invalid base.
+        for (uint32_t g = 0; g < n_genomes; g++) {
+            uint64_t pos = gbeg[g];
+            for (uint64_t r = genome_rec[g]; r < genome_rec[g + 1]; r++) {
+                const uint64_t len = rec_off[r + 1] - rec_off[r];
+                const uint8_t *q = qual + rec_off[r];
+                for (uint64_t i = 0; i < len; i++)
+                    if ((int)(char)q[i] < least_qual) h_packed[pos + i] = 0;
+                pos += len + 1;
+            }
+        }
+    }
     DevBuf<uint8_t> d_packed;
     if (!rc && d_packed.alloc(bytes) != hipSuccess) rc = rk_fail(ctx, RK_ERR_NOMEM, "device alloc of %llu bytes failed", (unsigned long long)bytes);
     if (!rc && hipMemcpy(d_packed.p, h_packed, bytes, hipMemcpyHostToDevice) != hipSuccess)
         rc = rk_fail(ctx, RK_ERR_HIP, "sequence upload failed");
     (void)hipHostFree(h_packed);
     if (rc) return rc;
-    return rk_sketch_packed_dev(ctx, f, d_packed.p, bytes, gbeg.data(), gend.data(), n_genomes, nullptr, out);
+    return rk_sketch_packed_dev_ex(ctx, f, d_packed.p, bytes, gbeg.data(), gend.data(), n_genomes,
+                                   min_count ? min_count : 1, nullptr, out);
 }
 
 }  // extern "C"

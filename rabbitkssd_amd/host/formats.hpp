@@ -205,7 +205,9 @@ inline bool read_index(const std::string &dict, const std::string &index, std::v
 // per record.  Returns false when the file cannot be opened.
 class RecordReader {
   public:
-    static bool read_file(const std::string &path, std::vector<uint8_t> &seq, std::vector<uint64_t> &rec_off)
+    // qual (optional): one quality character per base; '~' for records without qualities
+    static bool read_file(const std::string &path, std::vector<uint8_t> &seq, std::vector<uint64_t> &rec_off,
+                          std::vector<uint8_t> *qual = nullptr)
     {
         gzFile fp = gzopen(path.c_str(), "r");  // reads plain text too (src/sketch.cpp:462)
         if (!fp) return false;
@@ -218,11 +220,12 @@ class RecordReader {
             n += (size_t)r;
         }
         gzclose(fp);
-        parse(buf.data(), n, seq, rec_off);
+        parse(buf.data(), n, seq, rec_off, qual);
         return true;
     }
 
-    static void parse(const uint8_t *b, size_t n, std::vector<uint8_t> &seq, std::vector<uint64_t> &rec_off)
+    static void parse(const uint8_t *b, size_t n, std::vector<uint8_t> &seq, std::vector<uint64_t> &rec_off,
+                      std::vector<uint8_t> *qual = nullptr)
     {
         size_t pos = 0;
         int last_char = 0;
@@ -257,6 +260,7 @@ class RecordReader {
             }
             if (stop == '>' || stop == '@') last_char = stop;  // :197
             if (stop != '+') {  // FASTA record, :204
+                if (qual) qual->resize(seq.size(), '~');
                 rec_off.push_back(seq.size());
                 if (stop < 0 && pos >= n) {
                     // EOF: the next call finds no name and ends the file
@@ -269,17 +273,17 @@ class RecordReader {
             if (pos >= n) { seq.resize(start); return; }  // -2: no quality string
             pos++;
             const size_t want = seq.size() - start;
-            size_t got = 0;
-            while (pos < n && got < want) {
+            std::vector<uint8_t> q;
+            while (pos < n && q.size() < want) {  // quality lines appended like sequence lines, :211
                 size_t e = pos;
                 while (e < n && b[e] != '\n') e++;
-                size_t l = e - pos;
-                got += l;
-                if (l && got > 1 && b[e - 1] == '\r') got--;
+                q.insert(q.end(), b + pos, b + e);
                 pos = e < n ? e + 1 : n;
+                if (q.size() > 1 && q.back() == '\r') q.pop_back();
             }
             last_char = 0;
-            if (got != want) { seq.resize(start); return; }  // -2: truncated quality
+            if (q.size() != want) { seq.resize(start); return; }  // -2: quality string of a different length
+            if (qual) { qual->resize(start, '~'); qual->insert(qual->end(), q.begin(), q.end()); }
             rec_off.push_back(seq.size());
         }
     }

@@ -2,7 +2,8 @@
 // hot-path subcommands, built on the C ABI of librabbitkssd.so (include/rabbitkssd.h).
 //
 //   shuffle  -k -s -l -o                     (host only, src/shuffle.cpp:25-104)
-//   sketch   -i list -o out [-L shuf] [-q]   (GPU: rk_sketch_batch [+ rk_index_build])
+//   sketch   -i list -o out [-L shuf] [-q] [-Q q -n c]   (GPU: rk_sketch_batch_ex [+ rk_index_build];
+//                                             FASTA or FASTQ lists, plain or .gz)
 //   alldist  -i sketch|list -o out [-D -M -L]            (GPU: rk_index_build, rk_dist_rows)
 //   dist     -r ref -q qry -o out [-D -M -N -L]          (GPU: rk_dist_rows [+ rk_topn_rows])
 //   info     -i sketch -o out [-F]           (host only, src/subCommand.cpp:70-147)
@@ -100,8 +101,31 @@ static Args parse_args(int argc, char **argv, int first, const std::map<string, 
 // Replaces sketchFastaFile (src/sketch.cpp:318-593): genomes keep list order and hashes are
 // sorted (the reference's order is unordered_set / OpenMP completion order; every consumer
 // treats them as sets).
+struct FastqOpts {
+    bool fastq = false;   // the list holds FASTQ files (sketchFastqFile, src/sketch.cpp:596-890)
+    int least_qual = 0;   // -Q
+    int least_num = 1;    // -n
+};
+
+// '>' -> FASTA list, '@' -> FASTQ list, anything else / mixed -> error (src/sketch.cpp:52-94,
+// src/subCommand.cpp:54-62).  *.gz names are accepted by suffix like isFastaGZList/isFastqGZList.
+static bool list_is_fastq(const vector<string> &files)
+{
+    int n_fa = 0, n_fq = 0;
+    for (const string &f : files) {
+        int c;
+        if (ends_with(f, ".gz")) c = (ends_with(f, ".fq.gz") || ends_with(f, ".fastq.gz")) ? '@' : '>';
+        else c = first_byte(f);
+        if (c == '>') n_fa++;
+        else if (c == '@') n_fq++;
+        else die("the input file list for sketching must be list of fasta and fastq file in normal format or gz format");
+    }
+    if (n_fa && n_fq) die("the input file list for sketching must be list of fasta and fastq file in normal format or gz format");
+    return n_fq > 0;
+}
+
 static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf &shuf, int threads,
-                        SketchSet &out, const string &out_path_in)
+                        SketchSet &out, const string &out_path_in, const FastqOpts &fq = FastqOpts())
 {
     const double t0 = get_sec();
     rk_params P;
@@ -126,7 +150,7 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
     size_t next = 0;
     uint64_t total_windows = 0;
     while (next < files.size()) {
-        vector<vector<uint8_t>> seqs;
+        vector<vector<uint8_t>> seqs, quals;
         vector<vector<uint64_t>> offs;
         size_t first = next;
         uint64_t bytes = 0;
@@ -138,6 +162,7 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
         }
         const size_t nb = next - first;
         seqs.resize(nb);
+        quals.resize(nb);
         offs.resize(nb);
         std::vector<std::thread> pool;
         std::vector<int> ok(nb, 1);
@@ -145,22 +170,28 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
         for (int t = 0; t < nt; t++)
             pool.emplace_back([&, t]() {
                 for (size_t i = (size_t)t; i < nb; i += (size_t)nt)
-                    ok[i] = RecordReader::read_file(files[first + i], seqs[i], offs[i]) ? 1 : 0;
+                    ok[i] = RecordReader::read_file(files[first + i], seqs[i], offs[i], fq.fastq ? &quals[i] : nullptr) ? 1 : 0;
             });
         for (auto &th : pool) th.join();
-        vector<uint8_t> seq;
+        vector<uint8_t> seq, qual;
         vector<uint64_t> rec_off{0}, genome_rec{0};
         for (size_t i = 0; i < nb; i++) {
             if (!ok[i]) die("cannot open the genome file: %s", files[first + i].c_str());
             const uint64_t base = seq.size();
             seq.insert(seq.end(), seqs[i].begin(), seqs[i].end());
+            if (fq.fastq) {
+                quals[i].resize(seqs[i].size(), '~');
+                qual.insert(qual.end(), quals[i].begin(), quals[i].end());
+                vector<uint8_t>().swap(quals[i]);
+            }
             for (size_t r = 1; r < offs[i].size(); r++) rec_off.push_back(base + offs[i][r]);
             genome_rec.push_back(rec_off.size() - 1);
             vector<uint8_t>().swap(seqs[i]);
         }
         rk_sketches *sk = nullptr;
-        gpu.check(rk_sketch_batch(gpu.ctx, flt, seq.data(), rec_off.data(), rec_off.size() - 1, genome_rec.data(),
-                                  (uint32_t)nb, &sk), "rk_sketch_batch");
+        gpu.check(rk_sketch_batch_ex(gpu.ctx, flt, seq.data(), fq.fastq ? qual.data() : nullptr, fq.least_qual,
+                                     (uint32_t)std::max(1, fq.least_num), rec_off.data(), rec_off.size() - 1,
+                                     genome_rec.data(), (uint32_t)nb, &sk), "rk_sketch_batch_ex");
         vector<uint64_t> off(nb + 1);
         vector<uint32_t> h(rk_sketches_total(sk));
         gpu.check(rk_sketches_download(sk, h.data(), off.data()), "rk_sketches_download");
@@ -275,17 +306,16 @@ static void load_or_sketch(Gpu &gpu, const string &input, bool is_query, const A
     // list of FASTA files (src/subCommand.cpp:174-181): sketch into <list>.sketch
     const vector<string> files = read_list(input);
     if (files.empty()) die("cannot open the inputFile or empty list: %s", input.c_str());
-    for (const string &f : files) {
-        const int c = first_byte(f);
-        if (c == '@') die("FASTQ input lists are not supported by this build (FASTA only)");
-        if (c != '>') die("the input file list for sketching must be list of fasta and fastq file");
-    }
+    FastqOpts fq;
+    fq.fastq = list_is_fastq(files);
+    fq.least_qual = a.num("Q", 0);
+    fq.least_num = a.num("n", 1);
     Shuf shuf;
     const string shuf_file = a.str("L", "shuf_file/L3K10.shuf");
     cerr << "---read the shuffle file: " << shuf_file << endl;
     if (!read_shuf(shuf_file, shuf, err)) die("read_shuffle_dim(), %s", err.c_str());
     sketch_path = input + ".sketch";
-    sketch_list(gpu, input, is_query, shuf, threads, s, sketch_path);
+    sketch_list(gpu, input, is_query, shuf, threads, s, sketch_path, fq);
 }
 
 static int cmd_shuffle(const Args &a)
@@ -316,17 +346,13 @@ static int cmd_sketch(const Args &a)
     const string shuf_file = a.str("L", "shuf_file/L3K10.shuf");
     cerr << "---read the shuffle file: " << shuf_file << endl;
     if (!read_shuf(shuf_file, shuf, err)) die("read_shuffle_dim(), %s", err.c_str());
-    const vector<string> files = read_list(in);
-    for (const string &f : files) {
-        const bool gz = ends_with(f, ".gz");
-        const int c = gz ? '>' : first_byte(f);
-        if (c == '@' || ends_with(f, ".fq.gz") || ends_with(f, ".fastq.gz"))
-            die("FASTQ input lists are not supported by this build (FASTA only)");
-        if (c != '>') die("command_sketch(), the input file list for sketching must be list of fasta and fastq file in normal format or gz format");
-    }
+    FastqOpts fq;
+    fq.fastq = list_is_fastq(read_list(in));
+    fq.least_qual = a.num("Q", 0);
+    fq.least_num = a.num("n", 1);
     SketchSet s;
     string out_path = out;
-    sketch_list(gpu, in, is_query, shuf, threads, s, out_path);
+    sketch_list(gpu, in, is_query, shuf, threads, s, out_path, fq);
     if (!is_sketch_file(out_path)) out_path += ".sketch";
     if (!is_query) rk_index_free(build_index(gpu, s, out_path, true));
     return 0;

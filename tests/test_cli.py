@@ -188,3 +188,31 @@ def test_cli_dist_matches_reference_text(tmp_path):
             got = (tmp_path / "o.txt").read_text().split("\n")
             assert [x for x in got[1:] if x] == want, case["file"]   # same order as the reference at -t 1
     assert os.path.exists(str(ref) + ".dict") and os.path.exists(str(ref) + ".index")
+
+
+@pytest.mark.gpu
+def test_cli_fastq_list_with_quality_and_count_options(tmp_path):
+    """sketch -Q/-n on a FASTQ list (sketchFastqFile, src/sketch.cpp:596-890) == oracle restatement"""
+    from test_gpu_parity import make_fastq
+    k, s, l = 8, 5, 2
+    shuf = tmp_path / "t.shuf"
+    run(["shuffle", "-k", k, "-s", s, "-l", l, "-o", shuf])
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    paths = []
+    for seed in (5, 6):
+        p = tmp_path / ("reads%d.fq" % seed)
+        p.write_bytes(make_fastq(seed))
+        paths.append(str(p))
+    lst = tmp_path / "fq.list"
+    lst.write_text("\n".join(paths) + "\n")
+    run(["sketch", "-i", lst, "-L", shuf, "-o", tmp_path / "fq", "-Q", 45, "-n", 2, "-q"], cwd=tmp_path)
+    info, names, h, off = ok.read_sketches32(str(tmp_path / "fq.sketch"))
+    assert names == paths and not os.path.exists(tmp_path / "fq.sketch.dict")   # -q: no index
+    for i, p in enumerate(paths):
+        sq, ql, o = ok.parse_fastq_bytes(open(p, "rb").read())
+        want = ok.sketch_records_fastq(param, table, sq, ql, o, 45, 2)
+        assert h[int(off[i]):int(off[i + 1])].astype(np.uint64).tolist() == want.tolist()
+    # a list mixing FASTA and FASTQ is rejected like the reference does
+    mixed = tmp_path / "mixed.list"
+    mixed.write_text(paths[0] + "\n" + os.path.join(GOLDEN, "sketch", "c0_s0.fa") + "\n")
+    assert run(["sketch", "-i", mixed, "-L", shuf, "-o", tmp_path / "m"], check=False).returncode == 1

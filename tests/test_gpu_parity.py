@@ -283,3 +283,44 @@ def test_end_to_end_sketch_index_alldist(ctx):
     mine, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05)
     assert len(want) >= 45 * 2  # two full clades of 10 strains
     assert_hits_equal(mine, want)
+
+
+# ------------------------------------------------------------------ FASTQ (f1)
+def make_fastq(seed, n_reads=400, read_len=150, genome_len=20000):
+    """reads sampled (with repeats -> occurrence counts > 1) from one genome, random qualities"""
+    rng = np.random.default_rng(seed)
+    g = synth.clade_genome(seed, 0, genome_len)
+    out = []
+    for r in range(n_reads):
+        p = int(rng.integers(0, genome_len - read_len))
+        seq = g[p:p + read_len].copy()
+        if r % 17 == 0:
+            seq[int(rng.integers(0, read_len))] = ord("N")
+        q = rng.integers(33, 74, size=read_len).astype(np.uint8)
+        out.append(b"@r%d extra\n" % r + seq.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("least_qual,least_num", [(0, 1), (40, 1), (0, 2), (45, 3), (127, 1)])
+def test_fastq_quality_gate_and_occurrence_count(ctx, least_qual, least_num):
+    k, s, l = 8, 5, 2
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    flt = ctx.filter(capi.params_init(k, s, l), table)
+    files = [make_fastq(seed) for seed in (1, 2, 3)]
+    seqs, quals, rec_off, genome_rec, wants = [], [], [0], [0], []
+    for data in files:
+        sq, ql, off = ok.parse_fastq_bytes(data)
+        wants.append(ok.sketch_records_fastq(param, table, sq, ql, off, least_qual, least_num))
+        seqs.append(sq)
+        quals.append(ql)
+        rec_off.extend((rec_off[-1] + off[1:]).tolist())
+        genome_rec.append(len(rec_off) - 1)
+    sk = ctx.sketch_batch_fastq(flt, np.concatenate(seqs), np.concatenate(quals), np.array(rec_off, dtype=np.uint64),
+                                np.array(genome_rec, dtype=np.uint64), least_qual, least_num)
+    gh, goff = sk.download()
+    for g, want in enumerate(wants):
+        assert np.array_equal(gh[int(goff[g]):int(goff[g + 1])].astype(np.uint64), want), (g, least_qual, least_num)
+    if least_qual == 0 and least_num == 1:
+        assert sum(len(w) for w in wants) > 100
+    if least_qual == 127:
+        assert sk.total == 0
