@@ -10,7 +10,7 @@
  *   rk_sketch_batch        <- per-genome loop of sketchFastaFile
  *                                                        src/sketch.cpp:455-566 (and :173-238)
  *   rk_sketch_batch_ex     <- per-file loop of sketchFastqFile   src/sketch.cpp:741-866
- *   rk_index_build         <- transSketches (32-bit)     src/sketch.cpp:970-1017
+ *   rk_index_build         <- transSketches              src/sketch.cpp:970-1017 (32-bit), :904-969 (64-bit)
  *   rk_index_import/export <- .dict/.index load/store    src/dist.cpp:86-129, src/sketch.cpp:991-1011
  *   rk_dist_rows           <- row loop of index_tridist  src/dist.cpp:174-258
  *                             row loop of index_dist     src/dist.cpp:560-692 (without -N)
@@ -46,7 +46,7 @@ typedef enum rk_status {
     RK_ERR_HIP = -3,        /* a HIP runtime call failed                                */
     RK_ERR_NOMEM = -4,      /* host or device allocation failed                         */
     RK_ERR_CAPACITY = -5,   /* caller-provided output buffer too small                  */
-    RK_ERR_UNSUPPORTED = -6 /* e.g. 64-bit hash layout (half_k - drlevel > 8)           */
+    RK_ERR_UNSUPPORTED = -6 /* outside this build's limits (e.g. >= 2^32 postings)      */
 } rk_status;
 
 typedef struct rk_ctx rk_ctx;
@@ -135,6 +135,12 @@ int rk_sketches_from_host(rk_ctx *ctx, const uint32_t *hashes, const uint64_t *o
 /* same from device-resident arrays (copied device-to-device into a library-owned object) */
 int rk_sketches_from_dev(rk_ctx *ctx, const uint32_t *hashes_dev, const uint64_t *off_dev,
                          uint32_t n_genomes, rk_sketches **out);
+/* 64-bit hash layout (use64: half_k - drlevel > 8, src/sketch.cpp:336): the sketch kernel produces it
+ * by itself when rk_hash_bits() > 32; these move such sketches across the boundary. */
+int rk_sketches_from_host64(rk_ctx *ctx, const uint64_t *hashes, const uint64_t *off,
+                            uint32_t n_genomes, rk_sketches **out);
+int rk_sketches_download64(const rk_sketches *s, uint64_t *hashes, uint64_t *off);
+int rk_sketches_is64(const rk_sketches *s);
 uint32_t rk_sketches_count(const rk_sketches *s);
 uint64_t rk_sketches_total(const rk_sketches *s);
 /* number of k-mer windows seen by the last sketch call that produced s (0 if imported) */
@@ -158,6 +164,13 @@ int rk_index_import(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const
                     int hash_bits, const uint32_t *ref_sizes, uint32_t n_ref, rk_index **out);
 /* To the on-disk pair: postings[total] and (optional) dense counts[2^hash_bits]. */
 int rk_index_export(const rk_index *idx, uint32_t *postings, uint32_t *counts);
+/* 64-bit hash layout: the sparse .index variant {u64 n; u64 hash[n]; u32 count[n]} with the .dict
+ * posting blocks in the same order (src/sketch.cpp:942-963, read at src/dist.cpp:36-82).  Export
+ * lists the hashes ascending; import accepts any block order (the reference writes hash-map order). */
+int rk_index_export64(const rk_index *idx, uint32_t *postings, uint64_t *hashes, uint32_t *counts);
+int rk_index_import64(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const uint64_t *hashes,
+                      const uint32_t *counts, uint64_t n_hash, int hash_bits, const uint32_t *ref_sizes,
+                      uint32_t n_ref, rk_index **out);
 uint64_t rk_index_total(const rk_index *idx);    /* H = number of postings        */
 uint64_t rk_index_distinct(const rk_index *idx); /* U = number of distinct hashes */
 uint32_t rk_index_genomes(const rk_index *idx);

@@ -134,6 +134,25 @@ uint32_t ok_topn_row(const ok_hit_t *row_hits, uint32_t n, uint64_t max_neighbor
 int ok_format_hit(char *buf, size_t cap, const char *name_a, const char *name_b, int common,
                   int size0, int size1, double jorc, double dist);
 
+/* ---- 64-bit hash layout (use64 = half_k - drlevel > 8), kssd_oracle64.c ---------------- */
+int ok_save_sketches64(const char *path, const ok_sketch_info_t *info, const char *const *names,
+                       const uint64_t *hashes, const uint64_t *off);
+int ok_read_sketches64(const char *path, ok_sketch_info_t *info, char **names_blob, uint64_t **hashes,
+                       uint64_t **off);
+/* I2: src/sketch.cpp:904-969; uhash ascending, postings grouped by hash, genome asc inside */
+int ok_index_build64(const uint64_t *hashes, const uint64_t *off, uint32_t n_genomes, uint64_t **uhash,
+                     uint32_t **ucount, uint32_t **postings, uint64_t *n_hash, uint64_t *total);
+int ok_write_index64(const char *dict_path, const char *index_path, const uint32_t *postings,
+                     const uint64_t *uhash, const uint32_t *ucount, uint64_t n_hash, uint64_t total);
+int ok_read_index64(const char *dict_path, const char *index_path, uint32_t **postings, uint64_t **uhash,
+                    uint32_t **ucount, uint64_t *n_hash, uint64_t *total);
+/* src/dist.cpp:181-191 / :566-576 + the common epilogue */
+int64_t ok_index_dist64(const uint64_t *uhash, const uint32_t *ucount, uint64_t n_hash,
+                        const uint32_t *postings, const uint32_t *ref_sizes, uint32_t n_ref,
+                        const uint64_t *q_hashes, const uint64_t *q_off, uint32_t n_query, int triangle,
+                        int metric, int kmer_size, double max_dist, int threads, int32_t *common_dense,
+                        ok_hit_t **hits_out);
+
 void ok_free(void *p);
 
 #ifdef __cplusplus

@@ -32,8 +32,8 @@ HIT_DTYPE = np.dtype([("row", "<u4"), ("col", "<u4"), ("common", "<i4"), ("size0
 
 def build(force=False):
     so = os.path.join(_DIR, "liboracle.so")
-    src = os.path.join(_DIR, "kssd_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_DIR, f) for f in ("kssd_oracle.c", "kssd_oracle64.c", "kssd_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -46,6 +46,7 @@ def lib():
         L.ok_sketch_records_fastq.restype = C.c_int64
         L.ok_count_windows.restype = C.c_uint64
         L.ok_index_dist32.restype = C.c_int64
+        L.ok_index_dist64.restype = C.c_int64
         L.ok_topn_row.restype = C.c_uint32
         L.ok_free.argtypes = [C.c_void_p]
         _LIB = L
@@ -312,3 +313,109 @@ def dist_text(qnames, rnames, hits):
     """lines as src/dist.cpp:642 writes them: query \\t ref ..."""
     return [format_hit(qnames[h["row"]], rnames[h["col"]], h["common"], h["size0"], h["size1"],
                        h["jorc"], h["dist"]) for h in hits]
+
+
+# ---- 64-bit hash layout (use64) ---------------------------------------------------------------
+def save_sketches64(path, half_k, half_subk, drlevel, names, hashes, off):
+    info = SketchInfo(0, half_k, half_subk, drlevel, len(names))
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    rc = lib().ok_save_sketches64(path.encode(), C.byref(info), arr, _p(hashes, C.c_uint64), _p(off, C.c_uint64))
+    if rc:
+        raise OSError("ok_save_sketches64 failed: %d" % rc)
+
+
+def read_sketches64(path):
+    info = SketchInfo()
+    blob = C.c_void_p()
+    h = C.POINTER(C.c_uint64)()
+    off = C.POINTER(C.c_uint64)()
+    rc = lib().ok_read_sketches64(path.encode(), C.byref(info), C.byref(blob), C.byref(h), C.byref(off))
+    if rc:
+        raise OSError("ok_read_sketches64 failed: %d" % rc)
+    n = info.genomeNumber
+    o = np.ctypeslib.as_array(off, shape=(n + 1,)).copy()
+    hashes = np.ctypeslib.as_array(h, shape=(max(int(o[-1]), 1),))[: int(o[-1])].copy()
+    names = []
+    addr = blob.value
+    for _ in range(n):
+        s = C.string_at(addr)
+        names.append(s.decode())
+        addr += len(s) + 1
+    for ptr in (blob, h, off):
+        lib().ok_free(ptr)
+    return info, names, hashes, o
+
+
+def index_build64(hashes, off):
+    """(uhash ascending u64[U], ucount u32[U], postings u32[H])"""
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    uh = C.POINTER(C.c_uint64)()
+    uc = C.POINTER(C.c_uint32)()
+    post = C.POINTER(C.c_uint32)()
+    nh = C.c_uint64()
+    tot = C.c_uint64()
+    rc = lib().ok_index_build64(_p(hashes, C.c_uint64), _p(off, C.c_uint64), C.c_uint32(len(off) - 1),
+                                C.byref(uh), C.byref(uc), C.byref(post), C.byref(nh), C.byref(tot))
+    if rc:
+        raise MemoryError("ok_index_build64 failed: %d" % rc)
+    uhash = np.ctypeslib.as_array(uh, shape=(max(nh.value, 1),))[: nh.value].copy()
+    ucount = np.ctypeslib.as_array(uc, shape=(max(nh.value, 1),))[: nh.value].copy()
+    postings = np.ctypeslib.as_array(post, shape=(max(tot.value, 1),))[: tot.value].copy()
+    for ptr in (uh, uc, post):
+        lib().ok_free(ptr)
+    return uhash, ucount, postings
+
+
+def write_index64(dict_path, index_path, postings, uhash, ucount):
+    postings = np.ascontiguousarray(postings, dtype=np.uint32)
+    uhash = np.ascontiguousarray(uhash, dtype=np.uint64)
+    ucount = np.ascontiguousarray(ucount, dtype=np.uint32)
+    rc = lib().ok_write_index64(dict_path.encode(), index_path.encode(), _p(postings, C.c_uint32),
+                                _p(uhash, C.c_uint64), _p(ucount, C.c_uint32), C.c_uint64(len(uhash)),
+                                C.c_uint64(len(postings)))
+    if rc:
+        raise OSError("ok_write_index64 failed: %d" % rc)
+
+
+def read_index64(dict_path, index_path):
+    post = C.POINTER(C.c_uint32)()
+    uh = C.POINTER(C.c_uint64)()
+    uc = C.POINTER(C.c_uint32)()
+    nh = C.c_uint64()
+    tot = C.c_uint64()
+    rc = lib().ok_read_index64(dict_path.encode(), index_path.encode(), C.byref(post), C.byref(uh), C.byref(uc),
+                               C.byref(nh), C.byref(tot))
+    if rc:
+        raise OSError("ok_read_index64 failed: %d" % rc)
+    postings = np.ctypeslib.as_array(post, shape=(max(tot.value, 1),))[: tot.value].copy()
+    uhash = np.ctypeslib.as_array(uh, shape=(max(nh.value, 1),))[: nh.value].copy()
+    ucount = np.ctypeslib.as_array(uc, shape=(max(nh.value, 1),))[: nh.value].copy()
+    for ptr in (post, uh, uc):
+        lib().ok_free(ptr)
+    return postings, uhash, ucount
+
+
+def index_dist64(uhash, ucount, postings, ref_sizes, q_hashes, q_off, triangle, metric, kmer_size, max_dist,
+                 threads=1, want_dense=False):
+    uhash = np.ascontiguousarray(uhash, dtype=np.uint64)
+    ucount = np.ascontiguousarray(ucount, dtype=np.uint32)
+    postings = np.ascontiguousarray(postings, dtype=np.uint32)
+    ref_sizes = np.ascontiguousarray(ref_sizes, dtype=np.uint32)
+    q_hashes = np.ascontiguousarray(q_hashes, dtype=np.uint64)
+    q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+    nq, nr = len(q_off) - 1, len(ref_sizes)
+    dense = np.zeros((nq, nr), dtype=np.int32) if want_dense else None
+    hits = C.c_void_p()
+    n = lib().ok_index_dist64(_p(uhash, C.c_uint64), _p(ucount, C.c_uint32), C.c_uint64(len(uhash)),
+                              _p(postings, C.c_uint32), _p(ref_sizes, C.c_uint32), C.c_uint32(nr),
+                              _p(q_hashes, C.c_uint64), _p(q_off, C.c_uint64), C.c_uint32(nq), int(triangle),
+                              int(metric), int(kmer_size), C.c_double(max_dist), int(threads),
+                              _p(dense, C.c_int32) if want_dense else None, C.byref(hits))
+    if n < 0:
+        raise MemoryError("ok_index_dist64 failed: %d" % n)
+    buf = C.string_at(hits.value, n * HIT_DTYPE.itemsize) if n else b""
+    lib().ok_free(hits)
+    return np.frombuffer(buf, dtype=HIT_DTYPE).copy(), dense

@@ -29,8 +29,10 @@ static void load_sketches(const char *path, std::vector<sketch_t> &out, sketchIn
     ok_sketch_info_t oi;
     char *names = nullptr;
     uint32_t *hashes = nullptr;
+    uint64_t *hashes64 = nullptr;
     uint64_t *off = nullptr;
     int rc = ok_read_sketches32(path, &oi, &names, &hashes, &off);
+    if (rc == -5) rc = ok_read_sketches64(path, &oi, &names, &hashes64, &off);  // use64 layout
     if (rc) {
         fprintf(stderr, "ref_driver: cannot read %s (%d)\n", path, rc);
         exit(2);
@@ -46,11 +48,13 @@ static void load_sketches(const char *path, std::vector<sketch_t> &out, sketchIn
         s.fileName = p;
         p += strlen(p) + 1;
         s.id = i;
-        s.hashSet.assign(hashes + off[i], hashes + off[i + 1]);
+        if (hashes64) s.hashSet64.assign(hashes64 + off[i], hashes64 + off[i + 1]);
+        else s.hashSet.assign(hashes + off[i], hashes + off[i + 1]);
         out.push_back(s);
     }
     free(names);
     free(hashes);
+    free(hashes64);
     free(off);
 }
 

@@ -18,9 +18,9 @@ EXPORTS = [
     "rk_device_count", "rk_ctx_create", "rk_ctx_destroy", "rk_last_error", "rk_version",
     "rk_free_host", "rk_params_init", "rk_hash_bits", "rk_filter_create", "rk_filter_free",
     "rk_sketch_batch", "rk_sketch_batch_ex", "rk_sketch_packed_dev", "rk_sketch_packed_dev_ex", "rk_pack_layout", "rk_pack_genomes",
-    "rk_sketches_from_host", "rk_sketches_from_dev", "rk_sketches_count", "rk_sketches_total", "rk_sketches_windows",
+    "rk_sketches_from_host", "rk_sketches_from_host64", "rk_sketches_download64", "rk_sketches_is64", "rk_sketches_from_dev", "rk_sketches_count", "rk_sketches_total", "rk_sketches_windows",
     "rk_sketches_download", "rk_sketches_hashes_dev", "rk_sketches_off_dev", "rk_sketches_free",
-    "rk_index_build", "rk_index_import", "rk_index_export", "rk_index_total",
+    "rk_index_build", "rk_index_import", "rk_index_export", "rk_index_import64", "rk_index_export64", "rk_index_total",
     "rk_index_distinct", "rk_index_genomes", "rk_index_hash_bits", "rk_index_sum_sq",
     "rk_index_free", "rk_index_blob_bytes", "rk_index_pack_dev", "rk_index_unpack_dev", "rk_dist_rows", "rk_dist_rows_dev", "rk_topn_rows", "rk_format_hit",
 ]
@@ -70,6 +70,7 @@ def lib():
                   "rk_index_sum_sq", "rk_index_blob_bytes"):
             getattr(L, f).restype = C.c_uint64
             getattr(L, f).argtypes = [C.c_void_p]
+        L.rk_sketches_is64.argtypes = [C.c_void_p]
         for f in ("rk_sketches_count", "rk_index_genomes"):
             getattr(L, f).restype = C.c_uint32
             getattr(L, f).argtypes = [C.c_void_p]
@@ -165,6 +166,24 @@ class Context:
         self.check(lib().rk_sketches_from_host(self._h, _ptr(hashes), _ptr(off),
                                                C.c_uint32(len(off) - 1), C.byref(h)))
         return Sketches(self, h)
+
+    def sketches_from_host64(self, hashes, off):
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        h = C.c_void_p()
+        self.check(lib().rk_sketches_from_host64(self._h, _ptr(hashes), _ptr(off), C.c_uint32(len(off) - 1), C.byref(h)))
+        return Sketches(self, h)
+
+    def index_import64(self, postings, hashes, counts, hash_bits_, ref_sizes):
+        postings = np.ascontiguousarray(postings, dtype=np.uint32)
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        ref_sizes = np.ascontiguousarray(ref_sizes, dtype=np.uint32)
+        h = C.c_void_p()
+        self.check(lib().rk_index_import64(self._h, _ptr(postings), C.c_uint64(len(postings)), _ptr(hashes),
+                                           _ptr(counts), C.c_uint64(len(hashes)), int(hash_bits_),
+                                           _ptr(ref_sizes), C.c_uint32(len(ref_sizes)), C.byref(h)))
+        return Index(self, h)
 
     def sketches_from_dev(self, hashes_dev_ptr, off_dev_ptr, n_genomes):
         h = C.c_void_p()
@@ -262,10 +281,19 @@ class Sketches(_Obj):
     def windows(self):
         return lib().rk_sketches_windows(self._h)
 
+    @property
+    def is64(self):
+        return bool(lib().rk_sketches_is64(self._h))
+
     def download(self):
+        """(hashes, off); hashes are uint64 for the 64-bit layout, uint32 otherwise"""
         off = np.zeros(self.count + 1, dtype=np.uint64)
-        hashes = np.zeros(self.total, dtype=np.uint32)
-        self.ctx.check(lib().rk_sketches_download(self._h, _ptr(hashes), _ptr(off)))
+        if self.is64:
+            hashes = np.zeros(self.total, dtype=np.uint64)
+            self.ctx.check(lib().rk_sketches_download64(self._h, _ptr(hashes), _ptr(off)))
+        else:
+            hashes = np.zeros(self.total, dtype=np.uint32)
+            self.ctx.check(lib().rk_sketches_download(self._h, _ptr(hashes), _ptr(off)))
         return hashes, off
 
 
@@ -299,6 +327,14 @@ class Index(_Obj):
     def pack_dev(self, blob_dev_ptr, blob_cap, stream=0):
         self.ctx.check(lib().rk_index_pack_dev(self._h, C.c_void_p(blob_dev_ptr), C.c_uint64(blob_cap),
                                                C.c_void_p(stream)))
+
+    def export64(self):
+        """(postings u32[H], hashes u64[U] ascending, counts u32[U]) -- the sparse .dict/.index content"""
+        postings = np.zeros(self.total, dtype=np.uint32)
+        hashes = np.zeros(self.distinct, dtype=np.uint64)
+        counts = np.zeros(self.distinct, dtype=np.uint32)
+        self.ctx.check(lib().rk_index_export64(self._h, _ptr(postings), _ptr(hashes), _ptr(counts)))
+        return postings, hashes, counts
 
     def export(self, want_counts=True):
         postings = np.zeros(self.total, dtype=np.uint32)

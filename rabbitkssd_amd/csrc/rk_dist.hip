@@ -506,10 +506,12 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
     if (!self || common_dense) {
         const rk_sketches *qs = queries;
         DevBuf<uint32_t> dummy;
-        const uint32_t *qh = qs ? qs->d_hashes : nullptr;
+        const void *qh = qs ? (qs->wide ? (const void *)qs->d_hashes64 : (const void *)qs->d_hashes) : nullptr;
         uint64_t qn = qs ? qs->total : idx->H;
         if (!qs)
             return rk_fail(ctx, RK_ERR_ARG, "common_dense needs explicit query sketches");
+        if (qs->wide != idx->wide)
+            return rk_fail(ctx, RK_ERR_ARG, "query sketches and index use different hash widths");
         RK_HIP(ctx, resolved.alloc(qn));
         rc = rk_resolve_ranges(ctx, idx, qh, qn, resolved.p, 0);
         if (rc) return rc;

@@ -36,15 +36,16 @@ __global__ void k_sizes(const uint64_t *off, uint32_t n, uint32_t *sizes)
     if (g < n) sizes[g] = (uint32_t)(off[g + 1] - off[g]);
 }
 
-__global__ void k_head_flags(const uint32_t *keys, uint64_t n, uint32_t *flags)
+template <class K> __global__ void k_head_flags(const K *keys, uint64_t n, uint32_t *flags)
 {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) flags[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1u : 0u;
 }
 
 // gidx = inclusive scan of head flags (1-based group number)
-__global__ void k_scatter_heads(const uint32_t *keys, const uint32_t *gidx, uint64_t n,
-                                uint32_t *uhash, uint32_t *upos, uint64_t U)
+template <class K>
+__global__ void k_scatter_heads(const K *keys, const uint32_t *gidx, uint64_t n, K *uhash, uint32_t *upos,
+                                uint64_t U)
 {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -105,8 +106,8 @@ __global__ void k_self_off(const uint64_t *off, const uint32_t *rank, uint32_t n
     self_off[g] = e < H ? rank[e] : n_self;
 }
 
-__global__ void k_dir(const uint32_t *uhash, uint64_t U, int shift, uint32_t n_buckets,
-                      uint32_t *dir)
+template <class K>
+__global__ void k_dir(const K *uhash, uint64_t U, int shift, uint32_t n_buckets, uint32_t *dir)
 {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > n_buckets) return;
@@ -164,16 +165,16 @@ __global__ void k_scatter_counts(const uint32_t *uhash, const uint32_t *upos, ui
     if (i < U) counts[uhash[i]] = upos[i + 1] - upos[i];
 }
 
-__global__ void k_resolve(const uint32_t *q, uint64_t n, const uint32_t *uhash,
-                          const uint32_t *upos, const uint32_t *dir, int dir_shift, int hash_bits,
-                          uint2 *ranges)
+template <class K>
+__global__ void k_resolve(const K *q, uint64_t n, const K *uhash, const uint32_t *upos, const uint32_t *dir,
+                          int dir_shift, int hash_bits, uint2 *ranges)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t h = q[i];
+    const K h = q[i];
     uint2 r = make_uint2(0, 0);
-    if (hash_bits >= 32 || (h >> hash_bits) == 0) {
-        const uint32_t b = h >> dir_shift;
+    if (hash_bits >= (int)(8 * sizeof(K)) || (h >> hash_bits) == 0) {
+        const uint32_t b = (uint32_t)(h >> dir_shift);
         uint32_t lo = dir[b], hi = dir[b + 1];
         while (lo < hi) {
             uint32_t mid = (lo + hi) >> 1;
@@ -195,8 +196,12 @@ int finish_index(rk_ctx *ctx, rk_index *idx)
     const uint32_t nb = 1u << dbits;
     DevBuf<uint32_t> dir;
     RK_HIP(ctx, dir.alloc((size_t)nb + 1));
-    hipLaunchKernelGGL(k_dir, dim3(blocks_for((uint64_t)nb + 1)), dim3(kThreads), 0, 0, idx->d_uhash,
-                       idx->U, idx->dir_shift, nb, dir.p);
+    if (idx->wide)
+        hipLaunchKernelGGL(k_dir<uint64_t>, dim3(blocks_for((uint64_t)nb + 1)), dim3(kThreads), 0, 0,
+                           idx->d_uhash64, idx->U, idx->dir_shift, nb, dir.p);
+    else
+        hipLaunchKernelGGL(k_dir<uint32_t>, dim3(blocks_for((uint64_t)nb + 1)), dim3(kThreads), 0, 0,
+                           idx->d_uhash, idx->U, idx->dir_shift, nb, dir.p);
     DevBuf<unsigned long long> acc;
     RK_HIP(ctx, acc.alloc(1));
     RK_HIP(ctx, hipMemset(acc.p, 0, 8));
@@ -213,13 +218,18 @@ int finish_index(rk_ctx *ctx, rk_index *idx)
 
 }  // namespace
 
-int rk_resolve_ranges(rk_ctx *ctx, const rk_index *idx, const uint32_t *q_hashes_dev, uint64_t n,
+int rk_resolve_ranges(rk_ctx *ctx, const rk_index *idx, const void *q_hashes_dev, uint64_t n,
                       uint2 *ranges_dev, hipStream_t stream)
 {
     if (!n) return RK_OK;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n)), dim3(kThreads), 0, stream, q_hashes_dev, n,
-                       idx->d_uhash, idx->d_upos, idx->d_dir, idx->dir_shift, idx->hash_bits,
-                       ranges_dev);
+    if (idx->wide)
+        hipLaunchKernelGGL(k_resolve<uint64_t>, dim3(blocks_for(n)), dim3(kThreads), 0, stream,
+                           (const uint64_t *)q_hashes_dev, n, idx->d_uhash64, idx->d_upos, idx->d_dir,
+                           idx->dir_shift, idx->hash_bits, ranges_dev);
+    else
+        hipLaunchKernelGGL(k_resolve<uint32_t>, dim3(blocks_for(n)), dim3(kThreads), 0, stream,
+                           (const uint32_t *)q_hashes_dev, n, idx->d_uhash, idx->d_upos, idx->d_dir,
+                           idx->dir_shift, idx->hash_bits, ranges_dev);
     RK_HIP(ctx, hipGetLastError());
     return RK_OK;
 }
@@ -231,6 +241,7 @@ void rk_index_free(rk_index *idx)
     if (!idx) return;
     (void)hipFree(idx->d_postings);
     (void)hipFree(idx->d_uhash);
+    (void)hipFree(idx->d_uhash64);
     (void)hipFree(idx->d_upos);
     (void)hipFree(idx->d_dir);
     (void)hipFree(idx->d_sizes);
@@ -251,9 +262,10 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     if (!ctx || !s || !out) return RK_ERR_ARG;
     *out = nullptr;
     if (hash_bits < 1) return rk_fail(ctx, RK_ERR_ARG, "hash_bits must be positive");
-    if (hash_bits > 32)
-        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "64-bit hash layout (hash_bits=%d) not supported",
-                       hash_bits);
+    if (hash_bits > 64) return rk_fail(ctx, RK_ERR_ARG, "hash_bits=%d", hash_bits);
+    if ((hash_bits > 32) != s->wide)
+        return rk_fail(ctx, RK_ERR_ARG, "hash_bits=%d does not match the sketches' %s-bit layout", hash_bits,
+                       s->wide ? "64" : "32");
     const uint64_t H = s->total;
     if (H >= 0xFFFFFFFFULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "more than 2^32-1 postings");
     RK_HIP(ctx, hipSetDevice(ctx->device));
@@ -263,6 +275,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     idx->n_ref = s->n;
     idx->H = H;
     idx->hash_bits = hash_bits;
+    idx->wide = s->wide;
     for (uint32_t g = 0; g < s->n; g++)
         idx->max_src_size = std::max<uint64_t>(idx->max_src_size, s->h_off[g + 1] - s->h_off[g]);
     struct Guard { rk_index *p; ~Guard() { if (p) rk_index_free(p); } } guard{idx};
@@ -277,8 +290,10 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     RK_HIP(ctx, hipMalloc((void **)&idx->d_selfrange, (H + 1) * sizeof(uint2)));
 
     DevBuf<uint32_t> iota, keys_sorted, sorted_e, flags;
+    DevBuf<uint64_t> keys_sorted64;
     RK_HIP(ctx, iota.alloc(H));
     RK_HIP(ctx, keys_sorted.alloc(H));
+    if (idx->wide) RK_HIP(ctx, keys_sorted64.alloc(H));
     RK_HIP(ctx, sorted_e.alloc(H));
     RK_HIP(ctx, flags.alloc(H));
     if (H) {
@@ -287,14 +302,24 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         // equal hashes stay in ascending genome order == hashMapId[hash].push_back(i) for
         // i ascending (src/sketch.cpp:979-985)
         size_t tmp_bytes = 0;
-        RK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, s->d_hashes, keys_sorted.p, iota.p,
-                                              sorted_e.p, H, 0, (unsigned)hash_bits));
         DevBuf<char> tmp;
-        RK_HIP(ctx, tmp.alloc(tmp_bytes));
-        RK_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, s->d_hashes, keys_sorted.p, iota.p,
-                                              sorted_e.p, H, 0, (unsigned)hash_bits));
-        hipLaunchKernelGGL(k_head_flags, dim3(blocks_for(H)), dim3(kThreads), 0, 0, keys_sorted.p, H,
-                           flags.p);
+        if (idx->wide) {
+            RK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, s->d_hashes64, keys_sorted64.p, iota.p,
+                                                  sorted_e.p, H, 0, (unsigned)hash_bits));
+            RK_HIP(ctx, tmp.alloc(tmp_bytes));
+            RK_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, s->d_hashes64, keys_sorted64.p, iota.p,
+                                                  sorted_e.p, H, 0, (unsigned)hash_bits));
+            hipLaunchKernelGGL(k_head_flags<uint64_t>, dim3(blocks_for(H)), dim3(kThreads), 0, 0, keys_sorted64.p,
+                               H, flags.p);
+        } else {
+            RK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, s->d_hashes, keys_sorted.p, iota.p,
+                                                  sorted_e.p, H, 0, (unsigned)hash_bits));
+            RK_HIP(ctx, tmp.alloc(tmp_bytes));
+            RK_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, s->d_hashes, keys_sorted.p, iota.p,
+                                                  sorted_e.p, H, 0, (unsigned)hash_bits));
+            hipLaunchKernelGGL(k_head_flags<uint32_t>, dim3(blocks_for(H)), dim3(kThreads), 0, 0, keys_sorted.p, H,
+                               flags.p);
+        }
         size_t tmp2 = 0;
         RK_HIP(ctx, rocprim::inclusive_scan(nullptr, tmp2, flags.p, iota.p, H, rocprim::plus<uint32_t>()));
         if (tmp2 > tmp_bytes) { RK_HIP(ctx, tmp.alloc(tmp2)); }
@@ -304,11 +329,16 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         idx->U = U32;
     }
     uint32_t *gidx = iota.p;  // 1-based group number of each sorted position
-    RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash, (idx->U + 1) * 4));
+    if (idx->wide) RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash64, (idx->U + 1) * 8));
+    else RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash, (idx->U + 1) * 4));
     RK_HIP(ctx, hipMalloc((void **)&idx->d_upos, (idx->U + 2) * 4));
     if (H) {
-        hipLaunchKernelGGL(k_scatter_heads, dim3(blocks_for(H)), dim3(kThreads), 0, 0, keys_sorted.p,
-                           gidx, H, idx->d_uhash, idx->d_upos, idx->U);
+        if (idx->wide)
+            hipLaunchKernelGGL(k_scatter_heads<uint64_t>, dim3(blocks_for(H)), dim3(kThreads), 0, 0,
+                               keys_sorted64.p, gidx, H, idx->d_uhash64, idx->d_upos, idx->U);
+        else
+            hipLaunchKernelGGL(k_scatter_heads<uint32_t>, dim3(blocks_for(H)), dim3(kThreads), 0, 0,
+                               keys_sorted.p, gidx, H, idx->d_uhash, idx->d_upos, idx->U);
         hipLaunchKernelGGL(k_postings_selfrange, dim3(blocks_for(H)), dim3(kThreads), 0, 0, sorted_e.p,
                            gidx, idx->d_upos, s->d_off, s->n, H, idx->d_postings, idx->d_selfrange);
     } else {
@@ -415,6 +445,8 @@ int rk_index_export(const rk_index *idx, uint32_t *postings, uint32_t *counts)
 {
     if (!idx) return RK_ERR_ARG;
     rk_ctx *ctx = idx->ctx;
+    if (idx->wide && counts)
+        return rk_fail(ctx, RK_ERR_ARG, "64-bit index: use rk_index_export64 (sparse .index layout)");
     RK_HIP(ctx, hipSetDevice(ctx->device));
     if (postings && idx->H)
         RK_HIP(ctx, hipMemcpy(postings, idx->d_postings, idx->H * 4, hipMemcpyDeviceToHost));
@@ -440,7 +472,7 @@ struct BlobHeader {
     uint64_t magic, bytes;
     uint64_t H, U, sum_sq, max_src_size, n_self;
     uint32_t n_ref, has_self;
-    int32_t hash_bits, dir_bits, dir_shift, pad_;
+    int32_t hash_bits, dir_bits, dir_shift, wide;
     uint64_t off_postings, off_uhash, off_upos, off_dir, off_sizes, off_self, off_selfoff, off_src;
 };
 constexpr uint64_t kBlobMagic = 0x31584449444b5352ULL;  // "RSKDIDX1"
@@ -460,9 +492,10 @@ void blob_layout(const rk_index *idx, BlobHeader *h)
     h->hash_bits = idx->hash_bits;
     h->dir_bits = idx->dir_bits;
     h->dir_shift = idx->dir_shift;
+    h->wide = idx->wide ? 1 : 0;
     uint64_t p = al256(sizeof(BlobHeader));
     h->off_postings = p; p = al256(p + (idx->H + 1) * 4);
-    h->off_uhash = p;    p = al256(p + (idx->U + 1) * 4);
+    h->off_uhash = p;    p = al256(p + (idx->U + 1) * (idx->wide ? 8 : 4));
     h->off_upos = p;     p = al256(p + (idx->U + 2) * 4);
     h->off_dir = p;      p = al256(p + ((1ULL << idx->dir_bits) + 1) * 4);
     h->off_sizes = p;    p = al256(p + ((uint64_t)idx->n_ref + 1) * 4);
@@ -497,7 +530,8 @@ int rk_index_pack_dev(const rk_index *idx, void *blob_dev, uint64_t blob_cap, vo
     RK_HIP(ctx, hipSetDevice(ctx->device));
     RK_HIP(ctx, hipMemcpyAsync(b, &h, sizeof(h), hipMemcpyHostToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(b + h.off_postings, idx->d_postings, idx->H * 4, hipMemcpyDeviceToDevice, st));
-    RK_HIP(ctx, hipMemcpyAsync(b + h.off_uhash, idx->d_uhash, idx->U * 4, hipMemcpyDeviceToDevice, st));
+    if (idx->wide) RK_HIP(ctx, hipMemcpyAsync(b + h.off_uhash, idx->d_uhash64, idx->U * 8, hipMemcpyDeviceToDevice, st));
+    else RK_HIP(ctx, hipMemcpyAsync(b + h.off_uhash, idx->d_uhash, idx->U * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(b + h.off_upos, idx->d_upos, (idx->U + 1) * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(b + h.off_dir, idx->d_dir, ((1ULL << idx->dir_bits) + 1) * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(b + h.off_sizes, idx->d_sizes, (uint64_t)idx->n_ref * 4, hipMemcpyDeviceToDevice, st));
@@ -533,18 +567,21 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
     idx->hash_bits = h.hash_bits;
     idx->dir_bits = h.dir_bits;
     idx->dir_shift = h.dir_shift;
+    idx->wide = h.wide != 0;
     BlobHeader chk;
     blob_layout(idx, &chk);  // offsets must be the ones this library would produce
     idx->d_selfrange = nullptr;
     const char *b = (const char *)blob_dev;
     const uint64_t nb = (1ULL << idx->dir_bits) + 1;
     RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (idx->H + 1) * 4));
-    RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash, (idx->U + 1) * 4));
+    if (idx->wide) RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash64, (idx->U + 1) * 8));
+    else RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash, (idx->U + 1) * 4));
     RK_HIP(ctx, hipMalloc((void **)&idx->d_upos, (idx->U + 2) * 4));
     RK_HIP(ctx, hipMalloc((void **)&idx->d_dir, nb * 4));
     RK_HIP(ctx, hipMalloc((void **)&idx->d_sizes, ((size_t)idx->n_ref + 1) * 4));
     RK_HIP(ctx, hipMemcpyAsync(idx->d_postings, b + h.off_postings, idx->H * 4, hipMemcpyDeviceToDevice, st));
-    RK_HIP(ctx, hipMemcpyAsync(idx->d_uhash, b + h.off_uhash, idx->U * 4, hipMemcpyDeviceToDevice, st));
+    if (idx->wide) RK_HIP(ctx, hipMemcpyAsync(idx->d_uhash64, b + h.off_uhash, idx->U * 8, hipMemcpyDeviceToDevice, st));
+    else RK_HIP(ctx, hipMemcpyAsync(idx->d_uhash, b + h.off_uhash, idx->U * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(idx->d_upos, b + h.off_upos, (idx->U + 1) * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(idx->d_dir, b + h.off_dir, nb * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(idx->d_sizes, b + h.off_sizes, (uint64_t)idx->n_ref * 4, hipMemcpyDeviceToDevice, st));
@@ -557,6 +594,95 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
         RK_HIP(ctx, hipMemcpyAsync(idx->d_src_off, b + h.off_src, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
     }
     RK_HIP(ctx, hipStreamSynchronize(st));
+    guard.p = nullptr;
+    *out = idx;
+    return RK_OK;
+}
+
+}  // extern "C"
+
+// ---- 64-bit hash layout: sparse .index = {u64 n; u64 hash[n]; u32 count[n]} ------------------
+// (src/sketch.cpp:961-963, read back at src/dist.cpp:36-82; any block order is legal)
+namespace {
+__global__ void k_counts_from_upos(const uint32_t *upos, uint64_t U, uint32_t *counts)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < U) counts[i] = upos[i + 1] - upos[i];
+}
+}  // namespace
+
+extern "C" {
+
+int rk_index_export64(const rk_index *idx, uint32_t *postings, uint64_t *hashes, uint32_t *counts)
+{
+    if (!idx) return RK_ERR_ARG;
+    rk_ctx *ctx = idx->ctx;
+    if (!idx->wide) return rk_fail(ctx, RK_ERR_ARG, "32-bit index: use rk_index_export (dense .index layout)");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    if (postings && idx->H) RK_HIP(ctx, hipMemcpy(postings, idx->d_postings, idx->H * 4, hipMemcpyDeviceToHost));
+    if (hashes && idx->U) RK_HIP(ctx, hipMemcpy(hashes, idx->d_uhash64, idx->U * 8, hipMemcpyDeviceToHost));
+    if (counts && idx->U) {
+        DevBuf<uint32_t> c;
+        RK_HIP(ctx, c.alloc(idx->U));
+        hipLaunchKernelGGL(k_counts_from_upos, dim3(blocks_for(idx->U)), dim3(kThreads), 0, 0, idx->d_upos, idx->U, c.p);
+        RK_HIP(ctx, hipGetLastError());
+        RK_HIP(ctx, hipMemcpy(counts, c.p, idx->U * 4, hipMemcpyDeviceToHost));
+    }
+    return RK_OK;
+}
+
+int rk_index_import64(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const uint64_t *hashes,
+                      const uint32_t *counts, uint64_t n_hash, int hash_bits, const uint32_t *ref_sizes,
+                      uint32_t n_ref, rk_index **out)
+{
+    if (!ctx || !out || (!postings && total) || ((!hashes || !counts) && n_hash) || (!ref_sizes && n_ref))
+        return RK_ERR_ARG;
+    *out = nullptr;
+    if (hash_bits <= 32 || hash_bits > 64) return rk_fail(ctx, RK_ERR_ARG, "hash_bits=%d is not a 64-bit layout", hash_bits);
+    if (total >= 0xFFFFFFFFULL || n_hash >= 0xFFFFFFFFULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "more than 2^32-1 postings");
+    // the file may list the posting blocks in any order (the reference writes hash-map order):
+    // bring them into ascending hash order on the host, then upload
+    std::vector<uint64_t> start(n_hash + 1, 0);
+    for (uint64_t i = 0; i < n_hash; i++) start[i + 1] = start[i] + counts[i];
+    if (start[n_hash] != total)
+        return rk_fail(ctx, RK_ERR_ARG, "mismatched total hash number: index says %llu, dict has %llu",
+                       (unsigned long long)start[n_hash], (unsigned long long)total);
+    std::vector<uint32_t> order(n_hash);
+    for (uint64_t i = 0; i < n_hash; i++) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hashes[a] < hashes[b]; });
+    std::vector<uint64_t> uh(n_hash + 1);
+    std::vector<uint32_t> up(n_hash + 2, 0), post(total + 1);
+    uint64_t w = 0;
+    for (uint64_t r = 0; r < n_hash; r++) {
+        const uint32_t i = order[r];
+        if (r && hashes[i] == uh[r - 1]) return rk_fail(ctx, RK_ERR_ARG, "duplicate hash in the index file");
+        uh[r] = hashes[i];
+        up[r] = (uint32_t)w;
+        memcpy(post.data() + w, postings + start[i], (size_t)counts[i] * 4);
+        w += counts[i];
+    }
+    up[n_hash] = (uint32_t)w;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    rk_index *idx = new (std::nothrow) rk_index;
+    if (!idx) return RK_ERR_NOMEM;
+    struct Guard { rk_index *p; ~Guard() { if (p) rk_index_free(p); } } guard{idx};
+    idx->ctx = ctx;
+    idx->wide = true;
+    idx->n_ref = n_ref;
+    idx->H = total;
+    idx->U = n_hash;
+    idx->hash_bits = hash_bits;
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_sizes, ((size_t)n_ref + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (total + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash64, (n_hash + 1) * 8));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_upos, (n_hash + 2) * 4));
+    RK_HIP(ctx, hipMemcpy(idx->d_sizes, ref_sizes, (size_t)n_ref * 4, hipMemcpyHostToDevice));
+    RK_HIP(ctx, hipMemcpy(idx->d_postings, post.data(), total * 4, hipMemcpyHostToDevice));
+    RK_HIP(ctx, hipMemcpy(idx->d_uhash64, uh.data(), n_hash * 8, hipMemcpyHostToDevice));
+    RK_HIP(ctx, hipMemcpy(idx->d_upos, up.data(), (n_hash + 1) * 4, hipMemcpyHostToDevice));
+    int rc = finish_index(ctx, idx);
+    if (rc) return rc;
+    RK_HIP(ctx, hipDeviceSynchronize());
     guard.p = nullptr;
     *out = idx;
     return RK_OK;

@@ -65,7 +65,9 @@ struct rk_sketches {
     uint32_t n = 0;
     uint64_t total = 0;
     uint64_t windows = 0;
-    uint32_t *d_hashes = nullptr;
+    bool wide = false;            // 64-bit hash layout (use64: half_k - drlevel > 8)
+    uint32_t *d_hashes = nullptr; // u32[total] when !wide
+    uint64_t *d_hashes64 = nullptr; // u64[total] when wide
     uint64_t *d_off = nullptr;
     std::vector<uint64_t> h_off;  // host mirror of d_off (n+1)
 };
@@ -80,7 +82,9 @@ struct rk_index {
     uint64_t sum_sq = 0;
     uint64_t max_src_size = 0;       // largest source sketch (built index only)
     uint32_t *d_postings = nullptr;  // u32[H]   (.dict order)
+    bool wide = false;               // 64-bit hashes: d_uhash64 instead of d_uhash
     uint32_t *d_uhash = nullptr;     // u32[U]   sorted distinct hashes
+    uint64_t *d_uhash64 = nullptr;   // u64[U]   (wide)
     uint32_t *d_upos = nullptr;      // u32[U+1] posting offsets
     uint32_t *d_dir = nullptr;       // u32[2^dir_bits+1] prefix directory into d_uhash
     uint32_t *d_sizes = nullptr;     // u32[n_ref] sketch sizes
@@ -92,5 +96,6 @@ struct rk_index {
 };
 
 // kernels/launchers implemented in the .hip files
-int rk_resolve_ranges(rk_ctx *ctx, const rk_index *idx, const uint32_t *q_hashes_dev, uint64_t n,
+// q_hashes_dev: u32[] or u64[] matching idx->wide
+int rk_resolve_ranges(rk_ctx *ctx, const rk_index *idx, const void *q_hashes_dev, uint64_t n,
                       uint2 *ranges_dev, hipStream_t stream);

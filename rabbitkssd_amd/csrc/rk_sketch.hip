@@ -70,6 +70,7 @@ struct SketchArgs {
     const int32_t *table;          // int32[16^half_subk]
     uint64_t tupmask, undomask0, undomask1;
     int32_t kmer, out2, dim_bits, hi_shift, dim_start, dim_end, dr_shift, und1_shift;
+    int32_t key_shift;             // emitted key = genome << key_shift | dr_tuple (32, or hash_bits when > 32)
     unsigned long long *cand;
     unsigned long long cand_cap;
     unsigned long long *n_cand;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
                     const uint64_t pf = (uint64_t)(v - a.dim_start);            // :519-521
                     const uint64_t dr = (((uni & a.undomask0) | ((uni & a.undomask1) << a.und1_shift)) >>
                                          a.dr_shift) | pf;                      // :524
-                    const unsigned long long key = ((unsigned long long)gid << 32) | (uint32_t)dr;
+                    const unsigned long long key = ((unsigned long long)gid << a.key_shift) | dr;
                     const uint32_t sl = atomicAdd(stage_n, 1u);
                     emitted++;
                     if (sl < kStageCap) stage[sl] = key;
@@ -312,12 +313,20 @@ __global__ void k_split_keys(const unsigned long long *ukeys, uint64_t n, uint32
     if (i < n) hashes[i] = (uint32_t)ukeys[i];
 }
 
+__global__ void k_split_keys64(const unsigned long long *ukeys, uint64_t n, int key_shift, uint64_t *hashes)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hashes[i] = ukeys[i] & ((1ULL << key_shift) - 1);
+}
+
 __global__ void k_genome_offsets(const unsigned long long *ukeys, uint64_t n, uint32_t n_genomes,
-                                 uint64_t *off)
+                                 int key_shift, uint64_t *off)
 {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g > n_genomes) return;
-    const unsigned long long key = (unsigned long long)g << 32;
+    // first key of genome g; g == n_genomes may not fit next to the hash bits: everything is below it
+    if (g == n_genomes) { off[g] = n; return; }
+    const unsigned long long key = (unsigned long long)g << key_shift;
     uint64_t lo = 0, hi = n;
     while (lo < hi) {
         uint64_t mid = (lo + hi) >> 1;
@@ -344,8 +353,6 @@ int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_di
 {
     if (!ctx || !p || !shuffled_dim || !out) return RK_ERR_ARG;
     *out = nullptr;
-    if (rk_hash_bits(p) > 32)
-        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "64-bit hash layout (half_k - drlevel > 8) not supported");
     if (p->half_subk < 1 || p->half_subk >= 8 || p->half_k > 16 || p->half_k < p->half_subk)
         return rk_fail(ctx, RK_ERR_ARG, "bad kssd parameters");
     RK_HIP(ctx, hipSetDevice(ctx->device));
@@ -424,6 +431,7 @@ void rk_sketches_free(rk_sketches *s)
 {
     if (!s) return;
     (void)hipFree(s->d_hashes);
+    (void)hipFree(s->d_hashes64);
     (void)hipFree(s->d_off);
     delete s;
 }
@@ -483,10 +491,49 @@ int rk_sketches_from_dev(rk_ctx *ctx, const uint32_t *hashes_dev, const uint64_t
     return RK_OK;
 }
 
+int rk_sketches_is64(const rk_sketches *s) { return s && s->wide ? 1 : 0; }
+
+int rk_sketches_from_host64(rk_ctx *ctx, const uint64_t *hashes, const uint64_t *off, uint32_t n, rk_sketches **out)
+{
+    if (!ctx || !off || !out || (!hashes && off[n])) return RK_ERR_ARG;
+    *out = nullptr;
+    for (uint32_t g = 0; g < n; g++)
+        if (off[g + 1] < off[g]) return rk_fail(ctx, RK_ERR_ARG, "offsets must be non-decreasing");
+    if (off[0] != 0) return rk_fail(ctx, RK_ERR_ARG, "off[0] must be 0");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    rk_sketches *s = new (std::nothrow) rk_sketches;
+    if (!s) return RK_ERR_NOMEM;
+    s->ctx = ctx;
+    s->n = n;
+    s->wide = true;
+    s->total = off[n];
+    s->h_off.assign(off, off + n + 1);
+    struct Guard { rk_sketches *p; ~Guard() { if (p) rk_sketches_free(p); } } guard{s};
+    RK_HIP(ctx, hipMalloc((void **)&s->d_hashes64, (s->total + 1) * 8));
+    RK_HIP(ctx, hipMalloc((void **)&s->d_off, ((size_t)n + 1) * 8));
+    if (s->total) RK_HIP(ctx, hipMemcpy(s->d_hashes64, hashes, s->total * 8, hipMemcpyHostToDevice));
+    RK_HIP(ctx, hipMemcpy(s->d_off, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+    guard.p = nullptr;
+    *out = s;
+    return RK_OK;
+}
+
+int rk_sketches_download64(const rk_sketches *s, uint64_t *hashes, uint64_t *off)
+{
+    if (!s) return RK_ERR_ARG;
+    rk_ctx *ctx = s->ctx;
+    if (!s->wide) return rk_fail(ctx, RK_ERR_ARG, "32-bit sketches: use rk_sketches_download");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    if (off) memcpy(off, s->h_off.data(), ((size_t)s->n + 1) * 8);
+    if (hashes && s->total) RK_HIP(ctx, hipMemcpy(hashes, s->d_hashes64, s->total * 8, hipMemcpyDeviceToHost));
+    return RK_OK;
+}
+
 int rk_sketches_download(const rk_sketches *s, uint32_t *hashes, uint64_t *off)
 {
     if (!s) return RK_ERR_ARG;
     rk_ctx *ctx = s->ctx;
+    if (s->wide && hashes) return rk_fail(ctx, RK_ERR_ARG, "64-bit sketches: use rk_sketches_download64");
     RK_HIP(ctx, hipSetDevice(ctx->device));
     if (off) memcpy(off, s->h_off.data(), ((size_t)s->n + 1) * 8);
     if (hashes && s->total)
@@ -511,6 +558,16 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
     hipStream_t stream = (hipStream_t)stream_v;
     RK_HIP(ctx, hipSetDevice(ctx->device));
     const rk_params &P = f->params;
+
+    // key = genome << key_shift | dr_tuple; the 64-bit layout (use64) needs room for the genome id
+    const int hash_bits = rk_hash_bits(&P);
+    const bool wide = hash_bits > 32;
+    const int key_shift = wide ? hash_bits : 32;
+    int gbits = 1;
+    while ((1ULL << gbits) < n_genomes) gbits++;
+    if (key_shift + gbits > 64)
+        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "%d-bit hashes leave no room for %u genome ids in one batch",
+                       hash_bits, n_genomes);
 
     // ---- chunk table: one wave per chunk of up to `cb` consecutive 1 KiB blocks
     uint64_t total_blocks = 0, total_len = 0;
@@ -582,6 +639,7 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             a.dim_end = P.dim_end;
             a.dr_shift = 4 * P.drlevel;
             a.und1_shift = (int32_t)P.kmer_size * 2 - P.half_outctx_len * 4;
+            a.key_shift = key_shift;
             a.cand = cand.p;
             a.cand_cap = cap;
             a.n_cand = d_counters.p;
@@ -611,20 +669,19 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
     RK_HIP(ctx, hipMalloc((void **)&s->d_off, ((size_t)n_genomes + 1) * 8));
     uint64_t n_unique = 0;
     DevBuf<unsigned long long> sorted, uniq;
+    s->wide = wide;
     if (n_cand) {
-        int gbits = 1;
-        while ((1ULL << gbits) < n_genomes) gbits++;
         RK_HIP(ctx, sorted.alloc(n_cand));
         RK_HIP(ctx, uniq.alloc(n_cand));
         DevBuf<unsigned long long> d_nuniq;
         RK_HIP(ctx, d_nuniq.alloc(1));
         size_t t1 = 0, t2 = 0;
-        RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t1, cand.p, sorted.p, n_cand, 0, (unsigned)(32 + gbits), stream));
+        RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t1, cand.p, sorted.p, n_cand, 0, (unsigned)(key_shift + gbits), stream));
         RK_HIP(ctx, rocprim::unique(nullptr, t2, sorted.p, uniq.p, d_nuniq.p, n_cand,
                                     rocprim::equal_to<unsigned long long>(), stream));
         DevBuf<char> tmp;
         RK_HIP(ctx, tmp.alloc(std::max(t1, t2)));
-        RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, t1, cand.p, sorted.p, n_cand, 0, (unsigned)(32 + gbits), stream));
+        RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, t1, cand.p, sorted.p, n_cand, 0, (unsigned)(key_shift + gbits), stream));
         if (min_count <= 1) {  // set semantics (FASTA, src/sketch.cpp:526-529)
             RK_HIP(ctx, rocprim::unique(tmp.p, t2, sorted.p, uniq.p, d_nuniq.p, n_cand,
                                         rocprim::equal_to<unsigned long long>(), stream));
@@ -661,12 +718,19 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
         n_unique = nu;
     }
     s->total = n_unique;
-    RK_HIP(ctx, hipMalloc((void **)&s->d_hashes, (n_unique + 1) * 4));
-    if (n_unique)
-        hipLaunchKernelGGL(k_split_keys, dim3(blocks_for(n_unique)), dim3(256), 0, stream, uniq.p, n_unique,
-                           s->d_hashes);
+    if (wide) {
+        RK_HIP(ctx, hipMalloc((void **)&s->d_hashes64, (n_unique + 1) * 8));
+        if (n_unique)
+            hipLaunchKernelGGL(k_split_keys64, dim3(blocks_for(n_unique)), dim3(256), 0, stream, uniq.p, n_unique,
+                               key_shift, s->d_hashes64);
+    } else {
+        RK_HIP(ctx, hipMalloc((void **)&s->d_hashes, (n_unique + 1) * 4));
+        if (n_unique)
+            hipLaunchKernelGGL(k_split_keys, dim3(blocks_for(n_unique)), dim3(256), 0, stream, uniq.p, n_unique,
+                               s->d_hashes);
+    }
     hipLaunchKernelGGL(k_genome_offsets, dim3(blocks_for((uint64_t)n_genomes + 1)), dim3(256), 0, stream,
-                       uniq.p, n_unique, n_genomes, s->d_off);
+                       uniq.p, n_unique, n_genomes, key_shift, s->d_off);
     RK_HIP(ctx, hipGetLastError());
     s->h_off.resize((size_t)n_genomes + 1);
     RK_HIP(ctx, hipMemcpyAsync(s->h_off.data(), s->d_off, ((size_t)n_genomes + 1) * 8, hipMemcpyDeviceToHost, stream));

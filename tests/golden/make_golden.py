@@ -160,6 +160,72 @@ def gen_dist(tmp):
               indent=1)
 
 
+def gen_dist64(tmp):
+    """use64 layout (half_k - drlevel > 8): K12 S6 L3 -> 36-bit hashes; real index_tridist/index_dist."""
+    d = os.path.join(HERE, "dist64")
+    os.makedirs(d, exist_ok=True)
+    K, S, L, BITS = 12, 6, 3, 36
+    rng = np.random.default_rng(64)
+    rparts, rnames = [], []
+    for c in range(3):
+        anc = np.unique(rng.integers(0, 1 << BITS, size=260, dtype=np.uint64))
+        for st in range(8):
+            keep = anc[rng.random(len(anc)) < 0.97 - 0.02 * st]
+            extra = rng.integers(0, 1 << BITS, size=12, dtype=np.uint64)
+            rparts.append(np.unique(np.concatenate([keep, extra])))
+            rnames.append("syn64/c%d_s%d.fna" % (c, st))
+    rparts.append(np.zeros(0, dtype=np.uint64)); rnames.append("edge/empty.fna")
+    rparts.append(rparts[2].copy()); rnames.append("edge/dup_of_2.fna")
+    rparts.append(np.array([0, 1, (1 << BITS) - 1], dtype=np.uint64)); rnames.append("edge/extremes.fna")
+    roff = np.concatenate([[0], np.cumsum([len(p) for p in rparts])]).astype(np.uint64)
+    rh = np.concatenate(rparts)
+    qparts, qnames = [], []
+    for qi in range(6):
+        src = rparts[qi * 4]
+        keep = src[rng.random(len(src)) < 0.85]
+        qparts.append(np.unique(np.concatenate([keep, rng.integers(0, 1 << BITS, size=25, dtype=np.uint64)])))
+        qnames.append("qry64/q%d.fna" % qi)
+    qparts.append(np.zeros(0, dtype=np.uint64)); qnames.append("qry64/empty.fna")
+    qoff = np.concatenate([[0], np.cumsum([len(p) for p in qparts])]).astype(np.uint64)
+    qh = np.concatenate(qparts)
+    ok.save_sketches64(os.path.join(d, "ref64.sketch"), K, S, L, rnames, rh, roff)
+    ok.save_sketches64(os.path.join(d, "qry64.sketch"), K, S, L, qnames, qh, qoff)
+    wref = os.path.join(tmp, "ref64.sketch")
+    ok.save_sketches64(wref, K, S, L, rnames, rh, roff)
+    uhash, ucount, postings = ok.index_build64(rh, roff)
+    # posting blocks in a scrambled (hash-map-like) order: any order is legal for the reader
+    perm = rng.permutation(len(uhash))
+    starts = np.concatenate([[0], np.cumsum(ucount.astype(np.int64))]).astype(np.int64)
+    scr_post = np.concatenate([postings[int(starts[i]):int(starts[i + 1])] for i in perm]) if len(perm) else postings
+    ok.write_index64(wref + ".dict", wref + ".index", scr_post, uhash[perm], ucount[perm])
+    rsizes = np.diff(roff).astype(np.uint32)
+    manifest = []
+    for metric, D in ((0, 0.05), (0, 1.0), (1, 0.2), (0, 1.5)):
+        name = "alldist64_M%d_D%g" % (metric, D)
+        ref("alldist", tmp, wref, name + ".out", D, metric, 2)
+        got = sorted_body(open(os.path.join(tmp, name + ".out")).read())
+        hits, _ = ok.index_dist64(uhash, ucount, postings, rsizes, rh, roff, 1, metric, 2 * K, D)
+        mine = sorted(x.rstrip("\n") for x in ok.alldist_text(rnames, hits))
+        assert mine == got, "alldist64 %s: restatement != reference" % name
+        open(os.path.join(d, name + ".ref.txt"), "w").write("\n".join(got) + "\n")
+        manifest.append({"file": name + ".ref.txt", "cmd": "alldist", "metric": metric, "max_dist": D, "lines": len(got)})
+    for metric, D, N in ((0, 0.3, 0), (1, 1.0, 2), (0, 1.0, 0)):
+        name = "dist64_M%d_D%g_N%d" % (metric, D, N)
+        ref("dist", tmp, wref, os.path.join(d, "qry64.sketch"), name + ".out", D, N, 1 if N else 0, metric, 1)
+        body = [x for x in open(os.path.join(tmp, name + ".out")).read().split("\n")[1:] if x]
+        hits, _ = ok.index_dist64(uhash, ucount, postings, rsizes, qh, qoff, 0, metric, 2 * K, D)
+        if N:
+            hits = np.concatenate([ok.topn_row(hits[hits["row"] == q], N) for q in range(len(qnames))])
+        mine = [x.rstrip("\n") for x in ok.dist_text(qnames, rnames, hits)]
+        assert mine == body, "dist64 %s: restatement != reference" % name
+        open(os.path.join(d, name + ".ref.txt"), "w").write("\n".join(body) + "\n")
+        manifest.append({"file": name + ".ref.txt", "cmd": "dist", "metric": metric, "max_dist": D,
+                         "max_neighbor": N, "lines": len(body)})
+    json.dump({"half_k": K, "half_subk": S, "drlevel": L, "hash_bits": BITS, "pinned": True,
+               "source": "real reference index_tridist/index_dist (use64 branch) via oracle/_ref/ref_driver",
+               "cases": manifest}, open(os.path.join(d, "manifest.json"), "w"), indent=1)
+
+
 def numpy_sketch(param, table, seq):
     """Independent (vectorised) restatement of src/sketch.cpp:491-530 for ONE record."""
     lut = np.full(256, -1, dtype=np.int64)
@@ -238,6 +304,7 @@ def main():
         gen_params()
         gen_shuf(tmp)
         gen_dist(tmp)
+        gen_dist64(tmp)
     gen_sketch()
     print("golden fixtures written to", HERE)
 

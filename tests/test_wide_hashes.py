@@ -1,0 +1,128 @@
+"""64-bit hash layout (use64: half_k - drlevel > 8).
+tests/golden/dist64 was produced by the REAL reference's use64 branch (index_tridist/index_dist
+reading a .dict/.index pair whose posting blocks are in scrambled, hash-map-like order)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as ok
+from rabbitkssd_amd import capi, synth
+
+D64 = os.path.join(GOLDEN, "dist64")
+
+
+def load():
+    man = json.load(open(os.path.join(D64, "manifest.json")))
+    _, rnames, rh, roff = ok.read_sketches64(os.path.join(D64, "ref64.sketch"))
+    _, qnames, qh, qoff = ok.read_sketches64(os.path.join(D64, "qry64.sketch"))
+    return man, (rnames, rh, roff), (qnames, qh, qoff)
+
+
+def test_oracle64_matches_reference_text():
+    man, (rnames, rh, roff), (qnames, qh, qoff) = load()
+    uhash, ucount, postings = ok.index_build64(rh, roff)
+    rsizes = np.diff(roff).astype(np.uint32)
+    kmer = 2 * man["half_k"]
+    for case in man["cases"]:
+        want = open(os.path.join(D64, case["file"])).read().split("\n")[:-1]
+        if case["cmd"] == "alldist":
+            hits, _ = ok.index_dist64(uhash, ucount, postings, rsizes, rh, roff, 1, case["metric"], kmer,
+                                      case["max_dist"], threads=2)
+            assert sorted(x.rstrip("\n") for x in ok.alldist_text(rnames, hits)) == want, case["file"]
+        else:
+            hits, _ = ok.index_dist64(uhash, ucount, postings, rsizes, qh, qoff, 0, case["metric"], kmer,
+                                      case["max_dist"])
+            if case["max_neighbor"]:
+                hits = np.concatenate([ok.topn_row(hits[hits["row"] == q], case["max_neighbor"])
+                                       for q in range(len(qnames))])
+            assert [x.rstrip("\n") for x in ok.dist_text(qnames, rnames, hits)] == want, case["file"]
+
+
+def test_oracle64_index_files_roundtrip(tmp_path):
+    _, (rnames, rh, roff), _ = load()
+    uhash, ucount, postings = ok.index_build64(rh, roff)
+    dp, ip = str(tmp_path / "x.dict"), str(tmp_path / "x.index")
+    ok.write_index64(dp, ip, postings, uhash, ucount)
+    assert os.path.getsize(ip) == 8 + 12 * len(uhash) and os.path.getsize(dp) == 4 * len(rh)   # src/sketch.cpp:961-963
+    p2, h2, c2 = ok.read_index64(dp, ip)
+    assert np.array_equal(p2, postings) and np.array_equal(h2, uhash) and np.array_equal(c2, ucount)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return capi.Context(0)
+
+
+@pytest.mark.gpu
+def test_gpu_wide_index_and_distances_match_reference(ctx):
+    man, (rnames, rh, roff), (qnames, qh, qoff) = load()
+    bits, kmer = man["hash_bits"], 2 * man["half_k"]
+    rsk = ctx.sketches_from_host64(rh, roff)
+    qsk = ctx.sketches_from_host64(qh, qoff)
+    assert rsk.is64
+    built = ctx.index_build(rsk, bits)
+    uhash, ucount, postings = ok.index_build64(rh, roff)
+    p2, h2, c2 = built.export64()
+    assert np.array_equal(p2, postings) and np.array_equal(h2, uhash) and np.array_equal(c2, ucount)
+    # import from a file-like scrambled block order
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(uhash))
+    starts = np.concatenate([[0], np.cumsum(ucount.astype(np.int64))])
+    scr = np.concatenate([postings[int(starts[i]):int(starts[i + 1])] for i in perm])
+    imported = ctx.index_import64(scr, uhash[perm], ucount[perm], bits, np.diff(roff))
+    assert np.array_equal(imported.export64()[0], postings)
+    for case in man["cases"]:
+        want = open(os.path.join(D64, case["file"])).read().split("\n")[:-1]
+        if case["cmd"] == "alldist":
+            for idx, q in ((built, None), (imported, rsk)):
+                hits, _ = ctx.dist_rows(idx, q, 1, case["metric"], kmer, case["max_dist"])
+                mine = sorted(capi.format_hit(rnames[h["col"]], rnames[h["row"]], h).rstrip("\n") for h in hits)
+                assert mine == want, case["file"]
+        else:
+            for idx in (built, imported):
+                hits, _ = ctx.dist_rows(idx, qsk, 0, case["metric"], kmer, case["max_dist"])
+                if case["max_neighbor"]:
+                    hits = capi.topn_rows(hits, case["max_neighbor"])
+                mine = [capi.format_hit(qnames[h["row"]], rnames[h["col"]], h).rstrip("\n") for h in hits]
+                assert mine == want, case["file"]
+    # dense counter rows
+    want_hits, want = ok.index_dist64(uhash, ucount, postings, np.diff(roff).astype(np.uint32), qh, qoff, 0, 0, kmer,
+                                      0.4, want_dense=True)
+    hits, dense = ctx.dist_rows(built, qsk, 0, 0, kmer, 0.4, want_dense=True)
+    assert np.array_equal(dense, want) and len(hits) == len(want_hits)
+    # width mismatch is an error, not a silent wrong answer
+    q32 = ctx.sketches_from_host(np.array([1, 2, 3], dtype=np.uint32), np.array([0, 3], dtype=np.uint64))
+    with pytest.raises(capi.RkError):
+        ctx.dist_rows(built, q32, 0, 0, kmer, 0.4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,s,l", [(12, 6, 3), (11, 6, 2), (16, 7, 4)])
+def test_gpu_wide_sketch_vs_oracle(ctx, k, s, l):
+    """K12L3 -> 36-bit, K11L2 -> 36-bit (1/256 sampling), K16 S7 L4 -> 48-bit hashes"""
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    flt = ctx.filter(capi.params_init(k, s, l), table)
+    genomes = synth.clade_genome_set(5, 120000)
+    seq = np.concatenate([b for _, b in genomes])
+    seq[1000:1040] = ord("N")
+    rec_off = np.arange(6, dtype=np.uint64) * 120000
+    sk = ctx.sketch_batch(flt, seq, rec_off, np.arange(6, dtype=np.uint64))
+    assert sk.is64
+    gh, goff = sk.download()
+    assert gh.dtype == np.uint64
+    total = 0
+    for g in range(5):
+        want = ok.sketch_records(param, table, seq[g * 120000:(g + 1) * 120000], np.array([0, 120000], dtype=np.uint64))
+        assert np.array_equal(gh[int(goff[g]):int(goff[g + 1])], want), g
+        total += len(want)
+    assert total > 0 and int(gh.max()) >= (1 << 32)
+    # end to end on the wide path: index + alldist
+    idx = ctx.index_build(sk, 4 * (k - l))
+    uhash, ucount, postings = ok.index_build64(gh, goff)
+    want, _ = ok.index_dist64(uhash, ucount, postings, np.diff(goff).astype(np.uint32), gh, goff, 1, 0, 2 * k, 0.2)
+    mine, _ = ctx.dist_rows(idx, None, 1, 0, 2 * k, 0.2)
+    assert len(mine) == len(want) and np.array_equal(mine["common"], want["common"])
+    assert np.max(np.abs(mine["dist"] - want["dist"]), initial=0.0) <= 1e-12
