@@ -19,12 +19,15 @@ struct SketchInfo {  // sketchInfo_t, src/sketch.h:27-34 (20 bytes on disk)
     int32_t id = 0, half_k = 0, half_subk = 0, drlevel = 0, genomeNumber = 0;
 };
 
-struct SketchSet {  // in-memory form of a .sketch file (32-bit hash layout)
+struct SketchSet {  // in-memory form of a .sketch file
     SketchInfo info;
     std::vector<std::string> names;
-    std::vector<uint32_t> hashes;  // CSR values
-    std::vector<uint64_t> off{0};  // CSR offsets, names.size()+1
+    std::vector<uint32_t> hashes;    // CSR values, 32-bit layout (half_k - drlevel <= 8)
+    std::vector<uint64_t> hashes64;  // CSR values, 64-bit layout (use64, src/sketch.cpp:336)
+    std::vector<uint64_t> off{0};    // CSR offsets, names.size()+1
     size_t size() const { return names.size(); }
+    bool wide() const { return info.half_k - info.drlevel > 8; }
+    uint64_t total() const { return off.empty() ? 0 : off.back(); }
 };
 
 inline bool ends_with(const std::string &s, const std::string &suf)
@@ -115,7 +118,8 @@ inline bool save_sketches(const std::string &path, SketchSet &s, std::string &er
     fwrite(cnt.data(), 4, s.size(), fp);
     for (size_t i = 0; i < s.size(); i++) {
         fwrite(s.names[i].data(), 1, s.names[i].size(), fp);
-        fwrite(s.hashes.data() + s.off[i], 4, (size_t)cnt[i], fp);
+        if (s.wide()) fwrite(s.hashes64.data() + s.off[i], 8, (size_t)cnt[i], fp);  // :1055-1058
+        else fwrite(s.hashes.data() + s.off[i], 4, (size_t)cnt[i], fp);
     }
     if (fclose(fp)) { err = "write error on " + path; return false; }
     return true;
@@ -129,11 +133,7 @@ inline bool read_sketches(const std::string &path, SketchSet &s, std::string &er
     if (fread(&s.info, sizeof(SketchInfo), 1, fp) != 1 || s.info.genomeNumber < 0) {
         fclose(fp); err = "mismatched read sketch_info: " + path; return false;
     }
-    if (s.info.half_k - s.info.drlevel > 8) {
-        fclose(fp);
-        err = "64-bit hash sketches (half_k - drlevel > 8) are not supported by this build: " + path;
-        return false;
-    }
+    const bool wide = s.wide();
     const size_t n = (size_t)s.info.genomeNumber;
     std::vector<int32_t> len(n), cnt(n);
     if (fread(len.data(), 4, n, fp) != n || fread(cnt.data(), 4, n, fp) != n) {
@@ -145,14 +145,17 @@ inline bool read_sketches(const std::string &path, SketchSet &s, std::string &er
         tot += (uint64_t)cnt[i];
     }
     s.names.resize(n);
-    s.hashes.resize(tot);
+    if (wide) s.hashes64.resize(tot);
+    else s.hashes.resize(tot);
     s.off.assign(n + 1, 0);
     for (size_t i = 0; i < n; i++) {
         s.names[i].resize((size_t)len[i]);
         if (len[i] && fread(&s.names[i][0], 1, (size_t)len[i], fp) != (size_t)len[i]) {
             fclose(fp); err = "the read nameLength is not equal to the saved nameLength: " + path; return false;
         }
-        if (cnt[i] && fread(s.hashes.data() + s.off[i], 4, (size_t)cnt[i], fp) != (size_t)cnt[i]) {
+        const size_t got = !cnt[i] ? 0 : wide ? fread(s.hashes64.data() + s.off[i], 8, (size_t)cnt[i], fp)
+                                              : fread(s.hashes.data() + s.off[i], 4, (size_t)cnt[i], fp);
+        if (got != (size_t)cnt[i]) {
             fclose(fp); err = "the read hashNumber is not equal to the saved hashNumber: " + path; return false;
         }
         s.off[i + 1] = s.off[i] + (uint64_t)cnt[i];
@@ -174,6 +177,25 @@ inline bool write_index(const std::string &dict, const std::string &index, const
     const uint64_t hash_size = counts.size(), total = postings.size();
     fwrite(&hash_size, 8, 1, fi);
     fwrite(&total, 8, 1, fi);
+    fwrite(counts.data(), 4, counts.size(), fi);
+    if (fclose(fi)) { err = "write error on " + index; return false; }
+    return true;
+}
+
+// 64-bit layout: .index = {u64 n; u64 hash[n]; u32 count[n]}, .dict = posting blocks in that order
+// (src/sketch.cpp:942-963)
+inline bool write_index64(const std::string &dict, const std::string &index, const std::vector<uint32_t> &postings,
+                          const std::vector<uint64_t> &hashes, const std::vector<uint32_t> &counts, std::string &err)
+{
+    FILE *fd = fopen(dict.c_str(), "wb");
+    if (!fd) { err = "cannot write " + dict; return false; }
+    fwrite(postings.data(), 4, postings.size(), fd);
+    if (fclose(fd)) { err = "write error on " + dict; return false; }
+    FILE *fi = fopen(index.c_str(), "wb");
+    if (!fi) { err = "cannot write " + index; return false; }
+    const uint64_t n = hashes.size();
+    fwrite(&n, 8, 1, fi);
+    fwrite(hashes.data(), 8, hashes.size(), fi);
     fwrite(counts.data(), 4, counts.size(), fi);
     if (fclose(fi)) { err = "write error on " + index; return false; }
     return true;

@@ -132,7 +132,6 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
     if (rk_params_init(shuf.k, shuf.subk, shuf.drlevel, &P))
         die("the half_subk - drlevel should at least 3 (half_subk=%d drlevel=%d), half_k >= half_subk, half_subk < 8",
             shuf.subk, shuf.drlevel);  // src/common.cpp:37
-    if (rk_hash_bits(&P) > 32) die("half_k - drlevel > 8 (64-bit hashes) is not supported by this build");
     rk_filter *flt = nullptr;
     gpu.check(rk_filter_create(gpu.ctx, &P, shuf.table.data(), &flt), "rk_filter_create");
 
@@ -193,12 +192,18 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
                                      (uint32_t)std::max(1, fq.least_num), rec_off.data(), rec_off.size() - 1,
                                      genome_rec.data(), (uint32_t)nb, &sk), "rk_sketch_batch_ex");
         vector<uint64_t> off(nb + 1);
-        vector<uint32_t> h(rk_sketches_total(sk));
-        gpu.check(rk_sketches_download(sk, h.data(), off.data()), "rk_sketches_download");
+        const uint64_t b0 = out.total();
+        if (out.wide()) {
+            vector<uint64_t> h(rk_sketches_total(sk));
+            gpu.check(rk_sketches_download64(sk, h.data(), off.data()), "rk_sketches_download64");
+            out.hashes64.insert(out.hashes64.end(), h.begin(), h.end());
+        } else {
+            vector<uint32_t> h(rk_sketches_total(sk));
+            gpu.check(rk_sketches_download(sk, h.data(), off.data()), "rk_sketches_download");
+            out.hashes.insert(out.hashes.end(), h.begin(), h.end());
+        }
         total_windows += rk_sketches_windows(sk);
         rk_sketches_free(sk);
-        const uint64_t b0 = out.hashes.size();
-        out.hashes.insert(out.hashes.end(), h.begin(), h.end());
         for (size_t i = 1; i <= nb; i++) out.off.push_back(b0 + off[i]);
         cerr << "finshed sketching: " << next << " genomes" << endl;
     }
@@ -214,23 +219,41 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
     (void)is_query;
 }
 
+static rk_sketches *upload(Gpu &gpu, const SketchSet &s)
+{
+    rk_sketches *sk = nullptr;
+    if (s.wide())
+        gpu.check(rk_sketches_from_host64(gpu.ctx, s.hashes64.data(), s.off.data(), (uint32_t)s.size(), &sk),
+                  "rk_sketches_from_host64");
+    else
+        gpu.check(rk_sketches_from_host(gpu.ctx, s.hashes.data(), s.off.data(), (uint32_t)s.size(), &sk),
+                  "rk_sketches_from_host");
+    return sk;
+}
+
 // builds the index on the GPU and, when asked, writes <sketch>.dict/.index (transSketches,
 // src/sketch.cpp:894-1021)
 static rk_index *build_index(Gpu &gpu, const SketchSet &s, const string &sketch_path, bool write_files)
 {
     const double t0 = get_sec();
     const int bits = 4 * (s.info.half_k - s.info.drlevel);
-    rk_sketches *sk = nullptr;
-    gpu.check(rk_sketches_from_host(gpu.ctx, s.hashes.data(), s.off.data(), (uint32_t)s.size(), &sk),
-              "rk_sketches_from_host");
+    rk_sketches *sk = upload(gpu, s);
     rk_index *idx = nullptr;
     gpu.check(rk_index_build(gpu.ctx, sk, bits, &idx), "rk_index_build");
     rk_sketches_free(sk);
     if (write_files) {
-        vector<uint32_t> postings(rk_index_total(idx)), counts((size_t)1 << bits);
-        gpu.check(rk_index_export(idx, postings.data(), counts.data()), "rk_index_export");
         string err;
-        if (!write_index(sketch_path + ".dict", sketch_path + ".index", postings, counts, err)) die("%s", err.c_str());
+        vector<uint32_t> postings(rk_index_total(idx));
+        if (s.wide()) {  // sparse layout, src/sketch.cpp:942-963
+            vector<uint64_t> hashes(rk_index_distinct(idx));
+            vector<uint32_t> counts(rk_index_distinct(idx));
+            gpu.check(rk_index_export64(idx, postings.data(), hashes.data(), counts.data()), "rk_index_export64");
+            if (!write_index64(sketch_path + ".dict", sketch_path + ".index", postings, hashes, counts, err)) die("%s", err.c_str());
+        } else {         // dense layout, src/sketch.cpp:991-1011
+            vector<uint32_t> counts((size_t)1 << bits);
+            gpu.check(rk_index_export(idx, postings.data(), counts.data()), "rk_index_export");
+            if (!write_index(sketch_path + ".dict", sketch_path + ".index", postings, counts, err)) die("%s", err.c_str());
+        }
     }
     cerr << "===============the time of transSketches is: " << get_sec() - t0 << endl;
     return idx;
@@ -415,9 +438,7 @@ static int cmd_dist(const Args &a)
             "try to use the same shuffle file to generate sketches of the reference and query datasets");
     const bool missing = !exist_file(ref_path + ".index") || !exist_file(ref_path + ".dict");
     rk_index *idx = build_index(gpu, ref, ref_path, missing);
-    rk_sketches *qs = nullptr;
-    gpu.check(rk_sketches_from_host(gpu.ctx, qry.hashes.data(), qry.off.data(), (uint32_t)qry.size(), &qs),
-              "rk_sketches_from_host");
+    rk_sketches *qs = upload(gpu, qry);
     const double t1 = get_sec();
     rk_dist_opts o{};
     o.triangle = 0;
@@ -452,7 +473,8 @@ static int cmd_info(const Args &a)
         fprintf(fp, "%s\t%d\n", s.names[i].c_str(), (int)cnt);
         if (a.has("F")) {
             for (uint64_t j = 0; j < cnt; j++) {
-                fprintf(fp, "%u\t", s.hashes[s.off[i] + j]);
+                if (s.wide()) fprintf(fp, "%lu\t", (unsigned long)s.hashes64[s.off[i] + j]);
+                else fprintf(fp, "%u\t", s.hashes[s.off[i] + j]);
                 if (j % 10 == 9) fprintf(fp, "\n");
             }
             fprintf(fp, "\n");
@@ -474,9 +496,10 @@ static int cmd_merge(const Args &a)
         if (!read_sketches(f, s, err)) die("command_merge(), %s", err.c_str());
         if (first) { all.info = s.info; first = false; }
         else if (s.info.id != all.info.id) die("command_merge(), mismatched sketch parameters in %s", f.c_str());
-        const uint64_t b0 = all.hashes.size();
+        const uint64_t b0 = all.total();
         all.names.insert(all.names.end(), s.names.begin(), s.names.end());
         all.hashes.insert(all.hashes.end(), s.hashes.begin(), s.hashes.end());
+        all.hashes64.insert(all.hashes64.end(), s.hashes64.begin(), s.hashes64.end());
         for (size_t i = 1; i < s.off.size(); i++) all.off.push_back(b0 + s.off[i]);
     }
     string out = a.str("o", "");
@@ -504,6 +527,7 @@ static int cmd_convert(const Args &a)
         if (!is_sketch_file(in)) die("command_convert(), need input RabbitKSSD sketch file: %s", in.c_str());
         SketchSet s;
         if (!read_sketches(in, s, err)) die("readSketches(), %s", err.c_str());
+        if (s.wide()) die("the Kssd sketch format holds 32-bit hashes only (half_k - drlevel <= 8)");
         if (mkdir(out_arg.c_str(), 0777) && errno != EEXIST) die("cannot create %s", out_arg.c_str());
         FILE *fs = fopen((out_arg + "/combco.0").c_str(), "w");
         if (!fs) die("cannot open: %s/combco.0", out_arg.c_str());
@@ -592,11 +616,18 @@ static int cmd_union(const Args &a)
     cerr << "the total genome number in sketch file is: " << s.size() << endl;
     SketchSet u;
     u.info = s.info;
-    u.hashes = s.hashes;  // ascending hash order == the reference's bitmap walk (:493-520)
-    std::sort(u.hashes.begin(), u.hashes.end());
-    u.hashes.erase(std::unique(u.hashes.begin(), u.hashes.end()), u.hashes.end());
+    // ascending hash order == the reference's bitmap walk (:493-520)
+    if (s.wide()) {
+        u.hashes64 = s.hashes64;
+        std::sort(u.hashes64.begin(), u.hashes64.end());
+        u.hashes64.erase(std::unique(u.hashes64.begin(), u.hashes64.end()), u.hashes64.end());
+    } else {
+        u.hashes = s.hashes;
+        std::sort(u.hashes.begin(), u.hashes.end());
+        u.hashes.erase(std::unique(u.hashes.begin(), u.hashes.end()), u.hashes.end());
+    }
     u.names = {in + " merged sketches"};  // :372
-    u.off = {0, u.hashes.size()};
+    u.off = {0, s.wide() ? u.hashes64.size() : u.hashes.size()};
     if (!save_sketches(a.str("o", ""), u, err)) die("%s", err.c_str());
     return 0;
 }
@@ -613,18 +644,28 @@ static int cmd_sub(const Args &a)
     if (!read_sketches(qs, qry, err)) die("command_sub(), %s", err.c_str());
     if (qry.info.id != ref.info.id)
         die("command_sub(): the sketch infos between subtraction reference and query sketches are not same");
-    vector<uint64_t> dict(((size_t)1 << 32) / 64, 0);  // one bit per hash value, MSB first (:575-583)
-    for (uint32_t h : ref.hashes) dict[h / 64] |= 0x8000000000000000ULL >> (h % 64);
     SketchSet out;
     out.info = qry.info;
     out.names = qry.names;
     out.off.assign(1, 0);
-    for (size_t i = 0; i < qry.size(); i++) {
-        for (uint64_t e = qry.off[i]; e < qry.off[i + 1]; e++) {
-            const uint32_t h = qry.hashes[e];
-            if (!(dict[h / 64] & (0x8000000000000000ULL >> (h % 64)))) out.hashes.push_back(h);
+    if (qry.wide()) {  // the reference's 2^bits bitmap (:561-572) is replaced by a sorted set
+        vector<uint64_t> rs64 = ref.hashes64;
+        std::sort(rs64.begin(), rs64.end());
+        for (size_t i = 0; i < qry.size(); i++) {
+            for (uint64_t e = qry.off[i]; e < qry.off[i + 1]; e++)
+                if (!std::binary_search(rs64.begin(), rs64.end(), qry.hashes64[e])) out.hashes64.push_back(qry.hashes64[e]);
+            out.off.push_back(out.hashes64.size());
         }
-        out.off.push_back(out.hashes.size());
+    } else {
+        vector<uint64_t> dict(((size_t)1 << 32) / 64, 0);  // one bit per hash value, MSB first (:575-583)
+        for (uint32_t h : ref.hashes) dict[h / 64] |= 0x8000000000000000ULL >> (h % 64);
+        for (size_t i = 0; i < qry.size(); i++) {
+            for (uint64_t e = qry.off[i]; e < qry.off[i + 1]; e++) {
+                const uint32_t h = qry.hashes[e];
+                if (!(dict[h / 64] & (0x8000000000000000ULL >> (h % 64)))) out.hashes.push_back(h);
+            }
+            out.off.push_back(out.hashes.size());
+        }
     }
     if (!save_sketches(a.str("o", ""), out, err)) die("%s", err.c_str());
     return 0;

@@ -126,3 +126,73 @@ def test_gpu_wide_sketch_vs_oracle(ctx, k, s, l):
     mine, _ = ctx.dist_rows(idx, None, 1, 0, 2 * k, 0.2)
     assert len(mine) == len(want) and np.array_equal(mine["common"], want["common"])
     assert np.max(np.abs(mine["dist"] - want["dist"]), initial=0.0) <= 1e-12
+
+
+# ------------------------------------------------------------------ host tool on the 64-bit layout
+def _tool(args, cwd=None, check=True):
+    import subprocess
+    from conftest import ROOT
+    p = subprocess.run([os.path.join(ROOT, "rabbitkssd_amd", "rabbit_kssd")] + [str(a) for a in args], cwd=cwd,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if check and p.returncode != 0:
+        raise AssertionError("rabbit_kssd %s failed:\n%s" % (args, p.stderr.decode()))
+    return p
+
+
+def test_tool_set_algebra_and_info_on_wide_sketches(tmp_path):
+    _, (rnames, rh, roff), (qnames, qh, qoff) = load()
+    ref, qry = os.path.join(D64, "ref64.sketch"), os.path.join(D64, "qry64.sketch")
+    _tool(["union", "-i", ref, "-o", tmp_path / "u.sketch"])
+    info, names, h, off = ok.read_sketches64(str(tmp_path / "u.sketch"))
+    assert info.genomeNumber == 1 and np.array_equal(h, np.unique(rh))
+    _tool(["sub", "--rs", ref, "--qs", qry, "-o", tmp_path / "s.sketch"])
+    info, names, h, off = ok.read_sketches64(str(tmp_path / "s.sketch"))
+    refset = set(rh.tolist())
+    for i in range(len(qnames)):
+        assert h[int(off[i]):int(off[i + 1])].tolist() == [x for x in qh[int(qoff[i]):int(qoff[i + 1])].tolist()
+                                                            if x not in refset]
+    _tool(["info", "-i", qry, "-o", tmp_path / "i.txt", "-F"])
+    lines = (tmp_path / "i.txt").read_text().split("\n")
+    assert lines[1] == "%s\t%d" % (qnames[0], qoff[1] - qoff[0]) and lines[2].split("\t")[0] == str(qh[0])
+    assert _tool(["convert", "--reverse", "-i", qry, "-o", tmp_path / "k"], check=False).returncode == 1
+
+
+@pytest.mark.gpu
+def test_tool_wide_alldist_dist_and_sketch(tmp_path):
+    man, (rnames, rh, roff), (qnames, qh, qoff) = load()
+    ref = tmp_path / "ref64.sketch"
+    ref.write_bytes(open(os.path.join(D64, "ref64.sketch"), "rb").read())
+    for case in man["cases"]:
+        want = open(os.path.join(D64, case["file"])).read().split("\n")[:-1]
+        if case["cmd"] == "alldist":
+            _tool(["alldist", "-i", ref, "-D", case["max_dist"], "-M", case["metric"], "-o", "o.txt"], cwd=tmp_path)
+            got = (tmp_path / "o.txt").read_text().split("\n")
+            assert sorted(x for x in got[1:] if x) == want, case["file"]
+        else:
+            args = ["dist", "-r", ref, "-q", os.path.join(D64, "qry64.sketch"), "-D", case["max_dist"], "-M",
+                    case["metric"], "-o", "o.txt"]
+            if case["max_neighbor"]:
+                args += ["-N", case["max_neighbor"]]
+            _tool(args, cwd=tmp_path)
+            assert [x for x in (tmp_path / "o.txt").read_text().split("\n")[1:] if x] == want, case["file"]
+    # the tool wrote the sparse .dict/.index pair the reference's use64 reader expects
+    postings, uhash, ucount = ok.read_index64(str(ref) + ".dict", str(ref) + ".index")
+    wu, wc, wp = ok.index_build64(rh, roff)
+    assert np.array_equal(postings, wp) and np.array_equal(uhash, wu) and np.array_equal(ucount, wc)
+    # sketch with a K12 shuffle file -> 64-bit .sketch
+    k, s, l = 12, 6, 3
+    shuf = tmp_path / "k12.shuf"
+    _tool(["shuffle", "-k", k, "-s", s, "-l", l, "-o", shuf])
+    files = []
+    for i, (name, bases) in enumerate(synth.clade_genome_set(3, 150000)):
+        p = tmp_path / (name + ".fa")
+        p.write_bytes(synth.fasta_text(name, bases))
+        files.append(str(p))
+    lst = tmp_path / "w.list"
+    lst.write_text("\n".join(files) + "\n")
+    _tool(["sketch", "-i", lst, "-L", shuf, "-o", tmp_path / "w", "-q"], cwd=tmp_path)
+    info, names, h, off = ok.read_sketches64(str(tmp_path / "w.sketch"))
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    for i, f in enumerate(files):
+        seq, o = ok.read_fasta(f)
+        assert np.array_equal(h[int(off[i]):int(off[i + 1])], ok.sketch_records(param, table, seq, o))
