@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--genomes", type=int, default=10000)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "rehearse the N>1 plumbing with all ranks on ONE GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-sketch", action="store_true")
     ap.add_argument("--sketch-genomes", type=int, default=128)
     ap.add_argument("--sketch-length", type=int, default=5_000_000)
@@ -155,9 +158,14 @@ def main():
         sys.exit(2)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the engine has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     ctx = capi.Context(local_rank)
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream().cuda_stream

@@ -502,7 +502,8 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
     const uint2 *ranges = idx->d_selfrange;
     const uint64_t *range_off = idx->d_self_off;
     const uint64_t *size_off = idx->d_src_off;
-    DevBuf<uint2> resolved;
+    DevBuf<uint2> resolved, kept;
+    DevBuf<uint64_t> kept_off;
     if (!self || common_dense) {
         const rk_sketches *qs = queries;
         DevBuf<uint32_t> dummy;
@@ -515,8 +516,15 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
         RK_HIP(ctx, resolved.alloc(qn));
         rc = rk_resolve_ranges(ctx, idx, qh, qn, resolved.p, 0);
         if (rc) return rc;
-        ranges = resolved.p;
-        range_off = size_off = qs->d_off;
+        // most query hashes of an unrelated genome are absent from the index: drop their empty
+        // slices so the kernel only walks real posting lists (size_off keeps the sketch sizes)
+        uint64_t n_kept = 0;
+        rc = rk_compact_ranges(ctx, resolved.p, qn, qs->d_off, qs->n, &kept.p, &kept_off.p, &n_kept, 0);
+        if (rc) return rc;
+        resolved.reset();
+        ranges = kept.p;
+        range_off = kept_off.p;
+        size_off = qs->d_off;
     }
 
     DevBuf<int32_t> dense;

@@ -218,6 +218,47 @@ int finish_index(rk_ctx *ctx, rk_index *idx)
 
 }  // namespace
 
+int rk_compact_ranges(rk_ctx *ctx, const uint2 *ranges_dev, uint64_t n, const uint64_t *off_dev, uint32_t n_rows,
+                      uint2 **out_ranges_dev, uint64_t **out_off_dev, uint64_t *n_out, hipStream_t stream)
+{
+    *out_ranges_dev = nullptr;
+    *out_off_dev = nullptr;
+    *n_out = 0;
+    DevBuf<uint64_t> new_off;
+    RK_HIP(ctx, new_off.alloc((size_t)n_rows + 1));
+    DevBuf<uint2> compact;
+    if (n) {
+        DevBuf<uint32_t> flags, rank;
+        RK_HIP(ctx, flags.alloc(n));
+        RK_HIP(ctx, rank.alloc(n));
+        hipLaunchKernelGGL(k_self_flags, dim3(blocks_for(n)), dim3(kThreads), 0, stream, ranges_dev, n, flags.p);
+        size_t tb = 0;
+        RK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, flags.p, rank.p, 0u, n, rocprim::plus<uint32_t>(), stream));
+        DevBuf<char> tmp;
+        RK_HIP(ctx, tmp.alloc(tb));
+        RK_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb, flags.p, rank.p, 0u, n, rocprim::plus<uint32_t>(), stream));
+        uint32_t last_rank = 0, last_flag = 0;
+        RK_HIP(ctx, hipMemcpyAsync(&last_rank, rank.p + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        RK_HIP(ctx, hipMemcpyAsync(&last_flag, flags.p + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        RK_HIP(ctx, hipStreamSynchronize(stream));
+        const uint64_t m = (uint64_t)last_rank + last_flag;
+        RK_HIP(ctx, compact.alloc(m));
+        hipLaunchKernelGGL(k_self_compact, dim3(blocks_for(n)), dim3(kThreads), 0, stream, ranges_dev, flags.p, rank.p,
+                           n, compact.p);
+        hipLaunchKernelGGL(k_self_off, dim3(blocks_for((uint64_t)n_rows + 1)), dim3(kThreads), 0, stream, off_dev,
+                           rank.p, n_rows, n, m, new_off.p);
+        RK_HIP(ctx, hipGetLastError());
+        RK_HIP(ctx, hipStreamSynchronize(stream));  // flags/rank die with this scope
+        *n_out = m;
+    } else {
+        RK_HIP(ctx, compact.alloc(0));
+        RK_HIP(ctx, hipMemsetAsync(new_off.p, 0, ((size_t)n_rows + 1) * 8, stream));
+    }
+    *out_ranges_dev = compact.release();
+    *out_off_dev = new_off.release();
+    return RK_OK;
+}
+
 int rk_resolve_ranges(rk_ctx *ctx, const rk_index *idx, const void *q_hashes_dev, uint64_t n,
                       uint2 *ranges_dev, hipStream_t stream)
 {
@@ -345,32 +386,13 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         RK_HIP(ctx, hipMemset(idx->d_upos, 0, 8));
     }
     RK_HIP(ctx, hipGetLastError());
-    // compact away the empty slices; flags/rank reuse the sort scratch
-    RK_HIP(ctx, hipMalloc((void **)&idx->d_self_off, ((size_t)s->n + 1) * 8));
-    if (H) {
-        uint32_t *sflags = flags.p, *srank = keys_sorted.p;
-        hipLaunchKernelGGL(k_self_flags, dim3(blocks_for(H)), dim3(kThreads), 0, 0, idx->d_selfrange, H, sflags);
-        size_t tb = 0;
-        RK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, sflags, srank, 0u, H, rocprim::plus<uint32_t>()));
-        DevBuf<char> tmp3;
-        RK_HIP(ctx, tmp3.alloc(tb));
-        RK_HIP(ctx, rocprim::exclusive_scan(tmp3.p, tb, sflags, srank, 0u, H, rocprim::plus<uint32_t>()));
-        uint32_t last_rank = 0, last_flag = 0;
-        RK_HIP(ctx, hipMemcpy(&last_rank, srank + (H - 1), 4, hipMemcpyDeviceToHost));
-        RK_HIP(ctx, hipMemcpy(&last_flag, sflags + (H - 1), 4, hipMemcpyDeviceToHost));
-        idx->n_self = (uint64_t)last_rank + last_flag;
-        DevBuf<uint2> compact;
-        RK_HIP(ctx, compact.alloc(idx->n_self));
-        hipLaunchKernelGGL(k_self_compact, dim3(blocks_for(H)), dim3(kThreads), 0, 0, idx->d_selfrange, sflags,
-                           srank, H, compact.p);
-        hipLaunchKernelGGL(k_self_off, dim3(blocks_for((uint64_t)s->n + 1)), dim3(kThreads), 0, 0, s->d_off, srank,
-                           s->n, H, idx->n_self, idx->d_self_off);
-        RK_HIP(ctx, hipGetLastError());
-        RK_HIP(ctx, hipDeviceSynchronize());
+    // compact away the empty slices (26 % of the elements at 10,000 genomes)
+    {
+        uint2 *compact = nullptr;
+        int rcc = rk_compact_ranges(ctx, idx->d_selfrange, H, s->d_off, s->n, &compact, &idx->d_self_off, &idx->n_self, 0);
+        if (rcc) return rcc;
         (void)hipFree(idx->d_selfrange);
-        idx->d_selfrange = compact.release();
-    } else {
-        RK_HIP(ctx, hipMemset(idx->d_self_off, 0, ((size_t)s->n + 1) * 8));
+        idx->d_selfrange = compact;
     }
     int rc = finish_index(ctx, idx);
     if (rc) return rc;

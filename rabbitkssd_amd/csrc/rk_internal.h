@@ -96,6 +96,9 @@ struct rk_index {
 };
 
 // kernels/launchers implemented in the .hip files
+// drops the empty slices of `ranges` (rows delimited by off_dev[n_rows+1]); outputs are hipMalloc'd
+int rk_compact_ranges(rk_ctx *ctx, const uint2 *ranges_dev, uint64_t n, const uint64_t *off_dev, uint32_t n_rows,
+                      uint2 **out_ranges_dev, uint64_t **out_off_dev, uint64_t *n_out, hipStream_t stream);
 // q_hashes_dev: u32[] or u64[] matching idx->wide
 int rk_resolve_ranges(rk_ctx *ctx, const rk_index *idx, const void *q_hashes_dev, uint64_t n,
                       uint2 *ranges_dev, hipStream_t stream);

@@ -51,7 +51,25 @@ def dist(n_genomes=10000, steps=5):
     print("dist %.3f ms/step, hits %d" % ((time.time() - t0) * 1e3 / steps, int(counters[0].item())))
 
 
+def dist_rq(n_ref=100000, n_query=1000, steps=3):
+    """configs[4] shape: ref-vs-query, 24-bit hashes (K10 S7 L4), queries of 45,776 hashes"""
+    ctx = capi.Context(0)
+    rn, rh, roff = synth.clade_sketches(n_ref, 76, 24, seed=31)
+    qn, qh, qoff = synth.clade_sketches(n_query, 45776, 24, seed=32)
+    t0 = time.time()
+    index = ctx.index_build(ctx.sketches_from_host(rh, roff), 24)
+    qs = ctx.sketches_from_host(qh, qoff)
+    torch.cuda.synchronize()
+    print("index build + uploads %.1f ms (H=%d, U=%d)" % ((time.time() - t0) * 1e3, index.total, index.distinct))
+    for _ in range(steps):
+        t0 = time.time()
+        hits, _ = ctx.dist_rows(index, qs, 0, 0, 20, 0.05)
+        dt = time.time() - t0
+        print("dist ref-vs-query %.3f ms, %d x %d = %.3g pairs -> %.3g pairs/s, %d hits"
+              % (dt * 1e3, n_query, n_ref, n_query * n_ref, n_query * n_ref / dt, len(hits)))
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
     args = [int(x) for x in sys.argv[2:]]
-    {"sketch": sketch, "dist": dist}[which](*args)
+    {"sketch": sketch, "dist": dist, "dist_rq": dist_rq}[which](*args)
