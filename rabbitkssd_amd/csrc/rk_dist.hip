@@ -24,8 +24,8 @@ namespace {
 constexpr int kDistThreads = 256;
 constexpr int kGroup = 8;                      // lanes per posting list
 constexpr uint32_t kRowsPerXcdChunk = 16;      // consecutive rows kept on one XCD (their L2 shares a clade's postings)
-constexpr uint32_t kStageHitsDefault = 48;     // reported pairs staged in LDS per workgroup
-constexpr uint32_t kCandCapDefault = 256;      // non-zero cells of one row compacted in LDS
+constexpr uint32_t kStageHitsDefault = 24;     // reported pairs staged in LDS per workgroup
+constexpr uint32_t kCandCapDefault = 128;      // non-zero cells of one row compacted in LDS
 
 struct DistArgs {
     const uint2 *ranges;        // posting slices [x,y) of the query hashes, rows back to back
