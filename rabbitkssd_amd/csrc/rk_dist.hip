@@ -2,15 +2,15 @@
 // Replaces the row loops of index_tridist (src/dist.cpp:174-258) and index_dist
 // (src/dist.cpp:560-692).
 //
-// One workgroup per (run of consecutive query rows, reference tile).  The counter row of the
-// reference (`int intersectionArr[tid][numRef]`, src/dist.cpp:167) lives in LDS, two 16-bit
-// counters per word when no count can overflow.  Per row: the posting ranges of the row's
-// hashes are staged in LDS (the next row's are prefetched into registers meanwhile), the
-// posting lists are gathered from HBM/L2 by 8-lane groups with 10 independent gathers in
-// flight per lane and scattered into the LDS row with ds_add_u32.  The epilogue scans the row
-// 16 B per lane, compacts the non-zero cells into an LDS list and evaluates the
-// Jaccard/Mash (or containment/AafD) formula in FP64 one cell per lane; reported pairs are
-// staged in LDS and flushed with one device-scope atomic per workgroup.
+// One workgroup per (run of consecutive query rows, reference tile).  The
+// counter row of the reference (`int intersectionArr[tid][numRef]`, src/dist.cpp:167) lives in
+// LDS, two 16-bit counters per word when no count can overflow.  Per row: the posting slices
+// of the row's hashes stream from HBM into registers one per thread (the next batch is always
+// in flight), the posting lists are gathered from HBM/L2 by 8-lane groups with 8-10
+// independent gathers in flight per lane and scattered into the LDS row with ds_add_u32.  The
+// epilogue scans the row 16 B per lane, compacts the non-zero cells into an LDS list and
+// evaluates the Jaccard/Mash (or containment/AafD) formula in FP64 one cell per lane; reported
+// pairs are staged in LDS and flushed with one device-scope atomic per workgroup.
 // Integer/index work: bound by VALU issue, LDS atomics and gather latency -- no MFMA.
 #include <algorithm>
 #include <cmath>
@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int kDistThreads = 256;
-constexpr int kGroup = 8;                      // lanes per posting list
+constexpr int kGroup = 8;                      // postings per slice walked by a quad (4 lanes x 2 postings)
 constexpr uint32_t kRowsPerXcdChunk = 16;      // consecutive rows kept on one XCD (their L2 shares a clade's postings)
 constexpr uint32_t kStageHitsDefault = 24;     // reported pairs staged in LDS per workgroup
 constexpr uint32_t kCandCapDefault = 128;      // non-zero cells of one row compacted in LDS
@@ -48,10 +48,13 @@ struct DistArgs {
 
 // D3/D4: src/dist.cpp:218-231 and :238-250, FP64, same operation order.
 // noinline: one copy of the FP64 divide + log sequence (~600 instructions) instead of one per call
-// site keeps the kernel inside the instruction cache
-__device__ __noinline__ void rk_distance(int common, int size0, int size1, int metric, int kmer_size,
-                                         double &jorc, double &dist)
+// site keeps the kernel inside the instruction cache; the pair is returned in registers
+struct JorcDist {
+    double jorc, dist;
+};
+__device__ __noinline__ JorcDist rk_distance(int common, int size0, int size1, int metric, int kmer_size)
 {
+    JorcDist r;
     if (!metric) {
         const int denom = size0 + size1 - common;
         double j = (size0 == 0 || size1 == 0) ? 0.0 : (double)common / (double)denom;
@@ -59,8 +62,8 @@ __device__ __noinline__ void rk_distance(int common, int size0, int size1, int m
         if (j == 1.0) d = 0.0;
         else if (j == 0.0) d = 1.0;
         else d = (-1.0 / (double)kmer_size) * log((2 * j) / (1.0 + j));
-        jorc = j;
-        dist = d;
+        r.jorc = j;
+        r.dist = d;
     } else {
         const int denom = size0 < size1 ? size0 : size1;
         double c = (size0 == 0 || size1 == 0) ? 0.0 : (double)common / (double)denom;
@@ -68,17 +71,50 @@ __device__ __noinline__ void rk_distance(int common, int size0, int size1, int m
         if (c == 1.0) d = 0.0;
         else if (c == 0.0) d = 1.0;
         else d = (-1.0 / (double)kmer_size) * log(c);
-        jorc = c;
-        dist = d;
+        r.jorc = c;
+        r.dist = d;
     }
+    return r;
 }
 
-// value held by lane (lane & 0x18) | J of the same half-wave: broadcast inside 8-lane groups
-// (ds_swizzle bit mode: and_mask 0x18, or_mask J; LDS crossbar only, no memory, no index VALU)
-template <int J> __device__ inline uint32_t group_bcast(uint32_t v)
+// value held by lane J of the same quad (DPP quad_perm:[J,J,J,J]: full-rate VALU, no LDS)
+template <int J> __device__ inline uint32_t quad_bcast(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x18 | (J << 5));
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xF, 0xF, true);
 }
+
+// two consecutive postings; dword-aligned only (a slice starts anywhere)
+struct __attribute__((packed, aligned(4))) PostingPair {
+    uint32_t x, y;
+};
+
+#ifdef RK_DIST_PROFILE
+// developer build only (-DRK_DIST_PROFILE, tools/dist_phase_profile.py): per-phase wave cycles
+constexpr int kProfWaves = 1 << 16;
+__device__ unsigned long long g_prof[kProfWaves][16];  // one row per wave, summed on the host
+#define PROF_MARK(i)                                                    \
+    do {                                                                \
+        const long long t_now = clock64();                              \
+        prof_acc[i] += t_now - prof_t;                                  \
+        prof_t = t_now;                                                 \
+    } while (0)
+#define PROF_FENCE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define PROF_FLUSH()                                                                         \
+    do {                                                                                     \
+        const uint32_t wv = (blockIdx.x * 4 + tid / 64) % kProfWaves;                        \
+        if (lane == 0) {                                                                     \
+            for (int i = 0; i < 12; i++) g_prof[wv][i] += (unsigned long long)prof_acc[i];   \
+            g_prof[wv][12] += (unsigned long long)(clock64() - prof_t0);                     \
+            g_prof[wv][13] += 1ULL;                                                          \
+            g_prof[wv][14] = (unsigned long long)prof_w0;                                    \
+            g_prof[wv][15] = (unsigned long long)wall_clock64();                             \
+        }                                                                                    \
+    } while (0)
+#else
+#define PROF_MARK(i)
+#define PROF_FENCE()
+#define PROF_FLUSH()
+#endif
 
 // U16: two 16-bit counters per LDS word.  Valid when no count can reach 65536, i.e. the
 // largest query sketch has < 65536 hashes (a count never exceeds |S_q|); halves the LDS row
@@ -87,21 +123,30 @@ template <int J> __device__ inline uint32_t group_bcast(uint32_t v)
 // self-join slices of rk_index_build), so every posting lands in the row unchecked.
 //
 // One workgroup handles rows_per_wg consecutive row slots (strains of one clade share their
-// posting lists: the second row finds them in this CU's L1/L2) and stages the reported
-// pairs in LDS, so the contended device-scope atomic on the hit counter is paid once per
-// workgroup instead of once per reporting wave.
+// posting lists: the second row finds them in this CU's L1/L2) and stages the reported pairs in LDS, so the contended device-scope atomic on
+// the hit counter is paid once per workgroup instead of once per reporting wave.
+// Per row: zero the LDS row | barrier | gather + scatter all slices | barrier | scan the row
+// into the cell list | barrier | evaluate the cells.  Three barriers; the evaluation of row r
+// overlaps the zeroing and scattering of row r+1 of faster waves (cell counters alternate).
 template <bool U16, bool FILTER>
 __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
 {
+#ifdef RK_DIST_PROFILE
+    long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_t = clock64();
+    const long long prof_t0 = prof_t;
+    const long long prof_w0 = wall_clock64();
+#endif
     // one dynamic LDS region (16-byte aligned base):
     // counter row | non-zero cell list | staged hits | scalars
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *cnt = lds;
     uint2 *cand = reinterpret_cast<uint2 *>(lds + a.cnt_words);  // (col, common) of the current row
     rk_hit *stage = reinterpret_cast<rk_hit *>(cand + a.cand_cap);
-    unsigned long long &s_base = *reinterpret_cast<unsigned long long *>(stage + a.stage_hits);
-    uint32_t &s_total = *(reinterpret_cast<uint32_t *>(stage + a.stage_hits) + 2);
-    uint32_t &s_cursor = *(reinterpret_cast<uint32_t *>(stage + a.stage_hits) + 3);
+    uint32_t *scal = reinterpret_cast<uint32_t *>(stage + a.stage_hits);
+    unsigned long long &s_base = *reinterpret_cast<unsigned long long *>(scal);
+    uint32_t *s_cells = scal + 2;   // [2] cells of the row being scanned (alternating per row)
+    uint32_t &s_cursor = scal[4];   // staged hits
     const uint32_t kCandCap = a.cand_cap, kStageHits = a.stage_hits;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
@@ -119,7 +164,7 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
     const uint32_t ncol = col1 - col0;
     if (tid == 0) s_cursor = 0;
 
-    const uint32_t sub = lane % kGroup;
+    const uint32_t sub = lane & 3;  // lane of the quad
     const bool tri_filter = a.triangle && !a.common_dense;
     constexpr uint32_t kPerWord = U16 ? 2 : 1;
     const uint4 *c4 = reinterpret_cast<const uint4 *>(cnt);
@@ -127,59 +172,44 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
 
     auto row_of = [&](uint32_t slot) { return a.row_first + slot * a.row_step; };
     auto skipped = [&](uint32_t row) { return a.triangle && col1 <= row + 1 && !a.common_dense; };
-
-    // ---- the run's work as one stream of batches -----------------------------------------
-    // A batch = up to 256 posting slices of one row, one slice per thread, loaded straight
-    // from HBM into a register pair (no LDS staging, no barrier).  Every row has at least one
-    // (possibly empty) batch so that it flows through the pipeline and gets its epilogue.
-    struct Cursor {
-        uint32_t slot;      // row slot of the batch, slot_end = exhausted
-        uint32_t b, nb;     // batch index / batches of that row
-        uint64_t e0, e1;    // the row's slice range in `ranges`
-    };
-    auto open_row = [&](Cursor &c) {  // c.slot points at a candidate row: skip tiles below the diagonal
-        while (c.slot < slot_end && skipped(row_of(c.slot))) c.slot++;
-        c.b = 0;
-        if (c.slot < slot_end) {
-            c.e0 = a.range_off[row_of(c.slot)];
-            c.e1 = a.range_off[row_of(c.slot) + 1];
-            c.nb = max(1u, (uint32_t)((c.e1 - c.e0 + kDistThreads - 1) / kDistThreads));
+    // first slot >= s whose row has work in this tile
+    auto next_live = [&](uint32_t s, uint32_t &row) {
+        while (s < slot_end) {
+            row = row_of(s);
+            if (!skipped(row)) break;
+            s++;
         }
+        return s;
     };
-    auto advance = [&](Cursor &c) {
-        if (++c.b >= c.nb) { c.slot++; open_row(c); }
-    };
-    auto load_ranges = [&](const Cursor &c) -> uint2 {
-        if (c.slot >= slot_end) return make_uint2(0, 0);
-        const uint64_t e = c.e0 + (uint64_t)c.b * kDistThreads + tid;
-        return e < c.e1 ? a.ranges[e] : make_uint2(0, 0);
+    auto load_slice = [&](uint64_t e, uint64_t e1) -> uint2 {
+        return e < e1 ? a.ranges[e] : make_uint2(0, 0);
     };
 
-    struct Gathered {  // head postings of the 8 slices a lane's group walks in one batch
-        uint32_t id[kGroup];
-        bool ok[kGroup];
+    struct Gathered {  // head postings of the 4 slices a lane's quad walks in one batch
+        PostingPair id[4];
+        bool ok0[4], ok1[4];
     };
-    // a wave walks its 64 slices in 8 steps; in step j the 8-lane group g handles the slice
-    // held by lane 8g+j (ds_swizzle broadcast inside the group), 8 gathers in flight per lane
+    // A wave walks its 64 slices in 4 steps; in step j quad q handles the slice held by lane
+    // 4q+j: each lane fetches two postings (8 B), the quad the first 8 of the list.  The L1
+    // looks up tags one quad per cycle, so a slice costs one lookup (two when it straddles a
+    // line) and no two lookups of a step wait on the same in-flight line.
     auto gather = [&](const uint2 rg, Gathered &g) {
         auto step = [&](int j, uint32_t rx, uint32_t ry) {
-            const uint32_t k = rx + sub;
-            g.ok[j] = k < ry;
-            g.id[j] = a.postings[g.ok[j] ? k : 0];  // unconditional load, index 0 is always mapped
+            const uint32_t k = rx + 2 * sub;
+            g.ok0[j] = k < ry;
+            g.ok1[j] = k + 1 < ry;
+            // unconditional load, postings[0..1] are always mapped
+            g.id[j] = *reinterpret_cast<const PostingPair *>(a.postings + (g.ok0[j] ? k : 0));
         };
-        step(0, group_bcast<0>(rg.x), group_bcast<0>(rg.y));
-        step(1, group_bcast<1>(rg.x), group_bcast<1>(rg.y));
-        step(2, group_bcast<2>(rg.x), group_bcast<2>(rg.y));
-        step(3, group_bcast<3>(rg.x), group_bcast<3>(rg.y));
-        step(4, group_bcast<4>(rg.x), group_bcast<4>(rg.y));
-        step(5, group_bcast<5>(rg.x), group_bcast<5>(rg.y));
-        step(6, group_bcast<6>(rg.x), group_bcast<6>(rg.y));
-        step(7, group_bcast<7>(rg.x), group_bcast<7>(rg.y));
-        static_assert(kGroup == 8, "the step list above is written for 8-lane groups");
+        step(0, quad_bcast<0>(rg.x), quad_bcast<0>(rg.y));
+        step(1, quad_bcast<1>(rg.x), quad_bcast<1>(rg.y));
+        step(2, quad_bcast<2>(rg.x), quad_bcast<2>(rg.y));
+        step(3, quad_bcast<3>(rg.x), quad_bcast<3>(rg.y));
+        static_assert(kGroup == 8, "a quad covers 4 lanes x 2 postings");
     };
 
     // ---- epilogue of one row (src/dist.cpp:207-255 / :600-682) ---------------------------
-    auto epilogue = [&](uint32_t row) {
+    auto epilogue = [&](uint32_t row, uint32_t &s_total) {
         if (a.common_dense) {
             int32_t *dst = a.common_dense + (size_t)row * a.n_ref + col0;
             for (uint32_t i = tid; i < ncol; i += kDistThreads)
@@ -197,17 +227,16 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
             // jaccard/containment and min_jorc sits strictly below the value at the threshold
             const int denom = a.metric ? min(size0, size1) : size0 + size1 - common;
             if ((double)common < a.min_jorc * (double)denom) return false;
-            double jorc, dist;
-            rk_distance(common, size0, size1, a.metric, a.kmer_size, jorc, dist);
+            const JorcDist jd = rk_distance(common, size0, size1, a.metric, a.kmer_size);
             hrec.row = row;
             hrec.col = j;
             hrec.common = common;
             hrec.size0 = size0;
             hrec.size1 = size1;
             hrec.pad_ = 0;
-            hrec.jorc = jorc;
-            hrec.dist = dist;
-            return a.triangle ? (dist < a.max_dist) : (dist <= a.max_dist);  // :232 / :624
+            hrec.jorc = jd.jorc;
+            hrec.dist = jd.dist;
+            return a.triangle ? (jd.dist < a.max_dist) : (jd.dist <= a.max_dist);  // :232 / :624
         };
         auto stage_hit = [&](const rk_hit &hrec) {
             const uint32_t sl = atomicAdd(&s_cursor, 1u);
@@ -217,43 +246,63 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
                 if (at < a.cap) a.hits[at] = hrec;
             }
         };
+        auto cell = [&](uint32_t c) -> uint32_t {
+            return U16 ? (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu : cnt[c];
+        };
 
         if (!a.dense_mode) {
             // Sparse mode: the threshold excludes distance 1.0 (== common 0), so only cells
             // that share a hash can be reported.  Scan the LDS row 16 B per lane skipping
-            // all-zero quads, compact the non-zero cells into an LDS list, then evaluate the
-            // list one cell per lane (FP64 divide + log run in parallel, not serialised on
-            // the lane that happened to own a clade's adjacent columns).
+            // all-zero quads and compact the non-zero cells into an LDS list (one LDS atomic
+            // per lane that found any), then evaluate the list one cell per lane: the FP64
+            // divide + log run in parallel, not serialised on the lane that happened to own a
+            // clade's adjacent columns.
             const uint32_t q_first = ((jbeg - col0) / kPerWord) / 4;
             const uint32_t q_end = ((ncol + kPerWord - 1) / kPerWord + 3) / 4;
             for (uint32_t q = q_first + tid; q < q_end; q += kDistThreads) {
                 const uint4 v = c4[q];
                 if ((v.x | v.y | v.z | v.w) == 0) continue;
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                uint32_t n = 0;
 #pragma unroll
                 for (int wi = 0; wi < 4; wi++) {
-                    if (w[wi] == 0) continue;
+                    if (U16) n += ((w[wi] & 0xFFFFu) != 0) + ((w[wi] >> 16) != 0);
+                    else n += w[wi] != 0;
+                }
+                uint32_t at = atomicAdd(&s_total, n);
+                const uint32_t jq = col0 + q * 4 * kPerWord;
+#pragma unroll
+                for (int wi = 0; wi < 4; wi++) {
 #pragma unroll
                     for (uint32_t h = 0; h < kPerWord; h++) {
-                        const uint32_t j = col0 + (q * 4 + wi) * kPerWord + h;
                         const uint32_t common = U16 ? (w[wi] >> (16 * h)) & 0xFFFFu : w[wi];
-                        if (common == 0 || j < jbeg || j >= col1) continue;
-                        const uint32_t sl = atomicAdd(&s_total, 1u);
-                        if (sl < kCandCap) cand[sl] = make_uint2(j, common);
-                        else {  // list full: evaluate in place (slow, only for very dense rows)
-                            rk_hit hrec;
-                            if (evaluate(j, (int)common, hrec)) stage_hit(hrec);
+                        if (common) {
+                            if (at < kCandCap) cand[at] = make_uint2(jq + wi * kPerWord + h, common);
+                            at++;
                         }
                     }
                 }
             }
+            PROF_MARK(2);
             __syncthreads();
-            const uint32_t n_cand = min(s_total, kCandCap);
-            for (uint32_t i = tid; i < n_cand; i += kDistThreads) {
-                const uint2 cj = cand[i];
-                rk_hit hrec;
-                if (evaluate(cj.x, (int)cj.y, hrec)) stage_hit(hrec);
+            PROF_MARK(3);
+            const uint32_t n_cells = s_total;
+            if (n_cells <= kCandCap) {
+                for (uint32_t i = tid; i < n_cells; i += kDistThreads) {
+                    const uint2 cj = cand[i];
+                    rk_hit hrec;
+                    if (cj.x >= jbeg && cj.x < col1 && evaluate(cj.x, (int)cj.y, hrec)) stage_hit(hrec);
+                }
+            } else {
+                // more sharing columns than the list holds: walk the row, one column per lane
+                for (uint32_t j = jbeg + tid; j < col1; j += kDistThreads) {
+                    const uint32_t common = cell(j - col0);
+                    rk_hit hrec;
+                    if (common && evaluate(j, (int)common, hrec)) stage_hit(hrec);
+                }
+                __syncthreads();  // the row is zeroed next
             }
+            PROF_MARK(4);
         } else {
             // Dense mode: every cell of [jbeg, col1) can be reported.  One column per lane;
             // pass 0 counts this row's reports, one atomic reserves their slots, pass 1
@@ -261,8 +310,7 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
             for (int pass_no = 0; pass_no < 2; pass_no++) {
                 uint32_t mine = 0;
                 for (uint32_t j = jbeg + tid; j < col1; j += kDistThreads) {
-                    const uint32_t c = j - col0;
-                    const int common = (int)(U16 ? (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu : cnt[c]);
+                    const int common = (int)cell(j - col0);
                     rk_hit hrec;
                     if (!evaluate(j, common, hrec)) continue;
                     if (pass_no == 0) { mine++; continue; }
@@ -279,65 +327,117 @@ __global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
                     __syncthreads();
                 }
             }
+            __syncthreads();  // the row is zeroed next
         }
     };
 
-    // ---- main loop: the slices of the NEXT batch (same or next row) are always in flight while
-    // the current batch is gathered and scattered.  (A deeper pipeline that also kept the
-    // posting gathers one batch ahead measured slower: more live registers, same issue load.)
-    Cursor cur_c{slot0, 0, 0, 0, 0};
-    open_row(cur_c);
-    if (cur_c.slot >= slot_end) return;  // nothing to do in this tile (uniform)
-    Cursor nxt_c = cur_c;
-    uint2 pre = load_ranges(cur_c);
-    uint32_t cur_slot = 0xFFFFFFFFu;     // row whose counters are live in LDS
+    // ---- rows of this run ---------------------------------------------------------------------
+    uint32_t row = 0;
+    uint32_t slot = next_live(slot0, row);
+    if (slot >= slot_end) return;  // nothing to do in this tile (uniform)
+    uint64_t e0 = a.range_off[row], e1 = a.range_off[row + 1];
+    uint2 pre = load_slice(e0 + tid, e1);  // the slices of the next batch are always in flight
+    uint32_t parity = 0;
 
-    while (cur_c.slot < slot_end) {
-        const uint2 rg = pre;
-        advance(nxt_c);
-        pre = load_ranges(nxt_c);                            // slices of the next batch
+    while (slot < slot_end) {
+        // look ahead: the next row's slice range is fetched while this row is processed
+        uint32_t nrow = 0;
+        const uint32_t nslot = next_live(slot + 1, nrow);
+        uint64_t ne0 = 0, ne1 = 0;
+        if (nslot < slot_end) { ne0 = a.range_off[nrow]; ne1 = a.range_off[nrow + 1]; }
 
-        if (cur_c.slot != cur_slot) {                        // first batch of a new row
-            if (cur_slot != 0xFFFFFFFFu) {
-                __syncthreads();                             // all scatters of the previous row done
-                epilogue(row_of(cur_slot));
-            }
-            __syncthreads();                                 // epilogue done with the LDS row / lists
-            uint4 *z4 = reinterpret_cast<uint4 *>(cnt);      // memset row (src/dist.cpp:179)
-            for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
-            if (tid == 0) s_total = 0;
-            __syncthreads();
-            cur_slot = cur_c.slot;
-        }
-        const uint32_t row = row_of(cur_slot);
-        const uint32_t lo_id = tri_filter ? row + 1 : 0;     // ids below are not needed (j > i)
-        auto bump = [&](uint32_t id, bool valid) {           // scatter, src/dist.cpp:199-202
+        uint4 *z4 = reinterpret_cast<uint4 *>(cnt);  // memset row (src/dist.cpp:179)
+        for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
+        if (tid == 0) s_cells[parity] = 0;
+        __syncthreads();
+        PROF_MARK(6);
+
+        const uint32_t lo_id = tri_filter ? row + 1 : 0;  // ids below are not needed (j > i)
+        auto bump = [&](uint32_t id, bool valid) {        // scatter, src/dist.cpp:199-202
             const uint32_t c = id - col0;
             if (valid && (!FILTER || (c < ncol && id >= lo_id))) {
                 if (U16) atomicAdd(&cnt[c >> 1], (c & 1) ? 0x10000u : 1u);
                 else atomicAdd(&cnt[c], 1u);
             }
         };
-        Gathered g;
-        gather(rg, g);
+        auto stream_list = [&](uint32_t sx, uint32_t sy) {  // whole wave, 2 x 64 postings in flight
+            for (uint32_t k = sx + lane; k < sy; k += 128) {
+                const bool ok1 = k + 64 < sy;
+                const uint32_t i0 = a.postings[k], i1 = a.postings[ok1 ? k + 64 : 0];
+                bump(i0, true);
+                bump(i1, ok1);
+            }
+        };
+
+        // A batch = up to 256 slices of the row, one per thread, loaded straight from HBM into
+        // a register pair (no LDS staging, no barrier).
+        const uint32_t nb = max(1u, (uint32_t)((e1 - e0 + kDistThreads - 1) / kDistThreads));
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint2 rg = pre;
+            if (b + 1 < nb) pre = load_slice(e0 + (uint64_t)(b + 1) * kDistThreads + tid, e1);
+            else if (nslot < slot_end) pre = load_slice(ne0 + tid, ne1);
+            else pre = make_uint2(0, 0);
+            PROF_MARK(0);
+
+            Gathered g;
+            gather(rg, g);
+            // Lists longer than 8 (2.5 % of the slices at 10,000 genomes, 1.6 per wave and
+            // batch): postings 8..23 of up to four of them are requested right away, one list
+            // per 16-lane row, so their latency overlaps the quad gathers instead of adding a
+            // dependent round trip each; whatever is longer still is streamed by the whole wave.
+            unsigned long long longs = __ballot(rg.y - rg.x > (uint32_t)kGroup);
+            uint32_t lx[4] = {0, 0, 0, 0}, ly[4] = {0, 0, 0, 0};  // uniform
+            uint32_t qx = 0, qy = 0;                              // this lane's row
 #pragma unroll
-        for (int j = 0; j < kGroup; j++) bump(g.id[j], g.ok[j]);
-        // lists longer than the group (1.7 % at 10,000 genomes): the whole wave streams the rest
-        unsigned long long longs = __ballot(rg.y - rg.x > (uint32_t)kGroup);
-        while (longs) {
-            const int L = __ffsll((long long)longs) - 1;
-            longs &= longs - 1;
-            const uint32_t sx = __builtin_amdgcn_readlane(rg.x, L), sy = __builtin_amdgcn_readlane(rg.y, L);
-            for (uint32_t k = sx + kGroup + lane; k < sy; k += 64) bump(a.postings[k], true);
+            for (int t = 0; t < 4; t++) {
+                if (longs) {  // uniform
+                    const int L = __ffsll((long long)longs) - 1;
+                    longs &= longs - 1;
+                    lx[t] = __builtin_amdgcn_readlane(rg.x, L) + kGroup;
+                    ly[t] = __builtin_amdgcn_readlane(rg.y, L);
+                    if ((lane >> 4) == (uint32_t)t) { qx = lx[t]; qy = ly[t]; }
+                }
+            }
+            const uint32_t kq = qx + (lane & 15);
+            const bool lokq = kq < qy;
+            const uint32_t lidq = a.postings[lokq ? kq : 0];
+            PROF_MARK(7);
+            PROF_FENCE();
+            PROF_MARK(8);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bump(g.id[j].x, g.ok0[j]);
+                bump(g.id[j].y, g.ok1[j]);
+            }
+            PROF_FENCE();
+            PROF_MARK(9);
+            bump(lidq, lokq);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (lx[t] + 16 < ly[t]) stream_list(lx[t] + 16, ly[t]);  // uniform
+            while (longs) {
+                const int L = __ffsll((long long)longs) - 1;
+                longs &= longs - 1;
+                stream_list(__builtin_amdgcn_readlane(rg.x, L) + kGroup, __builtin_amdgcn_readlane(rg.y, L));
+            }
+            PROF_FENCE();
+            PROF_MARK(10);
         }
-        advance(cur_c);
+        __syncthreads();  // all scatters of the row done
+        PROF_MARK(1);
+        epilogue(row, s_cells[parity]);
+        parity ^= 1;
+        slot = nslot;
+        row = nrow;
+        e0 = ne0;
+        e1 = ne1;
     }
-    __syncthreads();
-    epilogue(row_of(cur_slot));
 
     // flush the staged hits of this workgroup: one device-scope atomic, coalesced 8-byte stores
     __syncthreads();
     const uint32_t n_st = min(s_cursor, kStageHits);
+    PROF_MARK(11);
+    PROF_FLUSH();
     if (n_st == 0) return;
     if (tid == 0) s_base = atomicAdd(a.n_hits, (unsigned long long)n_st);
     __syncthreads();
@@ -453,6 +553,27 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
 }
 
 }  // namespace
+
+#ifdef RK_DIST_PROFILE
+extern "C" int rk_debug_dist_prof_raw(unsigned long long *out, unsigned long long n_waves)
+{
+    if (n_waves > (unsigned long long)kProfWaves) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), n_waves * 16 * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int rk_debug_dist_prof(unsigned long long *out16, int reset)
+{
+    std::vector<unsigned long long> all((size_t)kProfWaves * 16);
+    if (hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_prof), sizeof(g_prof)) != hipSuccess) return -1;
+    for (int i = 0; i < 16; i++) out16[i] = 0;
+    for (size_t w = 0; w < (size_t)kProfWaves; w++)
+        for (int i = 0; i < 16; i++) out16[i] += all[w * 16 + i];
+    if (reset) {
+        std::fill(all.begin(), all.end(), 0ULL);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), all.data(), sizeof(g_prof)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" {
 

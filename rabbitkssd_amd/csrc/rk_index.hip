@@ -327,7 +327,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     if (s->n)
         hipLaunchKernelGGL(k_sizes, dim3(blocks_for(s->n)), dim3(kThreads), 0, 0, s->d_off, s->n,
                            idx->d_sizes);
-    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (H + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (H + 4) * 4));
     RK_HIP(ctx, hipMalloc((void **)&idx->d_selfrange, (H + 1) * sizeof(uint2)));
 
     DevBuf<uint32_t> iota, keys_sorted, sorted_e, flags;
@@ -422,7 +422,7 @@ int rk_index_import(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const
 
     RK_HIP(ctx, hipMalloc((void **)&idx->d_sizes, ((size_t)n_ref + 1) * 4));
     RK_HIP(ctx, hipMemcpy(idx->d_sizes, ref_sizes, (size_t)n_ref * 4, hipMemcpyHostToDevice));
-    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (total + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (total + 4) * 4));
     RK_HIP(ctx, hipMemcpy(idx->d_postings, postings, total * 4, hipMemcpyHostToDevice));
 
     DevBuf<uint32_t> d_counts, flags, rank, cpos;
@@ -595,7 +595,7 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
     idx->d_selfrange = nullptr;
     const char *b = (const char *)blob_dev;
     const uint64_t nb = (1ULL << idx->dir_bits) + 1;
-    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (idx->H + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (idx->H + 4) * 4));
     if (idx->wide) RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash64, (idx->U + 1) * 8));
     else RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash, (idx->U + 1) * 4));
     RK_HIP(ctx, hipMalloc((void **)&idx->d_upos, (idx->U + 2) * 4));
@@ -695,7 +695,7 @@ int rk_index_import64(rk_ctx *ctx, const uint32_t *postings, uint64_t total, con
     idx->U = n_hash;
     idx->hash_bits = hash_bits;
     RK_HIP(ctx, hipMalloc((void **)&idx->d_sizes, ((size_t)n_ref + 1) * 4));
-    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (total + 1) * 4));
+    RK_HIP(ctx, hipMalloc((void **)&idx->d_postings, (total + 4) * 4));
     RK_HIP(ctx, hipMalloc((void **)&idx->d_uhash64, (n_hash + 1) * 8));
     RK_HIP(ctx, hipMalloc((void **)&idx->d_upos, (n_hash + 2) * 4));
     RK_HIP(ctx, hipMemcpy(idx->d_sizes, ref_sizes, (size_t)n_ref * 4, hipMemcpyHostToDevice));
