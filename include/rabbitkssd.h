@@ -81,6 +81,21 @@ const char *rk_last_error(const rk_ctx *ctx);
 const char *rk_version(void);
 void rk_free_host(void *p);
 
+/* ---- memory / stream helpers ----------------------------------------------------------
+ * What a host compiled without the HIP headers (the reference's g++ build) needs to keep the
+ * device fed the way src/sketch.cpp's producer/consumer threads keep the CPU cores fed
+ * (src/sketch.cpp:318-460): page-locked staging buffers the parser threads fill, device
+ * buffers, a stream, and an upload that returns immediately so parsing of the next batch
+ * overlaps it.  A stream is an opaque handle; NULL is the default stream. */
+int rk_pinned_alloc(rk_ctx *ctx, uint64_t bytes, void **out);
+void rk_pinned_free(void *p);
+int rk_dev_alloc(rk_ctx *ctx, uint64_t bytes, void **out);
+void rk_dev_free(void *p);
+int rk_stream_create(rk_ctx *ctx, void **out);
+void rk_stream_destroy(void *stream);
+int rk_stream_sync(rk_ctx *ctx, void *stream);
+int rk_upload_async(rk_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes, void *stream);
+
 /* ---- parameters (host arithmetic only) -------------------------------------------- */
 /* RK_ERR_ARG when half_subk - drlevel < 3 (src/common.cpp:37), half_k < half_subk or
  * half_subk >= 8 (src/shuffle.cpp:26,30), half_k > 16. */

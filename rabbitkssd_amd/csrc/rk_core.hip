@@ -56,6 +56,62 @@ const char *rk_last_error(const rk_ctx *ctx) { return ctx ? ctx->err.c_str() : "
 
 void rk_free_host(void *p) { free(p); }
 
+// ---- memory / stream helpers: what a host without the HIP headers needs to keep the device
+// fed (pinned staging, device buffers, an upload that overlaps the parser threads) -----------
+int rk_pinned_alloc(rk_ctx *ctx, uint64_t bytes, void **out)
+{
+    if (!ctx || !out) return RK_ERR_ARG;
+    *out = nullptr;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        *out = nullptr;
+        return rk_fail(ctx, RK_ERR_NOMEM, "cannot pin %llu bytes of host memory", (unsigned long long)bytes);
+    }
+    return RK_OK;
+}
+void rk_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+
+int rk_dev_alloc(rk_ctx *ctx, uint64_t bytes, void **out)
+{
+    if (!ctx || !out) return RK_ERR_ARG;
+    *out = nullptr;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    if (hipMalloc(out, bytes ? bytes : 1) != hipSuccess) {
+        *out = nullptr;
+        return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu bytes on the device", (unsigned long long)bytes);
+    }
+    return RK_OK;
+}
+void rk_dev_free(void *p) { if (p) (void)hipFree(p); }
+
+int rk_stream_create(rk_ctx *ctx, void **out)
+{
+    if (!ctx || !out) return RK_ERR_ARG;
+    *out = nullptr;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = nullptr;
+    RK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *out = (void *)st;
+    return RK_OK;
+}
+void rk_stream_destroy(void *stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
+
+int rk_stream_sync(rk_ctx *ctx, void *stream)
+{
+    if (!ctx) return RK_ERR_ARG;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    RK_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return RK_OK;
+}
+
+int rk_upload_async(rk_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes, void *stream)
+{
+    if (!ctx || (bytes && (!dst_dev || !src_host))) return RK_ERR_ARG;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) RK_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return RK_OK;
+}
+
 // src/common.cpp:35-78 (initParameter); argument checks of src/shuffle.cpp:26,30 folded in.
 int rk_params_init(int half_k, int half_subk, int drlevel, rk_params *p)
 {

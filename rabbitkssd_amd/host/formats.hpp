@@ -5,6 +5,7 @@
 #pragma once
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -222,26 +223,57 @@ inline bool read_index(const std::string &dict, const std::string &index, std::v
 }
 
 // ---- FASTA/FASTQ record reader with kseq_read semantics (src/kseq.h:176-215) -------------
-// Sequence bytes of every record are appended to `seq` (newlines dropped, a trailing '\r'
-// of a line dropped once the record holds more than one byte); rec_off gets one more entry
-// per record.  Returns false when the file cannot be opened.
+// One control flow, two sinks:
+//  * vectors: sequence bytes of every record appended to `seq` (newlines dropped, a trailing
+//    '\r' of a line dropped once the record holds more than one byte), rec_off gets one more
+//    entry per record, optional quality characters;
+//  * packed: the same bytes written straight into a caller buffer in the layout
+//    rk_sketch_packed_dev expects (records separated by one 0x00 byte), which is how the
+//    parser threads of the sketch pipeline fill the page-locked staging buffer without an
+//    intermediate copy.  The FASTQ quality gate (src/sketch.cpp:785) is applied in place.
 class RecordReader {
   public:
+    // whole file into buf (plain or gzip'd, src/sketch.cpp:462 reads both through gzopen);
+    // buf is caller-owned so that a parser thread reuses one allocation for all its files
+    static bool slurp(const std::string &path, std::vector<uint8_t> &buf, size_t &n)
+    {
+        n = 0;
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        unsigned char magic[2] = {0, 0};
+        const size_t got = fread(magic, 1, 2, f);
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {  // gzip
+            fclose(f);
+            gzFile fp = gzopen(path.c_str(), "r");
+            if (!fp) return false;
+            gzbuffer(fp, 1 << 20);
+            for (;;) {
+                if (buf.size() - n < (1u << 20)) buf.resize(buf.size() < (1u << 22) ? (1u << 22) : buf.size() * 2);
+                const int r = gzread(fp, buf.data() + n, (unsigned)std::min<size_t>(buf.size() - n, 1u << 30));
+                if (r <= 0) break;
+                n += (size_t)r;
+            }
+            gzclose(fp);
+            return true;
+        }
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (sz > 0) {
+            if (buf.size() < (size_t)sz) buf.resize((size_t)sz);
+            n = fread(buf.data(), 1, (size_t)sz, f);
+        }
+        fclose(f);
+        return true;
+    }
+
     // qual (optional): one quality character per base; '~' for records without qualities
     static bool read_file(const std::string &path, std::vector<uint8_t> &seq, std::vector<uint64_t> &rec_off,
                           std::vector<uint8_t> *qual = nullptr)
     {
-        gzFile fp = gzopen(path.c_str(), "r");  // reads plain text too (src/sketch.cpp:462)
-        if (!fp) return false;
         std::vector<uint8_t> buf;
         size_t n = 0;
-        for (;;) {
-            if (buf.size() - n < (1u << 20)) buf.resize(buf.size() ? buf.size() * 2 : (1u << 22));
-            const int r = gzread(fp, buf.data() + n, (unsigned)std::min<size_t>(buf.size() - n, 1u << 30));
-            if (r <= 0) break;
-            n += (size_t)r;
-        }
-        gzclose(fp);
+        if (!slurp(path, buf, n)) return false;
         parse(buf.data(), n, seq, rec_off, qual);
         return true;
     }
@@ -249,9 +281,87 @@ class RecordReader {
     static void parse(const uint8_t *b, size_t n, std::vector<uint8_t> &seq, std::vector<uint64_t> &rec_off,
                       std::vector<uint8_t> *qual = nullptr)
     {
+        if (rec_off.empty()) rec_off.push_back(seq.size());
+        VecSink sink{seq, rec_off, qual};
+        parse_core(b, n, sink);
+    }
+
+    struct Packed {
+        uint64_t bytes = 0;   // bytes written: records and their separators, without the last separator
+        uint64_t n_rec = 0;
+        bool overflow = false;  // dst was too small: nothing usable was written
+    };
+    // least_qual: bases of FASTQ records whose quality character is below it become 0x00
+    // (pass a value <= 0 to keep everything).  dst needs at most n bytes for any input of n bytes.
+    static Packed parse_packed(const uint8_t *b, size_t n, uint8_t *dst, size_t cap, int least_qual = 0)
+    {
+        PackedSink sink{dst, cap, least_qual};
+        parse_core(b, n, sink);
+        Packed r;
+        r.n_rec = sink.n_rec;
+        r.overflow = sink.overflow;
+        r.bytes = sink.n_rec ? sink.w - 1 : 0;
+        return r;
+    }
+
+  private:
+    struct VecSink {
+        std::vector<uint8_t> &seq;
+        std::vector<uint64_t> &rec_off;
+        std::vector<uint8_t> *qual;
+        size_t size() const { return seq.size(); }
+        void push(uint8_t c) { seq.push_back(c); }
+        void append(const uint8_t *x, const uint8_t *y) { seq.insert(seq.end(), x, y); }
+        uint8_t back() const { return seq.back(); }
+        void pop() { seq.pop_back(); }
+        void truncate(size_t start) { seq.resize(start); }
+        void end_fasta() {
+            if (qual) qual->resize(seq.size(), '~');
+            rec_off.push_back(seq.size());
+        }
+        void end_fastq(size_t start, const std::vector<uint8_t> &q) {
+            if (qual) { qual->resize(start, '~'); qual->insert(qual->end(), q.begin(), q.end()); }
+            rec_off.push_back(seq.size());
+        }
+    };
+    struct PackedSink {
+        uint8_t *dst;
+        size_t cap;
+        int least_qual;
+        size_t w = 0;
+        uint64_t n_rec = 0;
+        bool overflow = false;
+        size_t size() const { return w; }
+        void push(uint8_t c) { if (w < cap) dst[w] = c; else overflow = true; w++; }
+        void append(const uint8_t *x, const uint8_t *y) {
+            const size_t len = (size_t)(y - x);
+            if (w + len <= cap) memcpy(dst + w, x, len); else overflow = true;
+            w += len;
+        }
+        uint8_t back() const { return w <= cap ? dst[w - 1] : 0; }
+        void pop() { w--; }
+        void truncate(size_t start) { w = start; }
+        void separator() { if (w < cap) dst[w] = 0; else overflow = true; w++; n_rec++; }
+        void end_fasta() { separator(); }
+        void end_fastq(size_t start, const std::vector<uint8_t> &q) {
+            if (least_qual > 0 && w <= cap)
+                for (size_t i = 0; i < q.size(); i++)
+                    if ((int)(char)q[i] < least_qual) dst[start + i] = 0;
+            separator();
+        }
+    };
+
+    static const uint8_t *line_end(const uint8_t *p, const uint8_t *end)
+    {
+        const void *e = memchr(p, '\n', (size_t)(end - p));
+        return e ? (const uint8_t *)e : end;
+    }
+
+    template <class Sink> static void parse_core(const uint8_t *b, size_t n, Sink &out)
+    {
         size_t pos = 0;
         int last_char = 0;
-        if (rec_off.empty()) rec_off.push_back(seq.size());
+        std::vector<uint8_t> q;
         for (;;) {
             if (last_char == 0) {  // jump to the next header line, :180-184
                 while (pos < n && b[pos] != '>' && b[pos] != '@') pos++;
@@ -263,54 +373,46 @@ class RecordReader {
             while (pos < n && !is_space(b[pos])) pos++;  // name
             if (pos < n) c = b[pos++];
             if (c != '\n') {  // comment up to end of line, :187
-                while (pos < n && b[pos] != '\n') pos++;
+                pos = (size_t)(line_end(b + pos, b + n) - b);
                 if (pos < n) pos++;
             }
-            const size_t start = seq.size();
+            const size_t start = out.size();
             int stop = -1;
             while (pos < n) {  // :192-196
                 const int ch = b[pos++];
                 if (ch == '>' || ch == '+' || ch == '@') { stop = ch; break; }
                 if (ch == '\n') continue;
-                seq.push_back((uint8_t)ch);
+                out.push((uint8_t)ch);
                 if (pos >= n) break;  // ks_getuntil2 at EOF returns before the '\r' rule
-                size_t e = pos;
-                while (e < n && b[e] != '\n') e++;
-                seq.insert(seq.end(), b + pos, b + e);
+                const size_t e = (size_t)(line_end(b + pos, b + n) - b);
+                out.append(b + pos, b + e);
                 pos = e < n ? e + 1 : n;
-                if (seq.size() - start > 1 && seq.back() == '\r') seq.pop_back();  // :140
+                if (out.size() - start > 1 && out.back() == '\r') out.pop();  // :140
             }
             if (stop == '>' || stop == '@') last_char = stop;  // :197
             if (stop != '+') {  // FASTA record, :204
-                if (qual) qual->resize(seq.size(), '~');
-                rec_off.push_back(seq.size());
-                if (stop < 0 && pos >= n) {
-                    // EOF: the next call finds no name and ends the file
-                    return;
-                }
+                out.end_fasta();
+                if (stop < 0 && pos >= n) return;  // EOF: the next call finds no name and ends the file
                 continue;
             }
             // FASTQ: skip the rest of the '+' line, then read quality lines, :209-214
-            while (pos < n && b[pos] != '\n') pos++;
-            if (pos >= n) { seq.resize(start); return; }  // -2: no quality string
+            pos = (size_t)(line_end(b + pos, b + n) - b);
+            if (pos >= n) { out.truncate(start); return; }  // -2: no quality string
             pos++;
-            const size_t want = seq.size() - start;
-            std::vector<uint8_t> q;
+            const size_t want = out.size() - start;
+            q.clear();
             while (pos < n && q.size() < want) {  // quality lines appended like sequence lines, :211
-                size_t e = pos;
-                while (e < n && b[e] != '\n') e++;
+                const size_t e = (size_t)(line_end(b + pos, b + n) - b);
                 q.insert(q.end(), b + pos, b + e);
                 pos = e < n ? e + 1 : n;
                 if (q.size() > 1 && q.back() == '\r') q.pop_back();
             }
             last_char = 0;
-            if (q.size() != want) { seq.resize(start); return; }  // -2: quality string of a different length
-            if (qual) { qual->resize(start, '~'); qual->insert(qual->end(), q.begin(), q.end()); }
-            rec_off.push_back(seq.size());
+            if (q.size() != want) { out.truncate(start); return; }  // -2: quality string of a different length
+            out.end_fastq(start, q);
         }
     }
 
-  private:
     static bool is_space(int c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
 };
 

@@ -16,10 +16,13 @@
 #include <sys/time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <condition_variable>
 #include <cstdarg>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <thread>
 
 #include "formats.hpp"
@@ -144,54 +147,100 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
     out.names = files;
     out.off.assign(1, 0);
 
-    // batches of ~1.5 GiB of sequence: parse on host threads, sketch on the GPU
-    const uint64_t batch_bytes = 1536ull << 20;
-    size_t next = 0;
+    // ---- streaming pipeline (the role of src/sketch.cpp:318-460's producer/consumer threads) ----
+    // Files are grouped into batches that fit one page-locked staging buffer.  The parser
+    // threads write every genome straight into its 1 KiB-aligned slot of the staging buffer
+    // in the packed layout of rk_sketch_packed_dev (no intermediate copy); a GPU thread
+    // uploads the batch, runs the sketch kernels and downloads the hashes while the parser
+    // threads already fill the other staging buffer.
+    struct Slot {
+        uint64_t off = 0, cap = 0;  // position / capacity in the staging buffer
+        uint64_t len = 0;           // packed bytes written
+        bool overflow = false;      // the size estimate was too small (multi-member .gz): slow path
+    };
+    struct Batch {
+        size_t first = 0, last = 0;  // files [first, last)
+        uint64_t bytes = 0;          // staging bytes used
+        vector<Slot> slots;
+    };
+    // upper bound of a file's packed size: a plain file cannot expand; a .gz member stores its
+    // length mod 2^32 in the trailer
+    auto packed_bound = [](const string &f) -> uint64_t {
+        struct stat st;
+        if (stat(f.c_str(), &st)) die("cannot open the genome file: %s", f.c_str());
+        uint64_t sz = (uint64_t)st.st_size;
+        FILE *fp = fopen(f.c_str(), "rb");
+        if (!fp) die("cannot open the genome file: %s", f.c_str());
+        unsigned char m[2] = {0, 0}, tail[4];
+        if (fread(m, 1, 2, fp) == 2 && m[0] == 0x1f && m[1] == 0x8b && sz >= 18 && !fseek(fp, -4, SEEK_END) &&
+            fread(tail, 1, 4, fp) == 4) {
+            const uint64_t isize = (uint64_t)tail[0] | ((uint64_t)tail[1] << 8) | ((uint64_t)tail[2] << 16) |
+                                   ((uint64_t)tail[3] << 24);
+            sz = std::max<uint64_t>(isize, sz);
+        }
+        fclose(fp);
+        return sz;
+    };
+    vector<uint64_t> bound(files.size());
+    uint64_t total_bound = 0, max_bound = 0;
+    for (size_t i = 0; i < files.size(); i++) {
+        bound[i] = ((packed_bound(files[i]) + 1 + 1023) & ~1023ULL);
+        total_bound += bound[i];
+        max_bound = std::max(max_bound, bound[i]);
+    }
+    // staging buffers: a quarter of the input each (so that uploads and kernels overlap the
+    // parsing of the next batch), between 64 MiB and 1 GiB, never below the largest file
+    uint64_t stage_bytes = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(64ull << 20, total_bound / 4));
+    stage_bytes = std::max(stage_bytes, max_bound);
+    stage_bytes = (stage_bytes + 1023) & ~1023ULL;
+    vector<Batch> batches;
+    for (size_t i = 0; i < files.size();) {
+        Batch bt;
+        bt.first = i;
+        uint64_t pos = 0;
+        while (i < files.size() && pos + bound[i] <= stage_bytes) {
+            Slot sl;
+            sl.off = pos;
+            sl.cap = bound[i];
+            bt.slots.push_back(sl);
+            pos += bound[i];
+            i++;
+        }
+        bt.last = i;
+        bt.bytes = pos;
+        batches.push_back(std::move(bt));
+    }
+
+    const int n_buf = batches.size() > 1 ? 2 : 1;
+    uint8_t *stage[2] = {nullptr, nullptr};
+    void *dev[2] = {nullptr, nullptr};
+    void *stream = nullptr;
+    gpu.check(rk_stream_create(gpu.ctx, &stream), "rk_stream_create");
+    for (int k = 0; k < n_buf; k++) {
+        gpu.check(rk_pinned_alloc(gpu.ctx, stage_bytes, (void **)&stage[k]), "rk_pinned_alloc");
+        gpu.check(rk_dev_alloc(gpu.ctx, stage_bytes, &dev[k]), "rk_dev_alloc");
+    }
+
+    // hand-over of filled staging buffers to the GPU thread
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t filled = 0, consumed = 0;  // batches parsed / batches whose staging buffer is free again
     uint64_t total_windows = 0;
-    while (next < files.size()) {
-        vector<vector<uint8_t>> seqs, quals;
-        vector<vector<uint64_t>> offs;
-        size_t first = next;
-        uint64_t bytes = 0;
-        while (next < files.size() && (bytes < batch_bytes || next == first)) {
-            struct stat st;
-            if (stat(files[next].c_str(), &st)) die("cannot open the genome file: %s", files[next].c_str());
-            bytes += (uint64_t)st.st_size;
-            next++;
-        }
-        const size_t nb = next - first;
-        seqs.resize(nb);
-        quals.resize(nb);
-        offs.resize(nb);
-        std::vector<std::thread> pool;
-        std::vector<int> ok(nb, 1);
-        const int nt = std::max(1, std::min<int>(threads, (int)nb));
-        for (int t = 0; t < nt; t++)
-            pool.emplace_back([&, t]() {
-                for (size_t i = (size_t)t; i < nb; i += (size_t)nt)
-                    ok[i] = RecordReader::read_file(files[first + i], seqs[i], offs[i], fq.fastq ? &quals[i] : nullptr) ? 1 : 0;
-            });
-        for (auto &th : pool) th.join();
+    string gpu_error;
+
+    auto slow_path = [&](size_t file_idx, rk_sketches **sk) {  // whole file through rk_sketch_batch_ex
         vector<uint8_t> seq, qual;
-        vector<uint64_t> rec_off{0}, genome_rec{0};
-        for (size_t i = 0; i < nb; i++) {
-            if (!ok[i]) die("cannot open the genome file: %s", files[first + i].c_str());
-            const uint64_t base = seq.size();
-            seq.insert(seq.end(), seqs[i].begin(), seqs[i].end());
-            if (fq.fastq) {
-                quals[i].resize(seqs[i].size(), '~');
-                qual.insert(qual.end(), quals[i].begin(), quals[i].end());
-                vector<uint8_t>().swap(quals[i]);
-            }
-            for (size_t r = 1; r < offs[i].size(); r++) rec_off.push_back(base + offs[i][r]);
-            genome_rec.push_back(rec_off.size() - 1);
-            vector<uint8_t>().swap(seqs[i]);
-        }
-        rk_sketches *sk = nullptr;
+        vector<uint64_t> rec_off, genome_rec{0};
+        if (!RecordReader::read_file(files[file_idx], seq, rec_off, fq.fastq ? &qual : nullptr))
+            die("cannot open the genome file: %s", files[file_idx].c_str());
+        if (rec_off.empty()) rec_off.push_back(0);
+        genome_rec.push_back(rec_off.size() - 1);
         gpu.check(rk_sketch_batch_ex(gpu.ctx, flt, seq.data(), fq.fastq ? qual.data() : nullptr, fq.least_qual,
                                      (uint32_t)std::max(1, fq.least_num), rec_off.data(), rec_off.size() - 1,
-                                     genome_rec.data(), (uint32_t)nb, &sk), "rk_sketch_batch_ex");
-        vector<uint64_t> off(nb + 1);
+                                     genome_rec.data(), 1, sk), "rk_sketch_batch_ex");
+    };
+    auto append_sketches = [&](rk_sketches *sk, uint32_t n) {
+        vector<uint64_t> off((size_t)n + 1);
         const uint64_t b0 = out.total();
         if (out.wide()) {
             vector<uint64_t> h(rk_sketches_total(sk));
@@ -203,10 +252,106 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
             out.hashes.insert(out.hashes.end(), h.begin(), h.end());
         }
         total_windows += rk_sketches_windows(sk);
-        rk_sketches_free(sk);
-        for (size_t i = 1; i <= nb; i++) out.off.push_back(b0 + off[i]);
-        cerr << "finshed sketching: " << next << " genomes" << endl;
+        for (size_t i = 1; i <= n; i++) out.off.push_back(b0 + off[i]);
+    };
+
+    std::thread gpu_thread([&]() {
+        for (size_t k = 0; k < batches.size(); k++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return filled > k; });
+            }
+            Batch &bt = batches[k];
+            const int bi = (int)(k % (size_t)n_buf);
+            const uint32_t nb = (uint32_t)(bt.last - bt.first);
+            vector<uint64_t> gbeg(nb), gend(nb);
+            bool any_overflow = false;
+            for (uint32_t i = 0; i < nb; i++) {
+                gbeg[i] = bt.slots[i].off;
+                gend[i] = bt.slots[i].off + (bt.slots[i].overflow ? 0 : bt.slots[i].len);
+                any_overflow |= bt.slots[i].overflow;
+            }
+            rk_sketches *sk = nullptr;
+            gpu.check(rk_upload_async(gpu.ctx, dev[bi], stage[bi], bt.bytes, stream), "rk_upload_async");
+            gpu.check(rk_sketch_packed_dev_ex(gpu.ctx, flt, (const uint8_t *)dev[bi], bt.bytes, gbeg.data(), gend.data(),
+                                              nb, (uint32_t)std::max(1, fq.least_num), stream, &sk),
+                      "rk_sketch_packed_dev_ex");
+            {   // the call above synchronised the stream: the staging buffer can be refilled
+                std::lock_guard<std::mutex> lk(mu);
+                consumed = k + 1;
+            }
+            cv.notify_all();
+            if (!any_overflow) {
+                append_sketches(sk, nb);
+            } else {  // rare: splice the slow-path genomes in, keeping list order
+                vector<uint64_t> off((size_t)nb + 1);
+                vector<uint32_t> h32;
+                vector<uint64_t> h64;
+                if (out.wide()) { h64.resize(rk_sketches_total(sk)); gpu.check(rk_sketches_download64(sk, h64.data(), off.data()), "rk_sketches_download64"); }
+                else { h32.resize(rk_sketches_total(sk)); gpu.check(rk_sketches_download(sk, h32.data(), off.data()), "rk_sketches_download"); }
+                total_windows += rk_sketches_windows(sk);
+                for (uint32_t i = 0; i < nb; i++) {
+                    if (bt.slots[i].overflow) {
+                        rk_sketches *one = nullptr;
+                        slow_path(bt.first + i, &one);
+                        append_sketches(one, 1);
+                        rk_sketches_free(one);
+                    } else {
+                        if (out.wide()) out.hashes64.insert(out.hashes64.end(), h64.begin() + off[i], h64.begin() + off[i + 1]);
+                        else out.hashes.insert(out.hashes.end(), h32.begin() + off[i], h32.begin() + off[i + 1]);
+                        out.off.push_back(out.off.back() + (off[i + 1] - off[i]));
+                    }
+                }
+            }
+            rk_sketches_free(sk);
+            cerr << "finshed sketching: " << bt.last << " genomes" << endl;
+        }
+    });
+
+    for (size_t k = 0; k < batches.size(); k++) {
+        {   // wait until the GPU thread has released this staging buffer
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return k < (size_t)n_buf || consumed + (size_t)n_buf > k; });
+        }
+        Batch &bt = batches[k];
+        uint8_t *base = stage[k % (size_t)n_buf];
+        const size_t nb = bt.last - bt.first;
+        std::atomic<size_t> next_file{0};
+        std::atomic<int> failed{-1};
+        const int nt = std::max(1, std::min<int>(threads, (int)nb));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; t++)
+            pool.emplace_back([&]() {
+                vector<uint8_t> buf;  // one allocation per thread, reused for all its files
+                for (;;) {
+                    const size_t i = next_file.fetch_add(1);
+                    if (i >= nb) break;
+                    Slot &sl = bt.slots[i];
+                    size_t n = 0;
+                    if (!RecordReader::slurp(files[bt.first + i], buf, n)) { failed = (int)i; continue; }
+                    const RecordReader::Packed pk =
+                        RecordReader::parse_packed(buf.data(), n, base + sl.off, sl.cap, fq.fastq ? fq.least_qual : 0);
+                    sl.overflow = pk.overflow;
+                    sl.len = pk.overflow ? 0 : pk.bytes;
+                    // zero-fill up to the next multiple of 1024 (the kernel reads whole 1 KiB lines)
+                    const uint64_t end = sl.len, pad_end = std::min<uint64_t>(sl.cap, (end + 1024) & ~1023ULL);
+                    memset(base + sl.off + end, 0, pad_end - end);
+                }
+            });
+        for (auto &th : pool) th.join();
+        if (failed >= 0) die("cannot open the genome file: %s", files[bt.first + (size_t)failed].c_str());
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            filled = k + 1;
+        }
+        cv.notify_all();
     }
+    gpu_thread.join();
+    for (int k = 0; k < n_buf; k++) {
+        rk_pinned_free(stage[k]);
+        rk_dev_free(dev[k]);
+    }
+    rk_stream_destroy(stream);
     rk_filter_free(flt);
 
     string out_path = out_path_in;
@@ -678,6 +823,21 @@ static int cmd_parse(int argc, char **argv)
         vector<uint8_t> seq;
         vector<uint64_t> off;
         if (!RecordReader::read_file(argv[i], seq, off)) die("cannot open %s", argv[i]);
+        {   // the packed sink must produce the same records, separated by 0x00
+            vector<uint8_t> buf, packed;
+            size_t n = 0;
+            RecordReader::slurp(argv[i], buf, n);
+            packed.assign(n + 2, 0xEE);
+            const RecordReader::Packed pk = RecordReader::parse_packed(buf.data(), n, packed.data(), n + 1);
+            vector<uint8_t> want;
+            for (size_t r = 1; r < off.size(); r++) {
+                want.insert(want.end(), seq.begin() + off[r - 1], seq.begin() + off[r]);
+                if (r + 1 < off.size()) want.push_back(0);
+            }
+            if (pk.overflow || pk.n_rec != off.size() - 1 || pk.bytes != want.size() ||
+                memcmp(want.data(), packed.data(), want.size()) != 0)
+                die("packed parse differs from the vector parse for %s", argv[i]);
+        }
         uint64_t h = 1469598103934665603ULL;
         for (uint8_t c : seq) { h ^= c; h *= 1099511628211ULL; }
         printf("%s\t%zu\t%zu\t%016llx", argv[i], off.size() - 1, seq.size(), (unsigned long long)h);

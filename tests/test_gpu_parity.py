@@ -105,6 +105,39 @@ def test_random_alldist_vs_oracle(ctx, n, m, bits, seed):
     assert_hits_equal(mine, want)
 
 
+@pytest.mark.parametrize("n,m,bits", [(600, 200, 12), (800, 300, 10)])
+def test_crowded_hash_space_long_lists_and_full_rows(ctx, n, m, bits):
+    # a tiny hash space: every hash sits in dozens to hundreds of genomes (posting lists far
+    # beyond the 8 a quad gathers and the 16 more the early loads cover: the whole-wave
+    # streaming path) and every pair shares hashes (hundreds of non-zero cells per row: more
+    # than the LDS cell list holds, the column-walk path)
+    rng = np.random.default_rng(n + bits)
+    parts = [np.unique(rng.integers(0, 1 << bits, size=m, dtype=np.uint64).astype(np.uint32)) for _ in range(n)]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    h = np.concatenate(parts)
+    postings, counts = ok.index_build32(h, off, bits)
+    assert counts.max() > 8 + 16 and (bits > 10 or counts.max() > 8 + 16 + 128)
+    sizes = np.diff(off).astype(np.uint32)
+    idx = ctx.index_build(ctx.sketches_from_host(h, off), bits)
+    qs = ctx.sketches_from_host(h, off)
+    want_hits, want = ok.index_dist32(counts, bits, postings, sizes, h, off, 1, 0, 20, 0.2, threads=4, want_dense=True)
+    assert (np.triu(want, 1) > 0).sum(axis=1).max() > 256
+    hits, dense = ctx.dist_rows(idx, qs, 1, 0, 20, 0.2, want_dense=True)
+    assert np.array_equal(dense, want)
+    assert_hits_equal(hits, want_hits)
+    for metric, D in ((0, 0.12), (1, 0.08), (0, 0.3)):
+        want_hits, _ = ok.index_dist32(counts, bits, postings, sizes, h, off, 1, metric, 20, D, threads=4)
+        assert len(want_hits) > 0 or metric == 1
+        mine, _ = ctx.dist_rows(idx, None, 1, metric, 20, D)          # self join: unfiltered slices
+        assert_hits_equal(mine, want_hits)
+        mine, _ = ctx.dist_rows(idx, qs, 1, metric, 20, D)            # explicit queries: filtered postings
+        assert_hits_equal(mine, want_hits)
+    # ref-vs-query over the same crowded index
+    want_hits, _ = ok.index_dist32(counts, bits, postings, sizes, h[: int(off[50])], off[:51], 0, 0, 20, 0.12, threads=4)
+    mine, _ = ctx.dist_rows(idx, ctx.sketches_from_host(h[: int(off[50])], off[:51]), 0, 0, 20, 0.12)
+    assert_hits_equal(mine, want_hits)
+
+
 def test_row_sharding_union_equals_full(ctx):
     names, h, off = synth.clade_sketches(500, 100, 22, seed=9)
     idx = ctx.index_build(ctx.sketches_from_host(h, off), 22)
