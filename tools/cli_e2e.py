@@ -59,5 +59,45 @@ def main(n=200, length=5_000_000, threads=16):
     print("   " + " | ".join(l for l in err.splitlines() if "time" in l))
 
 
+def write_sketch_file(path, names, hashes, off, half_k=10, half_subk=6, drlevel=3):
+    """.sketch layout: info, name lengths, hash counts, then name+hashes per genome"""
+    n = len(names)
+    with open(path, "wb") as f:
+        np.array([(half_k << 8) + (half_subk << 4) + drlevel, half_k, half_subk, drlevel, n], dtype=np.int32).tofile(f)
+        np.array([len(x) for x in names], dtype=np.int32).tofile(f)
+        np.diff(off).astype(np.int32).tofile(f)
+        for i, name in enumerate(names):
+            f.write(name.encode())
+            hashes[int(off[i]):int(off[i + 1])].astype(np.uint32).tofile(f)
+
+
+def alldist(n=10000, threads=16):
+    """configs[2]: alldist from a precomputed .sketch (and its .dict/.index after the first run)"""
+    sys.path.insert(0, ROOT)
+    from rabbitkssd_amd import synth
+    tmp = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rk_e2e")
+    os.makedirs(tmp, exist_ok=True)
+    names, hashes, off = synth.clade_sketches(n, 1220, 28)
+    sk = os.path.join(tmp, "syn%d.sketch" % n)
+    write_sketch_file(sk, names, hashes, off)
+    for f in (sk + ".dict", sk + ".index"):
+        if os.path.exists(f):
+            os.remove(f)
+    for rep in range(3):  # run 0 builds and writes .dict/.index, runs 1-2 load them
+        t = time.time()
+        r = subprocess.run([TOOL, "alldist", "-i", sk, "-o", os.path.join(tmp, "syn.dist"), "-D", "0.05", "-t", str(threads)],
+                           cwd=tmp, capture_output=True, text=True)
+        dt = time.time() - t
+        if r.returncode:
+            print(r.stderr[-2000:])
+            raise SystemExit("alldist failed")
+        lines = sum(1 for _ in open(os.path.join(tmp, "syn.dist")))
+        print("alldist run %d: %.2f s wall, %d pairs reported, %.3g genome-pairs/s end to end" % (rep, dt, lines, n * (n - 1) / 2 / dt))
+        print("   " + " | ".join(l.strip("= ") for l in r.stderr.splitlines() if "time" in l))
+
+
 if __name__ == "__main__":
-    main(*[int(x) for x in sys.argv[1:]])
+    if len(sys.argv) > 1 and sys.argv[1] == "alldist":
+        alldist(*[int(x) for x in sys.argv[2:]])
+    else:
+        main(*[int(x) for x in sys.argv[1:]])

@@ -10,7 +10,7 @@ while read -r group; do
   out=$GRAFT_REPO_ROOT/gpurun_out/${tag}_$n
   rm -rf "$out"; mkdir -p "$out"
   echo "$group" > "$out/group.txt"
-  ( cd /tmp && timeout -k 10 180 rocprofv3 --pmc $group --kernel-include-regex "$regex" --kernel-trace -d "$out" -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/prof_driver.py "$@" ) > "$out/log.txt" 2>&1
+  ( cd /tmp && timeout -k 10 90 rocprofv3 --pmc $group --kernel-include-regex "$regex" --kernel-trace -d "$out" -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/prof_driver.py "$@" ) > "$out/log.txt" 2>&1
   rc=$?
   echo "pass $n [$group] rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out, stopping"; exit 1; fi
