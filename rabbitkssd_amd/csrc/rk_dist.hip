@@ -21,7 +21,6 @@
 
 namespace {
 
-constexpr int kDistThreads = 256;
 constexpr int kGroup = 8;                      // postings per slice walked by a quad (4 lanes x 2 postings)
 constexpr uint32_t kRowsPerXcdChunk = 16;      // consecutive rows kept on one XCD (their L2 shares a clade's postings)
 constexpr uint32_t kStageHitsDefault = 24;     // reported pairs staged in LDS per workgroup
@@ -101,7 +100,7 @@ __device__ unsigned long long g_prof[kProfWaves][16];  // one row per wave, summ
 #define PROF_FENCE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #define PROF_FLUSH()                                                                         \
     do {                                                                                     \
-        const uint32_t wv = (blockIdx.x * 4 + tid / 64) % kProfWaves;                        \
+        const uint32_t wv = (blockIdx.x * (kDistThreads / 64) + tid / 64) % kProfWaves;      \
         if (lane == 0) {                                                                     \
             for (int i = 0; i < 12; i++) g_prof[wv][i] += (unsigned long long)prof_acc[i];   \
             g_prof[wv][12] += (unsigned long long)(clock64() - prof_t0);                     \
@@ -128,9 +127,15 @@ __device__ unsigned long long g_prof[kProfWaves][16];  // one row per wave, summ
 // Per row: zero the LDS row | barrier | gather + scatter all slices | barrier | scan the row
 // into the cell list | barrier | evaluate the cells.  Three barriers; the evaluation of row r
 // overlaps the zeroing and scattering of row r+1 of faster waves (cell counters alternate).
-template <bool U16, bool FILTER>
-__global__ __launch_bounds__(kDistThreads) void rk_dist_kernel(DistArgs a)
+//
+// THREADS: a counter row of N columns occupies 2N (U16) or 4N bytes of the CU's 160 KiB, which
+// caps the resident workgroups; bigger rows get bigger workgroups so that the CU keeps 16-32
+// waves to hide the gather latency (measured at 28,284 / 50,000 columns: 512 / 1024 threads are
+// 1.25x / 1.9x faster than 256).
+template <bool U16, bool FILTER, int THREADS>
+__global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
 {
+    constexpr uint32_t kDistThreads = THREADS;
 #ifdef RK_DIST_PROFILE
     long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_t = clock64();
@@ -457,7 +462,7 @@ inline uint32_t envu_chunk()
 
 struct Plan {
     uint32_t n_rows, tile_cols, n_tiles, cnt_words;
-    uint32_t cand_cap, stage_hits, rows_per_wg;
+    uint32_t cand_cap, stage_hits, rows_per_wg, threads;
     size_t lds_bytes;
     int dense_mode;
     bool u16;
@@ -492,6 +497,11 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     p->n_tiles = idx->n_ref ? (idx->n_ref + tile - 1) / tile : 1;
     p->cnt_words = ((p->u16 ? (tile + 1) / 2 : tile) + 3) & ~3u;  // whole 16-byte quads
     p->lds_bytes = (size_t)p->cnt_words * 4 + fixed;
+    // workgroup size by row size: 7 x 256 threads fit up to ~22 KiB rows; bigger rows leave room for
+    // fewer workgroups, which then need more waves each
+    p->threads = p->lds_bytes <= 24 * 1024 ? 256 : (p->lds_bytes <= 64 * 1024 ? 512 : 1024);
+    const uint32_t forced = envu("RK_DIST_THREADS", 0);
+    if (forced == 256 || forced == 512 || forced == 1024) p->threads = forced;
     // does a pair with distance exactly 1.0 (common == 0) pass the threshold?
     p->dense_mode = o->triangle ? (1.0 < o->max_dist) : (1.0 <= o->max_dist);
     return RK_OK;
@@ -538,16 +548,21 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     // postings need no range check when there is one tile and the ranges are the index's own
     // "later genomes" slices
     const bool filter = !(p.n_tiles == 1 && ranges == idx->d_selfrange && o->triangle && !dense_dev);
-    void (*kern)(DistArgs);
-    if (filter) kern = p.u16 ? rk_dist_kernel<true, true> : rk_dist_kernel<false, true>;
-    else kern = p.u16 ? rk_dist_kernel<true, false> : rk_dist_kernel<false, false>;
+    void (*kern)(DistArgs) = nullptr;
+#define RK_PICK(T)                                                                              \
+    (filter ? (p.u16 ? rk_dist_kernel<true, true, T> : rk_dist_kernel<false, true, T>)          \
+            : (p.u16 ? rk_dist_kernel<true, false, T> : rk_dist_kernel<false, false, T>))
+    if (p.threads == 256) kern = RK_PICK(256);
+    else if (p.threads == 512) kern = RK_PICK(512);
+    else kern = RK_PICK(1024);
+#undef RK_PICK
     if (p.lds_bytes > 48 * 1024)
         RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)p.lds_bytes));
     const uint32_t runs = (p.n_rows + a.rows_per_wg - 1) / a.rows_per_wg;
     const uint32_t per = 8 * a.runs_per_chunk;  // grid padded to whole XCD chunks
     const uint32_t gx = (runs + per - 1) / per * per;
-    hipLaunchKernelGGL(kern, dim3(gx, p.n_tiles), dim3(kDistThreads), p.lds_bytes, stream, a);
+    hipLaunchKernelGGL(kern, dim3(gx, p.n_tiles), dim3(p.threads), p.lds_bytes, stream, a);
     RK_HIP(ctx, hipGetLastError());
     return RK_OK;
 }
