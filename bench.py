@@ -216,7 +216,8 @@ def main():
 
     def step(i):
         ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap,
-                          counters.data_ptr() + 8 * i, row_first=rank, row_step=world, stream=stream)
+                          counters.data_ptr() + 8 * i, row_first=rank, row_step=world, stream=stream,
+                          row_block=shard.ROW_BLOCK)
 
     def fence():
         torch.cuda.synchronize()
@@ -273,7 +274,7 @@ def main():
                                "distance kernel only from an HBM-resident index" % (n_genomes, HASHES_PER_GENOME, MAX_DIST),
                    "genomes": n_genomes, "pairs": n_pairs, "hashes": int(H), "postings_streamed_T": int(T),
                    "hits": int(tot_hits.item()), "max_dist": MAX_DIST,
-                   "sharding": "query rows interleaved over %d rank(s); index broadcast once over RCCL" % world},
+                   "sharding": "query rows in blocks of 16 dealt round-robin to %d rank(s); index broadcast once (RCCL on GPUs)" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "rk_dist_kernel", "kernel_ms": kernel_ms,

@@ -210,10 +210,13 @@ typedef struct rk_dist_opts {
                            0: dist (all cols, keep dist <= max_dist, src/dist.cpp:600,624) */
     int32_t metric;     /* 0 jaccard->mashD, 1 containment->AafD (-M)                  */
     int32_t kmer_size;  /* 2*half_k                                                    */
-    int32_t reserved_;
+    int32_t row_block;  /* rows are dealt to the shards in blocks of row_block consecutive rows
+                           (block-cyclic); 0,1 = single rows.  An even row_block lets the
+                           all-vs-all kernel walk neighbouring rows in pairs (16 is a good
+                           value for multi-GPU runs)                                       */
     double max_dist;    /* -D                                                          */
-    uint32_t row_first; /* rows row_first, row_first+row_step, ... (< n_query):        */
-    uint32_t row_step;  /*   interleaved row sharding across GPUs; 0,1 = all rows      */
+    uint32_t row_first; /* this shard owns blocks row_first, row_first+row_step, ...:  */
+    uint32_t row_step;  /*   row sharding across GPUs; 0,1 = all rows                  */
 } rk_dist_opts;
 
 /* Counts |S_q n S_r| through the inverted index and applies the reference's epilogue.

@@ -37,7 +37,7 @@ class Params(C.Structure):
 
 class DistOpts(C.Structure):
     _fields_ = [("triangle", C.c_int32), ("metric", C.c_int32), ("kmer_size", C.c_int32),
-                ("reserved_", C.c_int32), ("max_dist", C.c_double), ("row_first", C.c_uint32),
+                ("row_block", C.c_int32), ("max_dist", C.c_double), ("row_first", C.c_uint32),
                 ("row_step", C.c_uint32)]
 
 
@@ -217,8 +217,8 @@ class Context:
 
     # ---- distances
     def dist_rows(self, index, queries, triangle, metric, kmer_size, max_dist, row_first=0,
-                  row_step=1, want_dense=False):
-        opts = DistOpts(int(triangle), int(metric), int(kmer_size), 0, float(max_dist),
+                  row_step=1, want_dense=False, row_block=0):
+        opts = DistOpts(int(triangle), int(metric), int(kmer_size), int(row_block), float(max_dist),
                         int(row_first), int(row_step))
         hits = C.c_void_p()
         n = C.c_uint64()
@@ -233,8 +233,8 @@ class Context:
         return np.frombuffer(buf, dtype=HIT_DTYPE).copy(), dense
 
     def dist_rows_dev(self, index, triangle, metric, kmer_size, max_dist, hits_dev_ptr, hits_cap,
-                      n_hits_dev_ptr, row_first=0, row_step=1, stream=0):
-        opts = DistOpts(int(triangle), int(metric), int(kmer_size), 0, float(max_dist),
+                      n_hits_dev_ptr, row_first=0, row_step=1, stream=0, row_block=0):
+        opts = DistOpts(int(triangle), int(metric), int(kmer_size), int(row_block), float(max_dist),
                         int(row_first), int(row_step))
         self.check(lib().rk_dist_rows_dev(self._h, index._h, None, C.byref(opts),
                                           C.c_void_p(hits_dev_ptr), C.c_uint64(hits_cap),

@@ -32,9 +32,10 @@ struct DistArgs {
     const uint64_t *size_off;   // u64[n_query+1] offsets whose differences are the sketch sizes
     const uint32_t *postings;
     const uint32_t *ref_sizes;
+    const uint64_t *range_split; // pair mode: u64[n_query], a row's slices from here on are covered by its partner
     uint32_t n_query, n_ref;
-    uint32_t row_first, row_step, n_rows;
-    uint32_t tile_cols, cnt_words, rows_per_wg, runs_per_chunk;
+    uint32_t row_first, row_step, row_block, units_per_block, n_units;
+    uint32_t tile_cols, cnt_words, pair_stride, units_per_wg, runs_per_chunk;
     uint32_t cand_cap, stage_hits;  // LDS carve-up (entries)
     int triangle, metric, kmer_size, dense_mode;
     double max_dist;
@@ -118,24 +119,39 @@ __device__ unsigned long long g_prof[kProfWaves][16];  // one row per wave, summ
 // U16: two 16-bit counters per LDS word.  Valid when no count can reach 65536, i.e. the
 // largest query sketch has < 65536 hashes (a count never exceeds |S_q|); halves the LDS row
 // and doubles the resident rows per CU.
-// FILTER=false: single reference tile and slices that already exclude ids <= row (the
-// self-join slices of rk_index_build), so every posting lands in the row unchecked.
 //
-// One workgroup handles rows_per_wg consecutive row slots (strains of one clade share their
-// posting lists: the second row finds them in this CU's L1/L2) and stages the reported pairs in LDS, so the contended device-scope atomic on
-// the hit counter is paid once per workgroup instead of once per reporting wave.
-// Per row: zero the LDS row | barrier | gather + scatter all slices | barrier | scan the row
-// into the cell list | barrier | evaluate the cells.  Three barriers; the evaluation of row r
-// overlaps the zeroing and scattering of row r+1 of faster waves (cell counters alternate).
+// MODE
+//   kFiltered: explicit queries, tiled references or dense counter output: every posting is
+//              range-checked against the tile and the triangle.
+//   kSelf:     the self join over the index's own "later genomes" slices, one tile: every
+//              posting lands in the row unchecked.
+//   kSelfPair: kSelf over PAIRS of neighbouring rows (2p, 2p+1) with one LDS row each.  A posting
+//              list is sorted by genome, so the slice of row 2p for a hash starts with 2p+1
+//              exactly when 2p+1 holds that hash too -- and then continues with precisely the
+//              slice of row 2p+1.  Walking it once serves both rows; row 2p+1 only walks the
+//              slices of hashes its partner lacks (the index stores them first, rk_index.hip
+//              compact_self).  Neighbouring genomes of a sorted collection are close relatives:
+//              at 10,000 genomes 41 % of all slice walks disappear.
+//
+// One workgroup handles units_per_wg consecutive units (a unit = a row, or a pair of rows) and
+// stages the reported pairs in LDS, so the contended device-scope atomic on the hit counter is
+// paid once per workgroup instead of once per reporting wave.
+// Per unit: zero the LDS rows | barrier | gather + scatter all slices | barrier | scan the rows
+// into the cell list | barrier | evaluate the cells.  Three barriers; the evaluation of unit u
+// overlaps the zeroing and scattering of unit u+1 in the faster waves (cell counters alternate).
 //
 // THREADS: a counter row of N columns occupies 2N (U16) or 4N bytes of the CU's 160 KiB, which
 // caps the resident workgroups; bigger rows get bigger workgroups so that the CU keeps 16-32
 // waves to hide the gather latency (measured at 28,284 / 50,000 columns: 512 / 1024 threads are
 // 1.25x / 1.9x faster than 256).
-template <bool U16, bool FILTER, int THREADS>
+enum { kFiltered = 0, kSelf = 1, kSelfPair = 2 };
+
+template <bool U16, int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
 {
     constexpr uint32_t kDistThreads = THREADS;
+    constexpr bool FILTER = MODE == kFiltered;
+    constexpr bool PAIR = MODE == kSelfPair;
 #ifdef RK_DIST_PROFILE
     long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_t = clock64();
@@ -143,27 +159,27 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     const long long prof_w0 = wall_clock64();
 #endif
     // one dynamic LDS region (16-byte aligned base):
-    // counter row | non-zero cell list | staged hits | scalars
+    // counter row(s) | non-zero cell list | staged hits | scalars
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *cnt = lds;
-    uint2 *cand = reinterpret_cast<uint2 *>(lds + a.cnt_words);  // (col, common) of the current row
+    uint2 *cand = reinterpret_cast<uint2 *>(lds + a.cnt_words);  // (cell, common) of the current unit
     rk_hit *stage = reinterpret_cast<rk_hit *>(cand + a.cand_cap);
     uint32_t *scal = reinterpret_cast<uint32_t *>(stage + a.stage_hits);
     unsigned long long &s_base = *reinterpret_cast<unsigned long long *>(scal);
-    uint32_t *s_cells = scal + 2;   // [2] cells of the row being scanned (alternating per row)
+    uint32_t *s_cells = scal + 2;   // [2] cells of the unit being scanned (alternating per unit)
     uint32_t &s_cursor = scal[4];   // staged hits
     const uint32_t kCandCap = a.cand_cap, kStageHits = a.stage_hits;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
 
-    // blockIdx.x -> run of row slots.  Workgroups are dealt round-robin over the 8 XCDs, so
+    // blockIdx.x -> run of unit slots.  Workgroups are dealt round-robin over the 8 XCDs, so
     // blocks b, b+8, ... share an L2: consecutive runs of one XCD are adjacent rows, while
     // heavy (early) rows stay spread over all XCDs.
     const uint32_t xcd = blockIdx.x & 7, s8 = blockIdx.x >> 3;
     const uint32_t rpc = a.runs_per_chunk;
     const uint32_t run = ((s8 / rpc) * 8 + xcd) * rpc + s8 % rpc;
-    const uint32_t slot0 = run * a.rows_per_wg;
-    if (slot0 >= a.n_rows) return;
+    const uint32_t slot0 = run * a.units_per_wg;
+    if (slot0 >= a.n_units) return;
     const uint32_t col0 = blockIdx.y * a.tile_cols;
     const uint32_t col1 = min(a.n_ref, col0 + a.tile_cols);
     const uint32_t ncol = col1 - col0;
@@ -173,14 +189,26 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     const bool tri_filter = a.triangle && !a.common_dense;
     constexpr uint32_t kPerWord = U16 ? 2 : 1;
     const uint4 *c4 = reinterpret_cast<const uint4 *>(cnt);
-    const uint32_t slot_end = min(a.n_rows, slot0 + a.rows_per_wg);
+    const uint32_t slot_end = min(a.n_units, slot0 + a.units_per_wg);
+    const uint32_t row_b_cell = a.pair_stride;  // first cell of the second row of a pair
 
-    auto row_of = [&](uint32_t slot) { return a.row_first + slot * a.row_step; };
-    auto skipped = [&](uint32_t row) { return a.triangle && col1 <= row + 1 && !a.common_dense; };
-    // first slot >= s whose row has work in this tile
+    // unit slot -> its first row.  Rows are dealt to the ranks in blocks of row_block rows
+    // (block-cyclic; row_block 1 = plain interleave): this rank owns blocks row_first,
+    // row_first + row_step, ...
+    auto unit_row = [&](uint32_t slot) -> uint32_t {
+        const uint32_t upb = a.units_per_block;
+        const uint32_t t = upb == 1 ? slot : slot / upb;
+        const uint32_t r = slot - t * upb;
+        const uint64_t row = ((uint64_t)a.row_first + (uint64_t)t * a.row_step) * a.row_block + (uint64_t)r * (PAIR ? 2 : 1);
+        return row < a.n_query ? (uint32_t)row : 0xFFFFFFFFu;
+    };
+    auto skipped = [&](uint32_t row) {
+        return row == 0xFFFFFFFFu || (a.triangle && col1 <= row + 1 && !a.common_dense);
+    };
+    // first slot >= s whose unit has work in this tile
     auto next_live = [&](uint32_t s, uint32_t &row) {
         while (s < slot_end) {
-            row = row_of(s);
+            row = unit_row(s);
             if (!skipped(row)) break;
             s++;
         }
@@ -188,6 +216,10 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     };
     auto load_slice = [&](uint64_t e, uint64_t e1) -> uint2 {
         return e < e1 ? a.ranges[e] : make_uint2(0, 0);
+    };
+    auto bump_cell = [&](uint32_t c) {  // scatter, src/dist.cpp:199-202
+        if (U16) atomicAdd(&cnt[c >> 1], (c & 1) ? 0x10000u : 1u);
+        else atomicAdd(&cnt[c], 1u);
     };
 
     struct Gathered {  // head postings of the 4 slices a lane's quad walks in one batch
@@ -213,18 +245,20 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         static_assert(kGroup == 8, "a quad covers 4 lanes x 2 postings");
     };
 
-    // ---- epilogue of one row (src/dist.cpp:207-255 / :600-682) ---------------------------
-    auto epilogue = [&](uint32_t row, uint32_t &s_total) {
-        if (a.common_dense) {
-            int32_t *dst = a.common_dense + (size_t)row * a.n_ref + col0;
+    // ---- epilogue of one unit (src/dist.cpp:207-255 / :600-682) --------------------------
+    // row_a: the unit's (first) row; row_b: its pair partner or 0xFFFFFFFF
+    auto epilogue = [&](uint32_t row_a, uint32_t row_b, uint32_t &s_total) {
+        const bool has_b = PAIR && row_b != 0xFFFFFFFFu;
+        if (a.common_dense) {  // never in pair mode
+            int32_t *dst = a.common_dense + (size_t)row_a * a.n_ref + col0;
             for (uint32_t i = tid; i < ncol; i += kDistThreads)
                 dst[i] = (int32_t)(U16 ? (cnt[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu : cnt[i]);
         }
-        const int qsize = (int)(a.size_off[row + 1] - a.size_off[row]);
-        const uint32_t jbeg = a.triangle ? max(col0, row + 1) : col0;  // :207 / :600
+        const int qsize_a = (int)(a.size_off[row_a + 1] - a.size_off[row_a]);
+        const int qsize_b = has_b ? (int)(a.size_off[row_b + 1] - a.size_off[row_b]) : 0;
 
         // evaluates one (row, j) cell; returns true when it is reported
-        auto evaluate = [&](uint32_t j, int common, rk_hit &hrec) -> bool {
+        auto evaluate = [&](uint32_t row, int qsize, uint32_t j, int common, rk_hit &hrec) -> bool {
             const int rs = (int)a.ref_sizes[j];
             const int size0 = a.triangle ? qsize : rs;  // :215-216 / :607-608
             const int size1 = a.triangle ? rs : qsize;
@@ -254,16 +288,27 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         auto cell = [&](uint32_t c) -> uint32_t {
             return U16 ? (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu : cnt[c];
         };
+        // cell of the LDS region -> (row, column) and the evaluation
+        auto eval_cell = [&](uint32_t c, uint32_t common) {
+            const bool in_b = PAIR && c >= row_b_cell;
+            const uint32_t row = in_b ? row_b : row_a;
+            const uint32_t j = col0 + (in_b ? c - row_b_cell : c);
+            const uint32_t jbeg = a.triangle ? max(col0, row + 1) : col0;  // :207 / :600
+            rk_hit hrec;
+            if (j >= jbeg && j < col1 && evaluate(row, in_b ? qsize_b : qsize_a, j, (int)common, hrec)) stage_hit(hrec);
+        };
+        const uint32_t jbeg_a = a.triangle ? max(col0, row_a + 1) : col0;
+        const uint32_t cells_end = has_b ? row_b_cell + ncol : ncol;   // cells in use
 
         if (!a.dense_mode) {
             // Sparse mode: the threshold excludes distance 1.0 (== common 0), so only cells
-            // that share a hash can be reported.  Scan the LDS row 16 B per lane skipping
+            // that share a hash can be reported.  Scan the LDS rows 16 B per lane skipping
             // all-zero quads and compact the non-zero cells into an LDS list (one LDS atomic
             // per lane that found any), then evaluate the list one cell per lane: the FP64
             // divide + log run in parallel, not serialised on the lane that happened to own a
             // clade's adjacent columns.
-            const uint32_t q_first = ((jbeg - col0) / kPerWord) / 4;
-            const uint32_t q_end = ((ncol + kPerWord - 1) / kPerWord + 3) / 4;
+            const uint32_t q_first = ((jbeg_a - col0) / kPerWord) / 4;
+            const uint32_t q_end = ((cells_end + kPerWord - 1) / kPerWord + 3) / 4;
             for (uint32_t q = q_first + tid; q < q_end; q += kDistThreads) {
                 const uint4 v = c4[q];
                 if ((v.x | v.y | v.z | v.w) == 0) continue;
@@ -275,14 +320,14 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                     else n += w[wi] != 0;
                 }
                 uint32_t at = atomicAdd(&s_total, n);
-                const uint32_t jq = col0 + q * 4 * kPerWord;
+                const uint32_t cq = q * 4 * kPerWord;
 #pragma unroll
                 for (int wi = 0; wi < 4; wi++) {
 #pragma unroll
                     for (uint32_t h = 0; h < kPerWord; h++) {
                         const uint32_t common = U16 ? (w[wi] >> (16 * h)) & 0xFFFFu : w[wi];
                         if (common) {
-                            if (at < kCandCap) cand[at] = make_uint2(jq + wi * kPerWord + h, common);
+                            if (at < kCandCap) cand[at] = make_uint2(cq + wi * kPerWord + h, common);
                             at++;
                         }
                     }
@@ -295,32 +340,36 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
             if (n_cells <= kCandCap) {
                 for (uint32_t i = tid; i < n_cells; i += kDistThreads) {
                     const uint2 cj = cand[i];
-                    rk_hit hrec;
-                    if (cj.x >= jbeg && cj.x < col1 && evaluate(cj.x, (int)cj.y, hrec)) stage_hit(hrec);
+                    eval_cell(cj.x, cj.y);
                 }
             } else {
-                // more sharing columns than the list holds: walk the row, one column per lane
-                for (uint32_t j = jbeg + tid; j < col1; j += kDistThreads) {
-                    const uint32_t common = cell(j - col0);
-                    rk_hit hrec;
-                    if (common && evaluate(j, (int)common, hrec)) stage_hit(hrec);
+                // more sharing columns than the list holds: walk the rows, one cell per lane
+                for (uint32_t c = (jbeg_a - col0) + tid; c < cells_end; c += kDistThreads) {
+                    const uint32_t common = cell(c);
+                    if (common) eval_cell(c, common);
                 }
-                __syncthreads();  // the row is zeroed next
+                __syncthreads();  // the rows are zeroed next
             }
             PROF_MARK(4);
         } else {
             // Dense mode: every cell of [jbeg, col1) can be reported.  One column per lane;
-            // pass 0 counts this row's reports, one atomic reserves their slots, pass 1
+            // pass 0 counts the unit's reports, one atomic reserves their slots, pass 1
             // re-evaluates and writes them.
             for (int pass_no = 0; pass_no < 2; pass_no++) {
                 uint32_t mine = 0;
-                for (uint32_t j = jbeg + tid; j < col1; j += kDistThreads) {
-                    const int common = (int)cell(j - col0);
-                    rk_hit hrec;
-                    if (!evaluate(j, common, hrec)) continue;
-                    if (pass_no == 0) { mine++; continue; }
-                    const unsigned long long at = s_base + atomicAdd(&s_total, 1u);
-                    if (at < a.cap) a.hits[at] = hrec;
+                for (int which = 0; which < (has_b ? 2 : 1); which++) {
+                    const uint32_t row = which ? row_b : row_a;
+                    const uint32_t base = which ? row_b_cell : 0;
+                    const int qsize = which ? qsize_b : qsize_a;
+                    const uint32_t jbeg = a.triangle ? max(col0, row + 1) : col0;
+                    for (uint32_t j = jbeg + tid; j < col1; j += kDistThreads) {
+                        const int common = (int)cell(base + j - col0);
+                        rk_hit hrec;
+                        if (!evaluate(row, qsize, j, common, hrec)) continue;
+                        if (pass_no == 0) { mine++; continue; }
+                        const unsigned long long at = s_base + atomicAdd(&s_total, 1u);
+                        if (at < a.cap) a.hits[at] = hrec;
+                    }
                 }
                 if (pass_no == 0) {
                     if (mine) atomicAdd(&s_total, mine);
@@ -332,24 +381,42 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                     __syncthreads();
                 }
             }
-            __syncthreads();  // the row is zeroed next
+            __syncthreads();  // the rows are zeroed next
         }
     };
 
-    // ---- rows of this run ---------------------------------------------------------------------
+    // ---- units of this run --------------------------------------------------------------------
+    // A unit's slices are one contiguous range [e0, e1) of `ranges`: the (first) row's slices and,
+    // in pair mode, right behind them the partner's uncovered slices (from eb on).  `pre` always
+    // holds the next batch of slices.
+    struct Unit {
+        uint64_t e0, eb, e1;
+        uint32_t row_b;
+    };
+    auto open_unit = [&](uint32_t row_a, Unit &u) {
+        u.e0 = a.range_off[row_a];
+        u.eb = u.e1 = a.range_off[row_a + 1];
+        u.row_b = 0xFFFFFFFFu;
+        if (PAIR && row_a + 1 < a.n_query) {
+            u.row_b = row_a + 1;
+            u.e1 = a.range_split[row_a + 1];  // eb == range_off[row_b]
+        }
+    };
     uint32_t row = 0;
     uint32_t slot = next_live(slot0, row);
     if (slot >= slot_end) return;  // nothing to do in this tile (uniform)
-    uint64_t e0 = a.range_off[row], e1 = a.range_off[row + 1];
-    uint2 pre = load_slice(e0 + tid, e1);  // the slices of the next batch are always in flight
+    Unit cur;
+    open_unit(row, cur);
+    uint2 pre = load_slice(cur.e0 + tid, cur.e1);
     uint32_t parity = 0;
 
     while (slot < slot_end) {
-        // look ahead: the next row's slice range is fetched while this row is processed
+        // look ahead: the next unit's slice range is fetched while this unit is processed
         uint32_t nrow = 0;
         const uint32_t nslot = next_live(slot + 1, nrow);
-        uint64_t ne0 = 0, ne1 = 0;
-        if (nslot < slot_end) { ne0 = a.range_off[nrow]; ne1 = a.range_off[nrow + 1]; }
+        Unit nxt = cur;
+        nxt.e0 = nxt.e1 = 0;
+        if (nslot < slot_end) open_unit(nrow, nxt);
 
         uint4 *z4 = reinterpret_cast<uint4 *>(cnt);  // memset row (src/dist.cpp:179)
         for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
@@ -358,30 +425,36 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         PROF_MARK(6);
 
         const uint32_t lo_id = tri_filter ? row + 1 : 0;  // ids below are not needed (j > i)
-        auto bump = [&](uint32_t id, bool valid) {        // scatter, src/dist.cpp:199-202
+        const uint32_t row_b = cur.row_b;
+        const uint64_t e0 = cur.e0, e1 = cur.e1;
+
+        // `in_b`: the slice belongs to the partner row (scatter into its LDS row only);
+        // `also_b`: a first-row slice shared with the partner (scatter into both)
+        auto bump = [&](uint32_t id, bool valid, bool in_b, bool also_b) {
             const uint32_t c = id - col0;
             if (valid && (!FILTER || (c < ncol && id >= lo_id))) {
-                if (U16) atomicAdd(&cnt[c >> 1], (c & 1) ? 0x10000u : 1u);
-                else atomicAdd(&cnt[c], 1u);
+                bump_cell((PAIR && in_b ? row_b_cell : 0) + c);
+                if (PAIR && also_b) bump_cell(row_b_cell + c);
             }
         };
-        auto stream_list = [&](uint32_t sx, uint32_t sy) {  // whole wave, 2 x 64 postings in flight
+        auto stream_list = [&](uint32_t sx, uint32_t sy, bool in_b, bool also_b) {  // whole wave, 2 x 64 postings in flight
             for (uint32_t k = sx + lane; k < sy; k += 128) {
                 const bool ok1 = k + 64 < sy;
                 const uint32_t i0 = a.postings[k], i1 = a.postings[ok1 ? k + 64 : 0];
-                bump(i0, true);
-                bump(i1, ok1);
+                bump(i0, true, in_b, also_b);
+                bump(i1, ok1, in_b, also_b);
             }
         };
 
-        // A batch = up to 256 slices of the row, one per thread, loaded straight from HBM into
-        // a register pair (no LDS staging, no barrier).
-        const uint32_t nb = max(1u, (uint32_t)((e1 - e0 + kDistThreads - 1) / kDistThreads));
+        // A batch = up to THREADS slices of the unit, one per thread, loaded straight from HBM
+        // into a register pair (no LDS staging, no barrier).
+        const uint32_t nb = (uint32_t)((e1 - e0 + kDistThreads - 1) / kDistThreads);
         for (uint32_t b = 0; b < nb; b++) {
+            const uint64_t at = e0 + (uint64_t)b * kDistThreads;
             const uint2 rg = pre;
-            if (b + 1 < nb) pre = load_slice(e0 + (uint64_t)(b + 1) * kDistThreads + tid, e1);
-            else if (nslot < slot_end) pre = load_slice(ne0 + tid, ne1);
-            else pre = make_uint2(0, 0);
+            const bool held_in_b = PAIR && at + tid >= cur.eb;   // the slice this lane holds is the partner's
+            if (b + 1 < nb) pre = load_slice(at + kDistThreads + tid, e1);
+            else pre = load_slice(nxt.e0 + tid, nxt.e1);
             PROF_MARK(0);
 
             Gathered g;
@@ -392,12 +465,14 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
             // dependent round trip each; whatever is longer still is streamed by the whole wave.
             unsigned long long longs = __ballot(rg.y - rg.x > (uint32_t)kGroup);
             uint32_t lx[4] = {0, 0, 0, 0}, ly[4] = {0, 0, 0, 0};  // uniform
-            uint32_t qx = 0, qy = 0;                              // this lane's row
+            int lown[4] = {0, 0, 0, 0};                           // uniform: lane holding the slice
+            uint32_t qx = 0, qy = 0;                              // this lane's 16-lane row
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 if (longs) {  // uniform
                     const int L = __ffsll((long long)longs) - 1;
                     longs &= longs - 1;
+                    lown[t] = L;
                     lx[t] = __builtin_amdgcn_readlane(rg.x, L) + kGroup;
                     ly[t] = __builtin_amdgcn_readlane(rg.y, L);
                     if ((lane >> 4) == (uint32_t)t) { qx = lx[t]; qy = ly[t]; }
@@ -409,33 +484,60 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
             PROF_MARK(7);
             PROF_FENCE();
             PROF_MARK(8);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                bump(g.id[j].x, g.ok0[j]);
-                bump(g.id[j].y, g.ok1[j]);
-            }
+            // pair mode: a first-row slice is shared with the partner iff its first posting IS
+            // the partner; the partner then gets every later posting of the list
+            bool held_shared = false;  // for the slice this lane holds
+            auto walk = [&](int j, bool in_b) {
+                bool shared = false;
+                if (PAIR) {
+                    const uint32_t first = quad_bcast<0>(g.ok0[j] ? g.id[j].x : 0xFFFFFFFEu);  // never a row
+                    shared = !in_b && first == row_b;
+                    if (sub == (uint32_t)j) held_shared = shared;
+                }
+                bump(g.id[j].x, g.ok0[j], in_b, shared && sub != 0);  // the first posting is the partner itself
+                bump(g.id[j].y, g.ok1[j], in_b, shared);
+            };
+            const uint32_t hb = held_in_b ? 1u : 0u;
+            walk(0, PAIR && quad_bcast<0>(hb) != 0);
+            walk(1, PAIR && quad_bcast<1>(hb) != 0);
+            walk(2, PAIR && quad_bcast<2>(hb) != 0);
+            walk(3, PAIR && quad_bcast<3>(hb) != 0);
             PROF_FENCE();
             PROF_MARK(9);
-            bump(lidq, lokq);
+            unsigned long long shared_mask = 0, in_b_mask = 0;
+            if (PAIR) {
+                shared_mask = __ballot(held_shared);
+                in_b_mask = __ballot(held_in_b);
+            }
+            bool q_shared = false, q_in_b = false;
 #pragma unroll
             for (int t = 0; t < 4; t++)
-                if (lx[t] + 16 < ly[t]) stream_list(lx[t] + 16, ly[t]);  // uniform
+                if ((lane >> 4) == (uint32_t)t) {
+                    q_shared = (shared_mask >> lown[t]) & 1;
+                    q_in_b = (in_b_mask >> lown[t]) & 1;
+                }
+            bump(lidq, lokq, q_in_b, q_shared);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (lx[t] + 16 < ly[t])  // uniform
+                    stream_list(lx[t] + 16, ly[t], (in_b_mask >> lown[t]) & 1, (shared_mask >> lown[t]) & 1);
             while (longs) {
                 const int L = __ffsll((long long)longs) - 1;
                 longs &= longs - 1;
-                stream_list(__builtin_amdgcn_readlane(rg.x, L) + kGroup, __builtin_amdgcn_readlane(rg.y, L));
+                stream_list(__builtin_amdgcn_readlane(rg.x, L) + kGroup, __builtin_amdgcn_readlane(rg.y, L),
+                            (in_b_mask >> L) & 1, (shared_mask >> L) & 1);
             }
             PROF_FENCE();
             PROF_MARK(10);
         }
-        __syncthreads();  // all scatters of the row done
+        if (nb == 0) pre = load_slice(nxt.e0 + tid, nxt.e1);  // a unit without slices still hands over the prefetch
+        __syncthreads();  // all scatters of the unit done
         PROF_MARK(1);
-        epilogue(row, s_cells[parity]);
+        epilogue(row, row_b, s_cells[parity]);
         parity ^= 1;
         slot = nslot;
         row = nrow;
-        e0 = ne0;
-        e1 = ne1;
+        cur = nxt;
     }
 
     // flush the staged hits of this workgroup: one device-scope atomic, coalesced 8-byte stores
@@ -454,37 +556,32 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         if (at0 + i / kW < a.cap) dst[at0 * kW + i] = src[i];
 }
 
-inline uint32_t envu_chunk()
+inline uint32_t envu(const char *name, uint32_t dflt)
 {
-    const char *v = getenv("RK_DIST_XCD_ROWS");
-    return v && atoi(v) > 0 ? (uint32_t)atoi(v) : kRowsPerXcdChunk;
+    const char *v = getenv(name);
+    return v && atoi(v) > 0 ? (uint32_t)atoi(v) : dflt;
 }
 
 struct Plan {
-    uint32_t n_rows, tile_cols, n_tiles, cnt_words;
-    uint32_t cand_cap, stage_hits, rows_per_wg, threads;
+    uint32_t n_units, tile_cols, n_tiles, cnt_words, row_words;
+    uint32_t cand_cap, stage_hits, units_per_wg, threads;
+    uint32_t row_first, row_step, row_block, units_per_block;
     size_t lds_bytes;
-    int dense_mode;
+    int dense_mode, mode;
     bool u16;
 };
 
+// want_self: the ranges are the index's own "later genomes" slices (self join, triangle, no dense output)
 int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_query_size,
-              const rk_dist_opts *o, Plan *p)
+              const rk_dist_opts *o, bool want_self, Plan *p)
 {
     if (o->kmer_size <= 0) return rk_fail(ctx, RK_ERR_ARG, "kmer_size must be positive");
     if (o->metric != 0 && o->metric != 1) return rk_fail(ctx, RK_ERR_ARG, "metric must be 0 or 1");
-    const uint32_t step = o->row_step ? o->row_step : 1;
-    p->n_rows = o->row_first < n_query ? (n_query - o->row_first + step - 1) / step : 0;
-    // counter row in LDS; tile the reference range when it does not fit.  40 KiB rows let
-    // four workgroups share a CU, which hides the posting-gather latency.
+    if (o->row_block < 0) return rk_fail(ctx, RK_ERR_ARG, "row_block must be >= 0");
+    // counter row in LDS; tile the reference range when it does not fit
     p->u16 = max_query_size < 65536;
-    auto envu = [](const char *name, uint32_t dflt) {
-        const char *v = getenv(name);
-        return v && atoi(v) > 0 ? (uint32_t)atoi(v) : dflt;
-    };
     p->cand_cap = (envu("RK_DIST_CAND_CAP", kCandCapDefault) + 1) & ~1u;
     p->stage_hits = envu("RK_DIST_STAGE_HITS", kStageHitsDefault);
-    p->rows_per_wg = envu("RK_DIST_ROWS", 2);
     const size_t fixed = (size_t)p->cand_cap * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
     const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - fixed;
     const uint32_t max_cols = (uint32_t)(p->u16 ? lds_cap / 2 : lds_cap / 4) & ~63u;
@@ -495,8 +592,29 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     }
     p->tile_cols = tile;
     p->n_tiles = idx->n_ref ? (idx->n_ref + tile - 1) / tile : 1;
-    p->cnt_words = ((p->u16 ? (tile + 1) / 2 : tile) + 3) & ~3u;  // whole 16-byte quads
+    p->row_words = ((p->u16 ? (tile + 1) / 2 : tile) + 3) & ~3u;  // whole 16-byte quads
+
+    // row distribution: blocks of row_block rows dealt round-robin to row_step shards
+    p->row_step = o->row_step ? o->row_step : 1;
+    p->row_first = o->row_first;
+    p->row_block = o->row_block > 0 ? (uint32_t)o->row_block : 1;
+    if (p->row_step == 1 && p->row_first == 0) p->row_block = std::max<uint32_t>(2, (n_query + 1) & ~1u);  // all rows: one block
+    p->mode = want_self && p->n_tiles == 1 ? kSelf : kFiltered;
+    // pairs of neighbouring rows: blocks must hold whole pairs and two rows must fit in LDS next to
+    // each other with room for at least three workgroups per CU (measured: with fewer, the lost
+    // occupancy costs more than the saved walks: 14,142 columns 0.127 ms paired vs 0.113 single)
+    const bool pair_ok = p->mode == kSelf && p->row_block % 2 == 0 && idx->d_self_split &&
+                         (size_t)p->row_words * 8 + fixed <= lds_cap / envu("RK_DIST_PAIR_MINWG", 3) &&
+                         envu("RK_DIST_PAIR", 1) != 2;
+    if (pair_ok) p->mode = kSelfPair;
+    const uint32_t unit_rows = p->mode == kSelfPair ? 2 : 1;
+    p->units_per_block = p->row_block / unit_rows;
+    const uint64_t n_blocks = ((uint64_t)n_query + p->row_block - 1) / p->row_block;
+    const uint64_t my_blocks = p->row_first < n_blocks ? (n_blocks - p->row_first + p->row_step - 1) / p->row_step : 0;
+    p->n_units = (uint32_t)std::min<uint64_t>(my_blocks * p->units_per_block, 0xFFFFFFF0u);
+    p->cnt_words = p->row_words * unit_rows;
     p->lds_bytes = (size_t)p->cnt_words * 4 + fixed;
+    p->units_per_wg = envu("RK_DIST_ROWS", p->mode == kSelfPair ? 1 : 2);
     // workgroup size by row size: 7 x 256 threads fit up to ~22 KiB rows; bigger rows leave room for
     // fewer workgroups, which then need more waves each
     p->threads = p->lds_bytes <= 24 * 1024 ? 256 : (p->lds_bytes <= 64 * 1024 ? 512 : 1024);
@@ -511,20 +629,24 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
                 const uint64_t *size_off, uint32_t n_query, const rk_dist_opts *o, const Plan &p, rk_hit *hits_dev,
                 uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev, hipStream_t stream)
 {
-    if (!p.n_rows || !idx->n_ref) return RK_OK;
+    if (!p.n_units || !idx->n_ref) return RK_OK;
     DistArgs a;
     a.ranges = ranges;
     a.range_off = range_off;
+    a.range_split = p.mode == kSelfPair ? idx->d_self_split : nullptr;
     a.size_off = size_off;
     a.postings = idx->d_postings;
     a.ref_sizes = idx->d_sizes;
     a.n_query = n_query;
     a.n_ref = idx->n_ref;
-    a.row_first = o->row_first;
-    a.row_step = o->row_step ? o->row_step : 1;
-    a.n_rows = p.n_rows;
+    a.row_first = p.row_first;
+    a.row_step = p.row_step;
+    a.row_block = p.row_block;
+    a.units_per_block = p.units_per_block;
+    a.n_units = p.n_units;
     a.tile_cols = p.tile_cols;
     a.cnt_words = p.cnt_words;
+    a.pair_stride = p.row_words * (p.u16 ? 2 : 1);
     a.triangle = o->triangle;
     a.metric = o->metric;
     a.kmer_size = o->kmer_size;
@@ -541,25 +663,25 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.cap = cap;
     a.n_hits = n_hits_dev;
     a.common_dense = dense_dev;
-    a.rows_per_wg = p.rows_per_wg;
-    a.runs_per_chunk = std::max<uint32_t>(1, envu_chunk() / p.rows_per_wg);
+    a.units_per_wg = p.units_per_wg;
+    const uint32_t unit_rows = p.mode == kSelfPair ? 2 : 1;
+    a.runs_per_chunk = std::max<uint32_t>(1, envu("RK_DIST_XCD_ROWS", kRowsPerXcdChunk) / (p.units_per_wg * unit_rows));
     a.cand_cap = p.cand_cap;
     a.stage_hits = p.stage_hits;
-    // postings need no range check when there is one tile and the ranges are the index's own
-    // "later genomes" slices
-    const bool filter = !(p.n_tiles == 1 && ranges == idx->d_selfrange && o->triangle && !dense_dev);
     void (*kern)(DistArgs) = nullptr;
-#define RK_PICK(T)                                                                              \
-    (filter ? (p.u16 ? rk_dist_kernel<true, true, T> : rk_dist_kernel<false, true, T>)          \
-            : (p.u16 ? rk_dist_kernel<true, false, T> : rk_dist_kernel<false, false, T>))
+#define RK_PICK3(U, T)                                                                          \
+    (p.mode == kSelfPair ? rk_dist_kernel<U, kSelfPair, T>                                      \
+                         : (p.mode == kSelf ? rk_dist_kernel<U, kSelf, T> : rk_dist_kernel<U, kFiltered, T>))
+#define RK_PICK(T) (p.u16 ? RK_PICK3(true, T) : RK_PICK3(false, T))
     if (p.threads == 256) kern = RK_PICK(256);
     else if (p.threads == 512) kern = RK_PICK(512);
     else kern = RK_PICK(1024);
 #undef RK_PICK
+#undef RK_PICK3
     if (p.lds_bytes > 48 * 1024)
         RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)p.lds_bytes));
-    const uint32_t runs = (p.n_rows + a.rows_per_wg - 1) / a.rows_per_wg;
+    const uint32_t runs = (p.n_units + a.units_per_wg - 1) / a.units_per_wg;
     const uint32_t per = 8 * a.runs_per_chunk;  // grid padded to whole XCD chunks
     const uint32_t gx = (runs + per - 1) / per * per;
     hipLaunchKernelGGL(kern, dim3(gx, p.n_tiles), dim3(p.threads), p.lds_bytes, stream, a);
@@ -603,7 +725,7 @@ int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *querie
     if (!opts->triangle || !idx->d_selfrange)
         return rk_fail(ctx, RK_ERR_ARG, "queries == NULL needs triangle=1 and an index built by rk_index_build");
     Plan p;
-    int rc = make_plan(ctx, idx, idx->n_ref, idx->max_src_size, opts, &p);
+    int rc = make_plan(ctx, idx, idx->n_ref, idx->max_src_size, opts, true, &p);
     if (rc) return rc;
     return launch_dist(ctx, idx, idx->d_selfrange, idx->d_self_off, idx->d_src_off, idx->n_ref, opts, p, hits_dev,
                        hits_cap, (unsigned long long *)n_hits_dev, nullptr, (hipStream_t)stream);
@@ -630,7 +752,7 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
         for (uint32_t g = 0; g < queries->n; g++)
             max_q = std::max<uint64_t>(max_q, queries->h_off[g + 1] - queries->h_off[g]);
     }
-    int rc = make_plan(ctx, idx, n_query, max_q, opts, &p);
+    int rc = make_plan(ctx, idx, n_query, max_q, opts, self && !common_dense, &p);
     if (rc) return rc;
 
     // posting ranges of every query hash: precomputed for the self join, resolved through
@@ -673,14 +795,13 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
 
     // sparse mode: optimistic capacity, exact retry on overflow.  dense mode: every
     // selected (row, col) cell is a hit, so the count is known up front.
-    uint64_t cap;
-    if (p.dense_mode) {
-        if (opts->triangle) {
-            cap = 0;
-            const uint32_t step = opts->row_step ? opts->row_step : 1;
-            for (uint32_t r = opts->row_first; r < n_query; r += step) cap += idx->n_ref - 1 - r;
-        } else cap = (uint64_t)p.n_rows * idx->n_ref;
-    } else cap = std::max<uint64_t>(1 << 16, (uint64_t)p.n_rows * 64);
+    uint64_t cap = 0, n_sel = 0;  // rows of this shard: blocks row_first, row_first + row_step, ... of row_block rows
+    for (uint64_t blk = p.row_first; blk * p.row_block < n_query; blk += p.row_step)
+        for (uint64_t r = blk * p.row_block; r < std::min<uint64_t>(n_query, (blk + 1) * p.row_block); r++) {
+            n_sel++;
+            if (p.dense_mode) cap += opts->triangle ? idx->n_ref - 1 - r : idx->n_ref;
+        }
+    if (!p.dense_mode) cap = std::max<uint64_t>(1 << 16, n_sel * 64);
     std::vector<rk_hit> host;
     for (int attempt = 0; attempt < 2; attempt++) {
         DevBuf<rk_hit> hits;

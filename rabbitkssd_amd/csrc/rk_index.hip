@@ -68,18 +68,59 @@ __device__ inline uint32_t genome_of(const uint64_t *off, uint32_t n, uint64_t e
     return lo;
 }
 
+// covered[e] (self join, row pairs): genome 2p+1 shares this hash with genome 2p, i.e. its
+// predecessor in the posting list is its pair partner.  Walking the partner's slice then serves
+// both rows (the slice of 2p starts with 2p+1 and continues with exactly the slice of 2p+1), so the
+// pair kernel skips the covered slices of the odd row.
 __global__ void k_postings_selfrange(const uint32_t *sorted_e, const uint32_t *gidx,
                                      const uint32_t *upos, const uint64_t *off, uint32_t n_genomes,
-                                     uint64_t n, uint32_t *postings, uint2 *selfrange)
+                                     uint64_t n, uint32_t *postings, uint2 *selfrange, uint8_t *covered)
 {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t e = sorted_e[k];
-    postings[k] = genome_of(off, n_genomes, e);
+    const uint32_t me = genome_of(off, n_genomes, e);
+    postings[k] = me;
     const uint32_t g = gidx[k] - 1;
     // the sort is stable and source elements are genome-major, so positions k+1..end of
     // the group hold strictly later genomes (a sketch is a set: no repeated hash inside it)
     selfrange[e] = make_uint2((uint32_t)k + 1, upos[g + 1]);
+    covered[e] = (me & 1u) && k > upos[g] && genome_of(off, n_genomes, sorted_e[k - 1]) == me - 1;
+}
+
+// ---- self-join slices: drop the empty ones, put a row's covered slices behind the others ------
+__global__ void k_self_flags2(const uint2 *self, const uint8_t *covered, uint64_t n, uint32_t *f_open, uint32_t *f_cov)
+{
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const bool nonempty = self[e].y > self[e].x;
+    f_open[e] = nonempty && !covered[e];
+    f_cov[e] = nonempty && covered[e];
+}
+
+// r_open / r_cov: exclusive scans of the two flag arrays, with one extra element holding the totals
+__global__ void k_self_place(const uint2 *self, const uint8_t *covered, const uint32_t *r_open, const uint32_t *r_cov,
+                             const uint64_t *off, uint32_t n_genomes, uint64_t n, uint2 *out)
+{
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || self[e].y <= self[e].x) return;
+    const uint32_t g = genome_of(off, n_genomes, e);
+    const uint64_t e0 = off[g], e1 = off[g + 1];
+    const uint64_t row0 = (uint64_t)r_open[e0] + r_cov[e0];          // slices of earlier rows
+    const uint64_t n_open = r_open[e1] - r_open[e0];
+    const uint64_t at = covered[e] ? row0 + n_open + (r_cov[e] - r_cov[e0]) : row0 + (r_open[e] - r_open[e0]);
+    out[at] = self[e];
+}
+
+__global__ void k_self_off2(const uint64_t *off, const uint32_t *r_open, const uint32_t *r_cov, uint32_t n_genomes,
+                            uint64_t *self_off, uint64_t *self_split)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_genomes) return;
+    const uint64_t e0 = off[g];
+    const uint64_t row0 = (uint64_t)r_open[e0] + r_cov[e0];
+    self_off[g] = row0;
+    if (g < n_genomes) self_split[g] = row0 + (r_open[off[g + 1]] - r_open[e0]);
 }
 
 // ---- drop the empty "later genomes" slices (26 % of the elements at 10,000 genomes) ---------
@@ -259,6 +300,52 @@ int rk_compact_ranges(rk_ctx *ctx, const uint2 *ranges_dev, uint64_t n, const ui
     return RK_OK;
 }
 
+// self-join variant of rk_compact_ranges: also reorders every row (uncovered slices first) and
+// returns the split points; see k_postings_selfrange
+static int compact_self(rk_ctx *ctx, const uint2 *ranges_dev, const uint8_t *covered_dev, uint64_t n,
+                        const uint64_t *off_dev, uint32_t n_rows, uint2 **out_ranges_dev, uint64_t **out_off_dev,
+                        uint64_t **out_split_dev, uint64_t *n_out)
+{
+    *out_ranges_dev = nullptr;
+    *out_off_dev = nullptr;
+    *out_split_dev = nullptr;
+    *n_out = 0;
+    DevBuf<uint64_t> new_off, split;
+    RK_HIP(ctx, new_off.alloc((size_t)n_rows + 1));
+    RK_HIP(ctx, split.alloc((size_t)n_rows + 1));
+    DevBuf<uint2> compact;
+    DevBuf<uint32_t> f_open, f_cov, r_open, r_cov;
+    RK_HIP(ctx, f_open.alloc(n + 1));
+    RK_HIP(ctx, f_cov.alloc(n + 1));
+    RK_HIP(ctx, r_open.alloc(n + 1));
+    RK_HIP(ctx, r_cov.alloc(n + 1));
+    RK_HIP(ctx, hipMemset(f_open.p + n, 0, 4));
+    RK_HIP(ctx, hipMemset(f_cov.p + n, 0, 4));
+    if (n) hipLaunchKernelGGL(k_self_flags2, dim3(blocks_for(n)), dim3(kThreads), 0, 0, ranges_dev, covered_dev, n, f_open.p, f_cov.p);
+    size_t tb = 0;
+    RK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, f_open.p, r_open.p, 0u, n + 1, rocprim::plus<uint32_t>()));
+    DevBuf<char> tmp;
+    RK_HIP(ctx, tmp.alloc(tb));
+    RK_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb, f_open.p, r_open.p, 0u, n + 1, rocprim::plus<uint32_t>()));
+    RK_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb, f_cov.p, r_cov.p, 0u, n + 1, rocprim::plus<uint32_t>()));
+    uint32_t t_open = 0, t_cov = 0;
+    RK_HIP(ctx, hipMemcpy(&t_open, r_open.p + n, 4, hipMemcpyDeviceToHost));
+    RK_HIP(ctx, hipMemcpy(&t_cov, r_cov.p + n, 4, hipMemcpyDeviceToHost));
+    const uint64_t m = (uint64_t)t_open + t_cov;
+    RK_HIP(ctx, compact.alloc(m));
+    if (n) hipLaunchKernelGGL(k_self_place, dim3(blocks_for(n)), dim3(kThreads), 0, 0, ranges_dev, covered_dev, r_open.p,
+                              r_cov.p, off_dev, n_rows, n, compact.p);
+    hipLaunchKernelGGL(k_self_off2, dim3(blocks_for((uint64_t)n_rows + 1)), dim3(kThreads), 0, 0, off_dev, r_open.p,
+                       r_cov.p, n_rows, new_off.p, split.p);
+    RK_HIP(ctx, hipGetLastError());
+    RK_HIP(ctx, hipDeviceSynchronize());  // the temporaries die with this scope
+    *n_out = m;
+    *out_ranges_dev = compact.release();
+    *out_off_dev = new_off.release();
+    *out_split_dev = split.release();
+    return RK_OK;
+}
+
 int rk_resolve_ranges(rk_ctx *ctx, const rk_index *idx, const void *q_hashes_dev, uint64_t n,
                       uint2 *ranges_dev, hipStream_t stream)
 {
@@ -288,6 +375,7 @@ void rk_index_free(rk_index *idx)
     (void)hipFree(idx->d_sizes);
     (void)hipFree(idx->d_selfrange);
     (void)hipFree(idx->d_self_off);
+    (void)hipFree(idx->d_self_split);
     (void)hipFree(idx->d_src_off);
     delete idx;
 }
@@ -332,6 +420,8 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
 
     DevBuf<uint32_t> iota, keys_sorted, sorted_e, flags;
     DevBuf<uint64_t> keys_sorted64;
+    DevBuf<uint8_t> covered;
+    RK_HIP(ctx, covered.alloc(H + 1));
     RK_HIP(ctx, iota.alloc(H));
     RK_HIP(ctx, keys_sorted.alloc(H));
     if (idx->wide) RK_HIP(ctx, keys_sorted64.alloc(H));
@@ -381,15 +471,16 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             hipLaunchKernelGGL(k_scatter_heads<uint32_t>, dim3(blocks_for(H)), dim3(kThreads), 0, 0,
                                keys_sorted.p, gidx, H, idx->d_uhash, idx->d_upos, idx->U);
         hipLaunchKernelGGL(k_postings_selfrange, dim3(blocks_for(H)), dim3(kThreads), 0, 0, sorted_e.p,
-                           gidx, idx->d_upos, s->d_off, s->n, H, idx->d_postings, idx->d_selfrange);
+                           gidx, idx->d_upos, s->d_off, s->n, H, idx->d_postings, idx->d_selfrange, covered.p);
     } else {
         RK_HIP(ctx, hipMemset(idx->d_upos, 0, 8));
     }
     RK_HIP(ctx, hipGetLastError());
-    // compact away the empty slices (26 % of the elements at 10,000 genomes)
+    // compact away the empty slices (26 % of the elements at 10,000 genomes); covered slices go last in their row
     {
         uint2 *compact = nullptr;
-        int rcc = rk_compact_ranges(ctx, idx->d_selfrange, H, s->d_off, s->n, &compact, &idx->d_self_off, &idx->n_self, 0);
+        int rcc = compact_self(ctx, idx->d_selfrange, covered.p, H, s->d_off, s->n, &compact, &idx->d_self_off,
+                               &idx->d_self_split, &idx->n_self);
         if (rcc) return rcc;
         (void)hipFree(idx->d_selfrange);
         idx->d_selfrange = compact;
@@ -495,9 +586,9 @@ struct BlobHeader {
     uint64_t H, U, sum_sq, max_src_size, n_self;
     uint32_t n_ref, has_self;
     int32_t hash_bits, dir_bits, dir_shift, wide;
-    uint64_t off_postings, off_uhash, off_upos, off_dir, off_sizes, off_self, off_selfoff, off_src;
+    uint64_t off_postings, off_uhash, off_upos, off_dir, off_sizes, off_self, off_selfoff, off_src, off_split;
 };
-constexpr uint64_t kBlobMagic = 0x31584449444b5352ULL;  // "RSKDIDX1"
+constexpr uint64_t kBlobMagic = 0x32584449444b5352ULL;  // "RSKDIDX2"
 inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ULL; }
 
 void blob_layout(const rk_index *idx, BlobHeader *h)
@@ -525,6 +616,7 @@ void blob_layout(const rk_index *idx, BlobHeader *h)
         h->off_self = p;    p = al256(p + (idx->n_self + 1) * sizeof(uint2));
         h->off_selfoff = p; p = al256(p + ((uint64_t)idx->n_ref + 1) * 8);
         h->off_src = p;     p = al256(p + ((uint64_t)idx->n_ref + 1) * 8);
+        h->off_split = p;   p = al256(p + ((uint64_t)idx->n_ref + 1) * 8);
     }
     h->bytes = p;
 }
@@ -561,6 +653,7 @@ int rk_index_pack_dev(const rk_index *idx, void *blob_dev, uint64_t blob_cap, vo
         RK_HIP(ctx, hipMemcpyAsync(b + h.off_self, idx->d_selfrange, idx->n_self * sizeof(uint2), hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(b + h.off_selfoff, idx->d_self_off, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(b + h.off_src, idx->d_src_off, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
+        RK_HIP(ctx, hipMemcpyAsync(b + h.off_split, idx->d_self_split, (uint64_t)idx->n_ref * 8, hipMemcpyDeviceToDevice, st));
     }
     RK_HIP(ctx, hipStreamSynchronize(st));
     return RK_OK;
@@ -614,6 +707,8 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
         RK_HIP(ctx, hipMemcpyAsync(idx->d_selfrange, b + h.off_self, idx->n_self * sizeof(uint2), hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(idx->d_self_off, b + h.off_selfoff, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(idx->d_src_off, b + h.off_src, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
+        RK_HIP(ctx, hipMalloc((void **)&idx->d_self_split, ((size_t)idx->n_ref + 1) * 8));
+        RK_HIP(ctx, hipMemcpyAsync(idx->d_self_split, b + h.off_split, (uint64_t)idx->n_ref * 8, hipMemcpyDeviceToDevice, st));
     }
     RK_HIP(ctx, hipStreamSynchronize(st));
     guard.p = nullptr;

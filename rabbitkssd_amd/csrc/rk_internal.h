@@ -91,6 +91,8 @@ struct rk_index {
     uint2 *d_selfrange = nullptr;    // uint2[n_self]: per source element with a non-empty slice,
                                      // the postings of LATER genomes (rows back to back)
     uint64_t *d_self_off = nullptr;  // u64[n_ref+1] offsets of each genome's slices in d_selfrange
+    uint64_t *d_self_split = nullptr; // u64[n_ref]: a row's slices from here on are "covered" by its pair partner
+                                      // (genome 2p+1 shares the hash with 2p): the pair kernel skips them
     uint64_t n_self = 0;
     uint64_t *d_src_off = nullptr;   // u64[n_ref+1] offsets of the source sketches (built only)
 };

@@ -1,21 +1,29 @@
 """Multi-GPU plumbing of the distance path: query rows are independent, so the N x N (or
-Q x R) matrix is sharded by interleaved rows (row r -> rank r mod world), the reference
-index is sent to every rank with ONE broadcast and per-rank hits are only concatenated --
-there is no reduction.  Backend-agnostic: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the
-CPU tests."""
+Q x R) matrix is sharded by rows, block-cyclically: blocks of ROW_BLOCK consecutive rows are
+dealt round-robin to the ranks (block b -> rank b mod world).  Neighbouring genomes of a
+sorted collection are close relatives that share posting lists, so a block keeps them on one
+GPU (and lets the kernel walk them in pairs), while the round-robin still balances the
+triangle.  The reference index is sent to every rank with ONE broadcast and per-rank hits are
+only concatenated -- there is no reduction.  Backend-agnostic: "nccl" (= RCCL over xGMI) on
+GPUs, "gloo" in the CPU tests."""
 import math
 
 import numpy as np
 
 
-def rank_rows(n_rows, rank, world):
-    """row_first/row_step of this rank (what rk_dist_opts takes) and the row indices."""
-    return rank, world, np.arange(rank, n_rows, world, dtype=np.int64)
+ROW_BLOCK = 16  # rk_dist_opts.row_block used by the multi-GPU callers
 
 
-def rank_pairs(n_genomes, rank, world):
+def rank_rows(n_rows, rank, world, row_block=ROW_BLOCK):
+    """row_first/row_step of this rank (what rk_dist_opts takes, together with row_block)
+    and the row indices it owns."""
+    rows = np.arange(n_rows, dtype=np.int64)
+    return rank, world, rows[(rows // row_block) % world == rank]
+
+
+def rank_pairs(n_genomes, rank, world, row_block=ROW_BLOCK):
     """all-vs-all pairs (j > i) whose row i belongs to this rank."""
-    rows = np.arange(rank, n_genomes, world, dtype=np.int64)
+    rows = rank_rows(n_genomes, rank, world, row_block)[2]
     return int(((n_genomes - 1) - rows).sum())
 
 

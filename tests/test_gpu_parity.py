@@ -138,6 +138,37 @@ def test_crowded_hash_space_long_lists_and_full_rows(ctx, n, m, bits):
     assert_hits_equal(mine, want_hits)
 
 
+@pytest.mark.parametrize("n,block,world", [(500, 2, 4), (501, 16, 3), (37, 16, 8), (1000, 6, 5)])
+def test_block_cyclic_row_sharding_union_equals_full(ctx, n, block, world):
+    # blocks of `block` rows dealt round-robin to `world` shards; even blocks run the pair kernel
+    names, h, off = synth.clade_sketches(n, 100, 22, seed=19)
+    idx = ctx.index_build(ctx.sketches_from_host(h, off), 22)
+    for D in (0.08, 1.5):  # sparse and dense epilogue
+        full, _ = ctx.dist_rows(idx, None, 1, 0, 20, D)
+        parts = [ctx.dist_rows(idx, None, 1, 0, 20, D, row_first=r, row_step=world, row_block=block)[0] for r in range(world)]
+        for r, p in enumerate(parts):
+            assert np.all((p["row"] // block) % world == r)
+        merged = np.concatenate(parts)
+        merged = merged[np.lexsort((merged["col"], merged["row"]))]
+        assert merged.tobytes() == full.tobytes()
+
+
+def test_pair_kernel_equals_single_row_kernel(ctx, monkeypatch):
+    # the same self join through the pair kernel (default) and the single-row kernel (RK_DIST_PAIR=2)
+    names, h, off = synth.clade_sketches(777, 300, 24, seed=23)
+    idx = ctx.index_build(ctx.sketches_from_host(h, off), 24)
+    postings, counts = ok.index_build32(h, off, 24)
+    sizes = np.diff(off).astype(np.uint32)
+    for metric, D in ((0, 0.05), (1, 0.02), (0, 0.5)):
+        want, _ = ok.index_dist32(counts, 24, postings, sizes, h, off, 1, metric, 20, D, threads=4)
+        pair, _ = ctx.dist_rows(idx, None, 1, metric, 20, D)
+        monkeypatch.setenv("RK_DIST_PAIR", "2")
+        single, _ = ctx.dist_rows(idx, None, 1, metric, 20, D)
+        monkeypatch.delenv("RK_DIST_PAIR")
+        assert_hits_equal(pair, want)
+        assert_hits_equal(single, want)
+
+
 def test_row_sharding_union_equals_full(ctx):
     names, h, off = synth.clade_sketches(500, 100, 22, seed=9)
     idx = ctx.index_build(ctx.sketches_from_host(h, off), 22)

@@ -49,7 +49,7 @@ def _worker(rank, port, outdir):
         assert len(sizes) == n_sizes == n
         first, step, rows = shard.rank_rows(n, rank, WORLD)
         hits, _ = ok.index_dist32(counts, BITS, postings, sizes, h, off, 1, 0, 20, 0.1)
-        mine = hits[hits["row"] % step == first]          # this rank's rows only
+        mine = hits[(hits["row"] // shard.ROW_BLOCK) % step == first]          # this rank's rows only
         assert set(np.unique(mine["row"])).issubset(set(rows.tolist()))
         merged = shard.gather_hits(mine, dist, 0)
         pairs = torch.tensor([shard.rank_pairs(n, rank, WORLD)], dtype=torch.int64)
@@ -77,6 +77,7 @@ def test_partition_arithmetic():
             assert sum(shard.rank_pairs(n, r, world) for r in range(world)) == n * (n - 1) // 2
     assert shard.weak_scaling_genomes(10000, 1) == 10000
     assert shard.weak_scaling_genomes(10000, 4) == 20000
-    # interleaving keeps the triangle balanced: max/min pairs per rank within 0.2 % at 10k x 8
+    # dealing blocks of 16 rows round-robin keeps the triangle balanced: max/min pairs per rank
+    # within 3 % at 10k x 8
     p = [shard.rank_pairs(10000, r, 8) for r in range(8)]
-    assert max(p) / min(p) < 1.002
+    assert max(p) / min(p) < 1.03

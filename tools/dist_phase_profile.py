@@ -52,8 +52,8 @@ def run(n=10000, steps=20):
     ev1.record()
     torch.cuda.synchronize()
     import numpy as np
-    raw = np.zeros((20480, 16), dtype=np.uint64)
-    L.rk_debug_dist_prof_raw(raw.ctypes.data_as(C.c_void_p), C.c_ulonglong(20480))
+    raw = np.zeros((65536, 16), dtype=np.uint64)
+    L.rk_debug_dist_prof_raw(raw.ctypes.data_as(C.c_void_p), C.c_ulonglong(65536))
     L.rk_debug_dist_prof(buf, 1)
     live = raw[raw[:, 13] > 0]
     t0, t1 = live[:, 14].astype(np.int64), live[:, 15].astype(np.int64)   # last launch, 100 MHz wall clock

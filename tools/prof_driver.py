@@ -37,7 +37,7 @@ def sketch(n_genomes=128, length=5_000_000, steps=3):
         print("sketch pass %.3f ms, %d windows, %d hashes" % ((time.time() - t0) * 1e3, sk.windows, sk.total))
 
 
-def dist(n_genomes=10000, steps=5, row_step=1):
+def dist(n_genomes=10000, steps=5, row_step=1, row_block=0):
     ctx = capi.Context(0)
     names, hashes, off = synth.clade_sketches(n_genomes, 1220, 28)
     index = ctx.index_build(ctx.sketches_from_host(hashes, off), 28)
@@ -47,10 +47,10 @@ def dist(n_genomes=10000, steps=5, row_step=1):
     t0 = time.time()
     for i in range(steps):
         ctx.dist_rows_dev(index, 1, 0, 20, 0.05, hits.data_ptr(), 1 << 20, counters.data_ptr() + 8 * i,
-                          row_first=0, row_step=row_step)
+                          row_first=0, row_step=row_step, row_block=row_block)
     torch.cuda.synchronize()
-    print("dist %.3f ms/step, hits %d (row_step %d)" % ((time.time() - t0) * 1e3 / steps, int(counters[0].item()),
-                                                        row_step))
+    print("dist %.3f ms/step, hits %d (row_step %d, row_block %d)" % ((time.time() - t0) * 1e3 / steps,
+                                                                      int(counters[0].item()), row_step, row_block))
 
 
 def dist_rq(n_ref=100000, n_query=1000, steps=3):
