@@ -36,6 +36,8 @@ struct DistArgs {
     uint32_t n_query, n_ref;
     uint32_t row_first, row_step, row_block, units_per_block, n_units;
     uint32_t tile_cols, cnt_words, pair_stride, units_per_wg, runs_per_chunk;
+    int persist;                 // 1: as many workgroups as the chip holds, each walks its share of the units
+    uint32_t units_per_xcd, units_per_chunk;
     uint32_t cand_cap, stage_hits;  // LDS carve-up (entries)
     int triangle, metric, kmer_size, dense_mode;
     double max_dist;
@@ -172,14 +174,23 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
 
-    // blockIdx.x -> run of unit slots.  Workgroups are dealt round-robin over the 8 XCDs, so
-    // blocks b, b+8, ... share an L2: consecutive runs of one XCD are adjacent rows, while
-    // heavy (early) rows stay spread over all XCDs.
+    // Which units this workgroup processes.
+    // One run per workgroup (a.persist == 0): blockIdx.x -> a run of units_per_wg consecutive unit
+    // slots.  Workgroups are dealt round-robin over the 8 XCDs, so blocks b, b+8, ... share an L2:
+    // consecutive runs of one XCD are adjacent rows, while heavy (early) rows stay spread over
+    // all XCDs.
+    // Persistent (a.persist == 1, single tile): as many workgroups as the chip holds; each XCD owns
+    // every 8th chunk of units_per_chunk units as a queue and its workgroups take the queue
+    // positions s8, s8 + G/8, s8 + 2G/8, ... (G = grid size): neighbouring units still run at the
+    // same time on the same XCD, and the slices of the next unit are always prefetched.  (Pulling
+    // the positions with a fetch-add per unit instead was measured slower, 0.134 vs 0.122 ms: the
+    // device-scope atomics cost more than the better balance at the end buys.)
     const uint32_t xcd = blockIdx.x & 7, s8 = blockIdx.x >> 3;
     const uint32_t rpc = a.runs_per_chunk;
     const uint32_t run = ((s8 / rpc) * 8 + xcd) * rpc + s8 % rpc;
+    const bool dynamic = a.persist != 0;
     const uint32_t slot0 = run * a.units_per_wg;
-    if (slot0 >= a.n_units) return;
+    if (!dynamic && slot0 >= a.n_units) return;
     const uint32_t col0 = blockIdx.y * a.tile_cols;
     const uint32_t col1 = min(a.n_ref, col0 + a.tile_cols);
     const uint32_t ncol = col1 - col0;
@@ -189,7 +200,8 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     const bool tri_filter = a.triangle && !a.common_dense;
     constexpr uint32_t kPerWord = U16 ? 2 : 1;
     const uint4 *c4 = reinterpret_cast<const uint4 *>(cnt);
-    const uint32_t slot_end = min(a.n_units, slot0 + a.units_per_wg);
+    const uint32_t slot_end = min(a.n_units, slot0 + a.units_per_wg);  // static runs
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
     const uint32_t row_b_cell = a.pair_stride;  // first cell of the second row of a pair
 
     // unit slot -> its first row.  Rows are dealt to the ranks in blocks of row_block rows
@@ -205,15 +217,18 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     auto skipped = [&](uint32_t row) {
         return row == 0xFFFFFFFFu || (a.triangle && col1 <= row + 1 && !a.common_dense);
     };
-    // first slot >= s whose unit has work in this tile
-    auto next_live = [&](uint32_t s, uint32_t &row) {
-        while (s < slot_end) {
-            row = unit_row(s);
-            if (!skipped(row)) break;
-            s++;
-        }
-        return s;
+    // the unit's first row, or kNone when the slot is past the end / has no work in this tile
+    auto live_row = [&](uint32_t s) -> uint32_t {
+        if (s == kNone || s >= a.n_units) return kNone;
+        const uint32_t r = unit_row(s);
+        return skipped(r) ? kNone : r;
     };
+    // persistent mode: queue position q of XCD x -> unit slot
+    auto queue_slot = [&](uint32_t x, uint32_t q) -> uint32_t {
+        const uint32_t upc = a.units_per_chunk;
+        return ((q / upc) * 8 + x) * upc + q % upc;
+    };
+    auto queue_unit = [&](uint32_t q) -> uint32_t { return q < a.units_per_xcd ? queue_slot(xcd, q) : kNone; };
     auto load_slice = [&](uint64_t e, uint64_t e1) -> uint2 {
         return e < e1 ? a.ranges[e] : make_uint2(0, 0);
     };
@@ -402,21 +417,38 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
             u.e1 = a.range_split[row_a + 1];  // eb == range_off[row_b]
         }
     };
-    uint32_t row = 0;
-    uint32_t slot = next_live(slot0, row);
-    if (slot >= slot_end) return;  // nothing to do in this tile (uniform)
+    // pipeline of unit slots: s_cur is processed, s_nxt is known (its slices get prefetched), the
+    // one after that is being pulled
+    uint32_t s_cur, s_nxt;
+    const uint32_t q_step = gridDim.x >> 3;  // persistent: workgroups of this XCD
+    uint32_t q_next = s8 + 2 * q_step;       // persistent: queue position of the unit after s_nxt
+    if (dynamic) {
+        s_cur = queue_unit(s8);
+        s_nxt = queue_unit(s8 + q_step);
+    } else {
+        s_cur = slot0;
+        s_nxt = slot0 + 1 < slot_end ? slot0 + 1 : kNone;
+    }
+    uint32_t row = live_row(s_cur);
     Unit cur;
-    open_unit(row, cur);
+    cur.e0 = cur.eb = cur.e1 = 0;
+    cur.row_b = kNone;
+    if (row != kNone) open_unit(row, cur);
     uint2 pre = load_slice(cur.e0 + tid, cur.e1);
     uint32_t parity = 0;
 
-    while (slot < slot_end) {
+    while (s_cur != kNone) {
+        uint32_t s_nn = kNone;  // the unit after next
+        if (dynamic) {
+            s_nn = queue_unit(q_next);
+            q_next += q_step;
+        } else if (s_nxt != kNone && s_nxt + 1 < slot_end) s_nn = s_nxt + 1;
         // look ahead: the next unit's slice range is fetched while this unit is processed
-        uint32_t nrow = 0;
-        const uint32_t nslot = next_live(slot + 1, nrow);
-        Unit nxt = cur;
-        nxt.e0 = nxt.e1 = 0;
-        if (nslot < slot_end) open_unit(nrow, nxt);
+        const uint32_t nrow = live_row(s_nxt);
+        Unit nxt;
+        nxt.e0 = nxt.eb = nxt.e1 = 0;
+        nxt.row_b = kNone;
+        if (nrow != kNone) open_unit(nrow, nxt);
 
         uint4 *z4 = reinterpret_cast<uint4 *>(cnt);  // memset row (src/dist.cpp:179)
         for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
@@ -533,9 +565,10 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         if (nb == 0) pre = load_slice(nxt.e0 + tid, nxt.e1);  // a unit without slices still hands over the prefetch
         __syncthreads();  // all scatters of the unit done
         PROF_MARK(1);
-        epilogue(row, row_b, s_cells[parity]);
+        if (row != kNone) epilogue(row, row_b, s_cells[parity]);
         parity ^= 1;
-        slot = nslot;
+        s_cur = s_nxt;
+        s_nxt = s_nn;
         row = nrow;
         cur = nxt;
     }
@@ -566,6 +599,7 @@ struct Plan {
     uint32_t n_units, tile_cols, n_tiles, cnt_words, row_words;
     uint32_t cand_cap, stage_hits, units_per_wg, threads;
     uint32_t row_first, row_step, row_block, units_per_block;
+    bool persist;
     size_t lds_bytes;
     int dense_mode, mode;
     bool u16;
@@ -581,7 +615,10 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // counter row in LDS; tile the reference range when it does not fit
     p->u16 = max_query_size < 65536;
     p->cand_cap = (envu("RK_DIST_CAND_CAP", kCandCapDefault) + 1) & ~1u;
-    p->stage_hits = envu("RK_DIST_STAGE_HITS", kStageHitsDefault);
+    // one tile: persistent workgroups that pull units from per-XCD queues; they live long, so they
+    // stage more hits before the one flush at their end
+    p->persist = idx->n_ref && (uint64_t)idx->n_ref * (p->u16 ? 2 : 4) + 8192 <= ctx->max_lds && envu("RK_DIST_PERSIST", 1) != 2;
+    p->stage_hits = envu("RK_DIST_STAGE_HITS", p->persist ? 4 * kStageHitsDefault : kStageHitsDefault);
     const size_t fixed = (size_t)p->cand_cap * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
     const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - fixed;
     const uint32_t max_cols = (uint32_t)(p->u16 ? lds_cap / 2 : lds_cap / 4) & ~63u;
@@ -614,7 +651,8 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     p->n_units = (uint32_t)std::min<uint64_t>(my_blocks * p->units_per_block, 0xFFFFFFF0u);
     p->cnt_words = p->row_words * unit_rows;
     p->lds_bytes = (size_t)p->cnt_words * 4 + fixed;
-    p->units_per_wg = envu("RK_DIST_ROWS", p->mode == kSelfPair ? 1 : 2);
+    p->persist = p->persist && p->n_tiles == 1;
+    p->units_per_wg = p->persist ? 1 : envu("RK_DIST_ROWS", p->mode == kSelfPair ? 1 : 2);
     // workgroup size by row size: 7 x 256 threads fit up to ~22 KiB rows; bigger rows leave room for
     // fewer workgroups, which then need more waves each
     p->threads = p->lds_bytes <= 24 * 1024 ? 256 : (p->lds_bytes <= 64 * 1024 ? 512 : 1024);
@@ -683,7 +721,19 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
                                         (int)p.lds_bytes));
     const uint32_t runs = (p.n_units + a.units_per_wg - 1) / a.units_per_wg;
     const uint32_t per = 8 * a.runs_per_chunk;  // grid padded to whole XCD chunks
-    const uint32_t gx = (runs + per - 1) / per * per;
+    uint32_t gx = (runs + per - 1) / per * per;
+    a.persist = 0;
+    a.units_per_chunk = a.runs_per_chunk;  // units_per_wg == 1 in persistent mode
+    a.units_per_xcd = gx / 8;
+    if (p.persist) {
+        int per_cu = 0;
+        RK_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, (int)p.threads, p.lds_bytes));
+        const uint32_t resident = ((uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, ctx->num_cu) + 7) / 8 * 8;
+        if (gx > resident) {  // otherwise every unit gets its own workgroup anyway
+            a.persist = 1;
+            gx = resident;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(gx, p.n_tiles), dim3(p.threads), p.lds_bytes, stream, a);
     RK_HIP(ctx, hipGetLastError());
     return RK_OK;
