@@ -88,6 +88,26 @@ def test_config3_alldist_50k_properties_and_exact(ctx):
     part, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=3, row_step=8)
     sel = mine[mine["row"] % 8 == 3]
     assert part.tobytes() == sel.tobytes()
+    # the block-cyclic shard the multi-GPU callers use (blocks of 16 rows)
+    part, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=5, row_step=8, row_block=16)
+    sel = mine[(mine["row"] // 16) % 8 == 5]
+    assert part.tobytes() == sel.tobytes()
+
+
+def test_self_join_with_tiled_columns_90k(ctx):
+    """more genomes than one LDS row holds (> ~78,000 columns): the self join runs tile by tile with
+    range-checked postings; exact vs the oracle"""
+    names, h, off = synth.clade_sketches(90000, 12, 22, seed=77)
+    idx = ctx.index_build(ctx.sketches_from_host(h, off), 22)
+    postings, counts = ok.index_build32(h, off, 22)
+    sizes = np.diff(off).astype(np.uint32)
+    want, _ = ok.index_dist32(counts, 22, postings, sizes, h, off, 1, 0, 20, 0.05, threads=CORES)
+    assert len(want) > 100000
+    mine, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05)
+    check_hits(mine, want)
+    part, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=1, row_step=3, row_block=16)
+    sel = mine[(mine["row"] // 16) % 3 == 1]
+    assert part.tobytes() == sel.tobytes()
 
 
 def test_config4_ref_vs_query_100k(ctx):
