@@ -3,6 +3,9 @@
 // Written from the format description; citations are file:line into
 // the reference tree.  Host code only: no arithmetic of the hot path lives here.
 #pragma once
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -12,6 +15,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace rkhost {
@@ -231,11 +235,31 @@ inline bool read_index(const std::string &dict, const std::string &index, std::v
 //    rk_sketch_packed_dev expects (records separated by one 0x00 byte), which is how the
 //    parser threads of the sketch pipeline fill the page-locked staging buffer without an
 //    intermediate copy.  The FASTQ quality gate (src/sketch.cpp:785) is applied in place.
+// growable byte buffer that does not zero-fill (a 3 GB std::vector costs a 3 GB memset)
+struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+    uint8_t *data() { return p; }
+    size_t size() const { return cap; }
+    void resize(size_t n)
+    {
+        if (n <= cap) return;
+        uint8_t *q = (uint8_t *)realloc(p, n);
+        if (!q) { fprintf(stderr, "ERROR: out of memory reading a file (%zu bytes)\n", n); exit(1); }
+        p = q;
+        cap = n;
+    }
+};
+
 class RecordReader {
   public:
     // whole file into buf (plain or gzip'd, src/sketch.cpp:462 reads both through gzopen);
     // buf is caller-owned so that a parser thread reuses one allocation for all its files
-    static bool slurp(const std::string &path, std::vector<uint8_t> &buf, size_t &n)
+    template <class Buf> static bool slurp(const std::string &path, Buf &buf, size_t &n)
     {
         n = 0;
         FILE *f = fopen(path.c_str(), "rb");
@@ -302,6 +326,110 @@ class RecordReader {
         r.overflow = sink.overflow;
         r.bytes = sink.n_rec ? sink.w - 1 : 0;
         return r;
+    }
+
+    // Big plain FASTA files (one 3 Gb genome is a single list entry): the buffer is cut into
+    // `threads` pieces at line starts -- kseq looks for '>' only at the start of a line
+    // (src/kseq.h:192-196), so a piece needs no context -- each piece counts its packed bytes, a
+    // prefix sum places it, and the pieces are copied concurrently.  Returns false, leaving dst
+    // undefined, for inputs that need the serial parser: FASTQ ('@' / '+' lines), '\r' line ends,
+    // small buffers.
+    static bool parse_packed_parallel(const uint8_t *b, size_t n, uint8_t *dst, size_t cap, int threads, Packed &out,
+                                      size_t min_bytes = 32u << 20)
+    {
+        if (threads < 2 || n < min_bytes) return false;
+        size_t start = 0;
+        while (start < n && b[start] != '>' && b[start] != '@') start++;  // :180-184
+        if (start >= n || b[start] == '@') return false;
+        const size_t T = (size_t)threads;
+        std::vector<size_t> cut(T + 1);
+        cut[0] = start;
+        cut[T] = n;
+        for (size_t i = 1; i < T; i++) {
+            size_t p = start + (n - start) / T * i;
+            if (p < cut[i - 1]) p = cut[i - 1];
+            const uint8_t *e = line_end(b + p, b + n);
+            cut[i] = e < b + n ? (size_t)(e - b) + 1 : n;
+        }
+        struct Piece { uint64_t bytes = 0, headers = 0; bool bad = false; };
+        std::vector<Piece> pc(T);
+        // what a piece contributes: every header line starts a record (a separator, except for the
+        // file's first), every other non-empty line its characters
+        auto walk = [&](size_t i, uint8_t *to) {
+            Piece &q = pc[i];
+            size_t pos = cut[i];
+            const size_t end = cut[i + 1];
+            uint8_t *w = to;
+            uint64_t bytes = 0, headers = 0;
+            while (pos < end) {
+                const uint8_t c = b[pos];
+                const size_t e = (size_t)(line_end(b + pos, b + end) - b);
+                if (c == '>') {
+                    if (pos != start) { if (w) *w++ = 0; bytes++; }
+                    headers++;
+                } else if (c == '+' || c == '@') {
+                    q.bad = true;
+                    return;
+                } else if (e > pos) {
+                    if (b[e - 1] == '\r') { q.bad = true; return; }
+                    if (w) { memcpy(w, b + pos, e - pos); w += e - pos; }
+                    bytes += e - pos;
+                }
+                pos = e + 1;
+            }
+            q.bytes = bytes;
+            q.headers = headers;
+        };
+        auto run = [&](uint8_t *const *targets) {
+            std::vector<std::thread> pool;
+            for (size_t i = 0; i < T; i++) pool.emplace_back([&, i]() { walk(i, targets ? targets[i] : nullptr); });
+            for (auto &th : pool) th.join();
+        };
+        run(nullptr);
+        uint64_t total = 0, headers = 0;
+        std::vector<uint8_t *> targets(T);
+        for (size_t i = 0; i < T; i++) {
+            if (pc[i].bad) return false;
+            targets[i] = dst + total;
+            total += pc[i].bytes;
+            headers += pc[i].headers;
+        }
+        if (total > cap) { out = Packed(); out.overflow = true; return true; }
+        run(targets.data());
+        out = Packed();
+        out.bytes = total;
+        out.n_rec = headers;
+        return true;
+    }
+
+    // whole plain file with `threads` concurrent preads (page-cache copies scale with threads)
+    template <class Buf> static bool slurp_parallel(const std::string &path, Buf &buf, size_t &n, int threads)
+    {
+        n = 0;
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) || st.st_size <= 0) { close(fd); return st.st_size == 0; }
+        const size_t sz = (size_t)st.st_size;
+        if (buf.size() < sz) buf.resize(sz);
+        const size_t T = (size_t)std::max(1, threads);
+        std::vector<std::thread> pool;
+        std::vector<int> ok(T, 1);
+        for (size_t i = 0; i < T; i++)
+            pool.emplace_back([&, i]() {
+                size_t pos = sz / T * i;
+                const size_t end = i + 1 == T ? sz : sz / T * (i + 1);
+                while (pos < end) {
+                    const ssize_t r = pread(fd, buf.data() + pos, end - pos, (off_t)pos);
+                    if (r <= 0) { ok[i] = 0; break; }
+                    pos += (size_t)r;
+                }
+            });
+        for (auto &th : pool) th.join();
+        close(fd);
+        for (size_t i = 0; i < T; i++) if (!ok[i]) return false;
+        n = sz;
+        return true;
     }
 
   private:

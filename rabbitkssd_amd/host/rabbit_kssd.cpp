@@ -137,6 +137,7 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
             shuf.subk, shuf.drlevel);  // src/common.cpp:37
     rk_filter *flt = nullptr;
     gpu.check(rk_filter_create(gpu.ctx, &P, shuf.table.data(), &flt), "rk_filter_create");
+    if (getenv("RK_TIMING")) fprintf(stderr, "[timing] rk_filter_create: %.3f s\n", get_sec() - t0);
 
     const vector<string> files = read_list(list);
     cerr << "the total fileNumber is: " << files.size() << endl;
@@ -161,6 +162,7 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
     struct Batch {
         size_t first = 0, last = 0;  // files [first, last)
         uint64_t bytes = 0;          // staging bytes used
+        bool pageable = false;       // one oversized file: staged in ordinary memory
         vector<Slot> slots;
     };
     // upper bound of a file's packed size: a plain file cannot expand; a .gz member stores its
@@ -190,14 +192,27 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
     }
     // staging buffers: a quarter of the input each (so that uploads and kernels overlap the
     // parsing of the next batch), between 64 MiB and 1 GiB, never below the largest file
+    // A file bigger than the staging buffer (a 3 Gb genome) gets a batch of its own and is parsed into
+    // ordinary memory: page-locking and releasing 3 GB costs 0.9 s, the slower upload 0.2 s.
     uint64_t stage_bytes = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(64ull << 20, total_bound / 4));
-    stage_bytes = std::max(stage_bytes, max_bound);
     stage_bytes = (stage_bytes + 1023) & ~1023ULL;
+    const uint64_t dev_bytes = std::max(stage_bytes, max_bound);
     vector<Batch> batches;
     for (size_t i = 0; i < files.size();) {
         Batch bt;
         bt.first = i;
         uint64_t pos = 0;
+        if (bound[i] > stage_bytes) {  // oversized: alone, pageable staging
+            Slot sl;
+            sl.cap = bound[i];
+            bt.slots.push_back(sl);
+            bt.last = i + 1;
+            bt.bytes = bound[i];
+            bt.pageable = true;
+            batches.push_back(std::move(bt));
+            i++;
+            continue;
+        }
         while (i < files.size() && pos + bound[i] <= stage_bytes) {
             Slot sl;
             sl.off = pos;
@@ -211,16 +226,22 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
         batches.push_back(std::move(bt));
     }
 
+    const bool timing = getenv("RK_TIMING") != nullptr;
+    const double t_alloc = get_sec();
     const int n_buf = batches.size() > 1 ? 2 : 1;
     uint8_t *stage[2] = {nullptr, nullptr};
     void *dev[2] = {nullptr, nullptr};
     void *stream = nullptr;
     gpu.check(rk_stream_create(gpu.ctx, &stream), "rk_stream_create");
+    bool need_pinned = false;
+    for (const Batch &bt : batches) need_pinned |= !bt.pageable;
     for (int k = 0; k < n_buf; k++) {
-        gpu.check(rk_pinned_alloc(gpu.ctx, stage_bytes, (void **)&stage[k]), "rk_pinned_alloc");
-        gpu.check(rk_dev_alloc(gpu.ctx, stage_bytes, &dev[k]), "rk_dev_alloc");
+        if (need_pinned) gpu.check(rk_pinned_alloc(gpu.ctx, stage_bytes, (void **)&stage[k]), "rk_pinned_alloc");
+        gpu.check(rk_dev_alloc(gpu.ctx, dev_bytes, &dev[k]), "rk_dev_alloc");
     }
 
+    if (timing) fprintf(stderr, "[timing] %d staging buffer(s) of %.1f MB pinned + device: %.3f s\n", n_buf, stage_bytes / 1e6, get_sec() - t_alloc);
+    RawBuf big_stage;  // pageable staging of an oversized file
     // hand-over of filled staging buffers to the GPU thread
     std::mutex mu;
     std::condition_variable cv;
@@ -272,10 +293,13 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
                 any_overflow |= bt.slots[i].overflow;
             }
             rk_sketches *sk = nullptr;
-            gpu.check(rk_upload_async(gpu.ctx, dev[bi], stage[bi], bt.bytes, stream), "rk_upload_async");
+            const double t_gpu = get_sec();
+            gpu.check(rk_upload_async(gpu.ctx, dev[bi], bt.pageable ? big_stage.data() : stage[bi], bt.bytes, stream),
+                      "rk_upload_async");
             gpu.check(rk_sketch_packed_dev_ex(gpu.ctx, flt, (const uint8_t *)dev[bi], bt.bytes, gbeg.data(), gend.data(),
                                               nb, (uint32_t)std::max(1, fq.least_num), stream, &sk),
                       "rk_sketch_packed_dev_ex");
+            if (timing) fprintf(stderr, "[timing] batch %zu: upload + sketch of %.1f MB: %.3f s\n", k, bt.bytes / 1e6, get_sec() - t_gpu);
             {   // the call above synchronised the stream: the staging buffer can be refilled
                 std::lock_guard<std::mutex> lk(mu);
                 consumed = k + 1;
@@ -314,23 +338,35 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
             cv.wait(lk, [&] { return k < (size_t)n_buf || consumed + (size_t)n_buf > k; });
         }
         Batch &bt = batches[k];
-        uint8_t *base = stage[k % (size_t)n_buf];
+        if (bt.pageable) {  // its own buffer; the previous oversized batch must be uploaded first
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return consumed == k; });
+            big_stage.resize(bt.bytes);
+        }
+        uint8_t *base = bt.pageable ? big_stage.data() : stage[k % (size_t)n_buf];
         const size_t nb = bt.last - bt.first;
+        const double t_parse = get_sec();
         std::atomic<size_t> next_file{0};
         std::atomic<int> failed{-1};
         const int nt = std::max(1, std::min<int>(threads, (int)nb));
         std::vector<std::thread> pool;
         for (int t = 0; t < nt; t++)
             pool.emplace_back([&]() {
-                vector<uint8_t> buf;  // one allocation per thread, reused for all its files
+                RawBuf buf;  // one allocation per thread, reused for all its files
                 for (;;) {
                     const size_t i = next_file.fetch_add(1);
                     if (i >= nb) break;
                     Slot &sl = bt.slots[i];
                     size_t n = 0;
-                    if (!RecordReader::slurp(files[bt.first + i], buf, n)) { failed = (int)i; continue; }
-                    const RecordReader::Packed pk =
-                        RecordReader::parse_packed(buf.data(), n, base + sl.off, sl.cap, fq.fastq ? fq.least_qual : 0);
+                    // a big plain file in a batch with idle parser threads: read and parse it in parallel
+                    const int spare = std::max(1, threads / nt);
+                    const bool big = spare > 1 && sl.cap >= (64u << 20) && !ends_with(files[bt.first + i], ".gz");
+                    if (!(big ? RecordReader::slurp_parallel(files[bt.first + i], buf, n, spare)
+                              : RecordReader::slurp(files[bt.first + i], buf, n))) { failed = (int)i; continue; }
+                    RecordReader::Packed pk;
+                    if (!(big && !fq.fastq &&
+                          RecordReader::parse_packed_parallel(buf.data(), n, base + sl.off, sl.cap, spare, pk)))
+                        pk = RecordReader::parse_packed(buf.data(), n, base + sl.off, sl.cap, fq.fastq ? fq.least_qual : 0);
                     sl.overflow = pk.overflow;
                     sl.len = pk.overflow ? 0 : pk.bytes;
                     // zero-fill up to the next multiple of 1024 (the kernel reads whole 1 KiB lines)
@@ -339,6 +375,7 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
                 }
             });
         for (auto &th : pool) th.join();
+        if (timing) fprintf(stderr, "[timing] batch %zu: read + parse of %zu file(s) on %d thread(s): %.3f s\n", k, nb, nt, get_sec() - t_parse);
         if (failed >= 0) die("cannot open the genome file: %s", files[bt.first + (size_t)failed].c_str());
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -347,11 +384,13 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
         cv.notify_all();
     }
     gpu_thread.join();
+    const double t_free = get_sec();
     for (int k = 0; k < n_buf; k++) {
         rk_pinned_free(stage[k]);
         rk_dev_free(dev[k]);
     }
     rk_stream_destroy(stream);
+    if (timing) fprintf(stderr, "[timing] releasing the staging buffers: %.3f s\n", get_sec() - t_free);
     rk_filter_free(flt);
 
     string out_path = out_path_in;
@@ -837,6 +876,15 @@ static int cmd_parse(int argc, char **argv)
             if (pk.overflow || pk.n_rec != off.size() - 1 || pk.bytes != want.size() ||
                 memcmp(want.data(), packed.data(), want.size()) != 0)
                 die("packed parse differs from the vector parse for %s", argv[i]);
+            // the parallel parser either declines or agrees
+            for (int threads = 2; threads <= 5; threads += 3) {
+                RecordReader::Packed pp;
+                std::fill(packed.begin(), packed.end(), 0xEE);
+                if (RecordReader::parse_packed_parallel(buf.data(), n, packed.data(), n + 1, threads, pp, 0) &&
+                    (pp.overflow || pp.n_rec != pk.n_rec || pp.bytes != pk.bytes ||
+                     memcmp(want.data(), packed.data(), want.size()) != 0))
+                    die("parallel packed parse differs from the serial parse for %s (%d threads)", argv[i], threads);
+            }
         }
         uint64_t h = 1469598103934665603ULL;
         for (uint8_t c : seq) { h ^= c; h *= 1099511628211ULL; }

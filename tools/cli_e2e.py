@@ -53,10 +53,10 @@ def main(n=200, length=5_000_000, threads=16):
     for rep in range(2):  # second pass: files in the page cache
         dt, err = run(["sketch", "-L", "L3K10.shuf", "-i", lst, "-o", "out", "-t", str(threads)])
         print("sketch pass %d: %.2f s wall -> %.2f GB/s of FASTA, %.2f genomes/s" % (rep, dt, total / dt / 1e9, n / dt))
-        print("   " + " | ".join(l for l in err.splitlines() if "time" in l))
+        print("   " + " | ".join(l for l in err.splitlines() if "time" in l or "timing" in l))
     dt, err = run(["alldist", "-i", "out.sketch", "-o", "out.dist", "-d", "0.05", "-t", str(threads)])
     print("alldist %.2f s wall, %d output lines" % (dt, sum(1 for _ in open(os.path.join(tmp, "out.dist")))))
-    print("   " + " | ".join(l for l in err.splitlines() if "time" in l))
+    print("   " + " | ".join(l for l in err.splitlines() if "time" in l or "timing" in l))
 
 
 def write_sketch_file(path, names, hashes, off, half_k=10, half_subk=6, drlevel=3):
@@ -93,11 +93,55 @@ def alldist(n=10000, threads=16):
             raise SystemExit("alldist failed")
         lines = sum(1 for _ in open(os.path.join(tmp, "syn.dist")))
         print("alldist run %d: %.2f s wall, %d pairs reported, %.3g genome-pairs/s end to end" % (rep, dt, lines, n * (n - 1) / 2 / dt))
-        print("   " + " | ".join(l.strip("= ") for l in r.stderr.splitlines() if "time" in l))
+        print("   " + " | ".join(l.strip("= ") for l in r.stderr.splitlines() if "time" in l or "timing" in l))
+
+
+def big(length=1_000_000_000, n=2, threads=16):
+    """S7: a few large genomes (one FASTA record of `length` bases each, 60-column lines)"""
+    tmp = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rk_e2e")
+    os.makedirs(tmp, exist_ok=True)
+    rng = np.random.default_rng(11)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    block = 60_000_000
+    paths = []
+    t0 = time.time()
+    for g in range(n):
+        p = os.path.join(tmp, "big%d.fa" % g)
+        with open(p, "wb") as f:
+            f.write(b">chr1 big genome %d\n" % g)
+            done = 0
+            while done < length:
+                m = min(block, length - done)
+                m -= m % 60
+                if m == 0:
+                    break
+                seq = lut[rng.integers(0, 4, m, dtype=np.uint8)].reshape(-1, 60)
+                f.write(np.concatenate([seq, np.full((seq.shape[0], 1), 10, np.uint8)], axis=1).tobytes())
+                done += m
+        paths.append(p)
+    lst = os.path.join(tmp, "big.list")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    total = sum(os.path.getsize(p) for p in paths)
+    print("wrote %d genomes, %.2f GB in %.1f s" % (n, total / 1e9, time.time() - t0), flush=True)
+    subprocess.run([TOOL, "shuffle", "-k", "10", "-s", "6", "-l", "3", "-o", "L3K10.shuf"], cwd=tmp, capture_output=True)
+    for rep in range(2):
+        t = time.time()
+        r = subprocess.run([TOOL, "sketch", "-L", "L3K10.shuf", "-i", lst, "-o", "bigout", "-t", str(threads)], cwd=tmp, env=dict(os.environ, RK_TIMING="1"),
+                           capture_output=True, text=True)
+        dt = time.time() - t
+        if r.returncode:
+            print(r.stderr[-2000:])
+            raise SystemExit("sketch failed")
+        print("big sketch pass %d: %.2f s wall -> %.2f GB/s" % (rep, dt, total / dt / 1e9))
+        print("   " + " | ".join(l.strip("= ") for l in r.stderr.splitlines() if "time" in l or "timing" in l))
+    for p in paths:
+        os.remove(p)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "alldist":
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        big(*[int(x) for x in sys.argv[2:]])
+    elif len(sys.argv) > 1 and sys.argv[1] == "alldist":
         alldist(*[int(x) for x in sys.argv[2:]])
     else:
         main(*[int(x) for x in sys.argv[1:]])
