@@ -170,21 +170,50 @@ inline bool read_sketches(const std::string &path, SketchSet &s, std::string &er
 }
 
 // ---- .dict / .index, 32-bit layout (src/sketch.cpp:991-1011, src/dist.cpp:86-129) -------
-inline bool write_index(const std::string &dict, const std::string &index, const std::vector<uint32_t> &postings,
-                        const std::vector<uint32_t> &counts, std::string &err)
+// `bytes` at file offset `at`, cut into pieces written concurrently (the dense .index is 1 GiB at
+// 28 hash bits: the page-cache copies scale with threads)
+inline bool pwrite_parallel(int fd, const void *data, uint64_t bytes, uint64_t at, int threads)
+{
+    const uint64_t T = (uint64_t)std::max(1, std::min(threads, (int)(bytes >> 24) + 1));
+    std::vector<int> ok(T, 1);
+    std::vector<std::thread> pool;
+    for (uint64_t i = 0; i < T; i++)
+        pool.emplace_back([&, i]() {
+            uint64_t pos = bytes / T * i;
+            const uint64_t end = i + 1 == T ? bytes : bytes / T * (i + 1);
+            while (pos < end) {
+                const ssize_t r = pwrite(fd, (const char *)data + pos, (size_t)std::min<uint64_t>(end - pos, 1u << 30), (off_t)(at + pos));
+                if (r <= 0) { ok[i] = 0; break; }
+                pos += (uint64_t)r;
+            }
+        });
+    for (auto &th : pool) th.join();
+    for (uint64_t i = 0; i < T; i++) if (!ok[i]) return false;
+    return true;
+}
+
+inline bool write_index(const std::string &dict, const std::string &index, const uint32_t *postings, uint64_t total,
+                        const uint32_t *counts, uint64_t hash_size, std::string &err, int threads = 8)
 {
     FILE *fd = fopen(dict.c_str(), "wb");
     if (!fd) { err = "cannot write " + dict; return false; }
-    fwrite(postings.data(), 4, postings.size(), fd);
+    fwrite(postings, 4, total, fd);
     if (fclose(fd)) { err = "write error on " + dict; return false; }
-    FILE *fi = fopen(index.c_str(), "wb");
-    if (!fi) { err = "cannot write " + index; return false; }
-    const uint64_t hash_size = counts.size(), total = postings.size();
-    fwrite(&hash_size, 8, 1, fi);
-    fwrite(&total, 8, 1, fi);
-    fwrite(counts.data(), 4, counts.size(), fi);
-    if (fclose(fi)) { err = "write error on " + index; return false; }
+    // no O_TRUNC: an existing .index of the same parameters has the same size, and overwriting its
+    // pages in place is twice as fast as freeing 1 GiB of page cache first
+    const int fi = open(index.c_str(), O_WRONLY | O_CREAT, 0644);
+    if (fi < 0) { err = "cannot write " + index; return false; }
+    const uint64_t head[2] = {hash_size, total};
+    bool good = pwrite(fi, head, 16, 0) == 16 && pwrite_parallel(fi, counts, hash_size * 4, 16, threads) &&
+                ftruncate(fi, (off_t)(16 + hash_size * 4)) == 0;
+    if (close(fi)) good = false;
+    if (!good) { err = "write error on " + index; return false; }
     return true;
+}
+inline bool write_index(const std::string &dict, const std::string &index, const std::vector<uint32_t> &postings,
+                        const std::vector<uint32_t> &counts, std::string &err)
+{
+    return write_index(dict, index, postings.data(), postings.size(), counts.data(), counts.size(), err);
 }
 
 // 64-bit layout: .index = {u64 n; u64 hash[n]; u32 count[n]}, .dict = posting blocks in that order

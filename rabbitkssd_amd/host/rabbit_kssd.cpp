@@ -434,9 +434,13 @@ static rk_index *build_index(Gpu &gpu, const SketchSet &s, const string &sketch_
             gpu.check(rk_index_export64(idx, postings.data(), hashes.data(), counts.data()), "rk_index_export64");
             if (!write_index64(sketch_path + ".dict", sketch_path + ".index", postings, hashes, counts, err)) die("%s", err.c_str());
         } else {         // dense layout, src/sketch.cpp:991-1011
-            vector<uint32_t> counts((size_t)1 << bits);
-            gpu.check(rk_index_export(idx, postings.data(), counts.data()), "rk_index_export");
-            if (!write_index(sketch_path + ".dict", sketch_path + ".index", postings, counts, err)) die("%s", err.c_str());
+            RawBuf counts;  // 4 * 2^bits bytes, every one of them written by the export: no zero-fill
+            counts.resize((size_t)4 << bits);
+            gpu.check(rk_index_export(idx, postings.data(), (uint32_t *)counts.data()), "rk_index_export");
+            if (!write_index(sketch_path + ".dict", sketch_path + ".index", postings.data(), postings.size(),
+                             (const uint32_t *)counts.data(), (uint64_t)1 << bits, err,
+                             (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()))))
+                die("%s", err.c_str());
         }
     }
     cerr << "===============the time of transSketches is: " << get_sec() - t0 << endl;
