@@ -145,7 +145,9 @@ __device__ inline uint32_t wave_shr1(uint32_t v, uint32_t lane0_val)
 template <int KS, int OUT2, bool EXACT>
 __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
 {
-    extern __shared__ uint32_t lds[];
+    // static allocation: the compiler knows every LDS address and folds the table bases into the
+    // offset field of ds_read (with a dynamic array each probe pays an extra v_add of the base)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kSketchLdsBytes / 4];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.filter_image);
         uint4 *dst = reinterpret_cast<uint4 *>(lds);
@@ -235,11 +237,17 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
             // The selection bitmaps are symmetric under reverse complement and stored
             // pre-complemented, so x indexes them directly: bitmap A on the low bits.
             uint32_t maybe = 0;
+            const uint32_t off_mask = (dim_mask & ((1u << kBitsA) - 1)) >> 5 << 2;  // dims may have < 19 bits
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                const uint32_t x = ext96_lo(G, G1, G2, 2 * (33 + j - k) + out2) & dim_mask;
-                const uint32_t ia = x & ((1u << kBitsA) - 1);
-                maybe |= ((bmA[ia >> 5] >> (ia & 31)) & 1u) << j;
+                // bit x[18:0] of bitmap A: the word's byte offset (x >> 5) * 4 is cut straight out of
+                // the base string (one funnel shift + mask), the bit position is x[4:0] (v_bfe reads
+                // only the low 5 bits of its offset operand): 5 VALU per window
+                const int sh = 2 * (33 + j - k) + out2;
+                const uint32_t x = ext96_lo(G, G1, G2, sh);
+                const uint32_t off = ext96_lo(G, G1, G2, sh + 3) & off_mask;
+                const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(bmA) + off);
+                maybe |= __builtin_amdgcn_ubfe(word, x, 1) << j;
             }
             maybe &= ~bad;
 
@@ -609,9 +617,8 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
 
     // candidate capacity: expected survivors = windows / 16^drlevel; x2 + slack, exact retry
     uint64_t cap = 2 * (total_len >> (4 * P.drlevel)) + (uint64_t)n_genomes * 64 + 65536;
-    const size_t lds = kSketchLdsBytes;
+    const size_t lds = 0;  // the kernel's LDS is static
     sketch_kernel_t kern = pick_kernel((int)P.kmer_size, 2 * P.half_outctx_len, f->exact);
-    RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
     DevBuf<unsigned long long> cand;
     unsigned long long counters[2] = {0, 0};
