@@ -99,6 +99,11 @@ __device__ inline uint32_t ext96_lo(uint32_t w2, uint32_t w1, uint32_t w0, int s
 // 16 ASCII bases -> G: 2-bit codes, base i of the lane at bits 2i (the orientation of the
 // reverse strand register `rvs_tuple`, src/sketch.cpp:499, before complementing);
 // V: bit i set when base i is one of ACGTacgt (BaseMap, src/common.h:27-37).
+// The hot loop works in the code the ASCII table gives for free, (c >> 1) & 3: A=0 C=1 T=2 G=3
+// ("scan code"; the reference's BaseMap has G=2 T=3).  The filter bitmaps are built for scan-coded
+// indices on the host, and the few windows that survive them are converted before the
+// reference arithmetic (to_base_code): the conversion costs 3 VALU per word on 0.05 % of the
+// windows instead of 3 VALU per input dword on all of them.
 __device__ inline void pack16(const uint4 w, uint32_t &G, uint32_t &V)
 {
     const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
@@ -106,14 +111,13 @@ __device__ inline void pack16(const uint4 w, uint32_t &G, uint32_t &V)
     G = 0;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        const uint32_t x = ws[d] | 0x20202020u;  // fold case
-        // a,c,g,t = 0x61,0x63,0x67,0x74 -> 0,1,2,3 in bits 1:0 of every byte
-        const uint32_t t = ((x >> 1) & 0x03030303u) ^ ((x >> 2) & 0x01010101u);
-        const uint32_t r = t | (t >> 6);
-        G |= ((r | (r >> 12)) & 0xFFu) << (8 * d);
-        // valid <=> the byte equals the letter its code stands for: one v_perm_b32 looks
-        // up "acgt"[code] for all four bytes
-        y[d] = x ^ __builtin_amdgcn_perm(0x74676361u, 0x74676361u, t);
+        const uint32_t u = (ws[d] >> 1) & 0x03030303u;  // scan code in bits 1:0 of every byte
+        // v_dot4_u32_u8 with weights 1,4,16,64 squeezes the four 2-bit codes into one byte
+        const uint32_t four = __builtin_amdgcn_udot4(u, 0x40100401u, 0u, false);
+        G = d ? (four << (8 * d)) | G : four;
+        // valid <=> the (case-folded) byte equals the letter its code stands for: one v_perm_b32
+        // looks up "actg"[code] for all four bytes
+        y[d] = (ws[d] | 0x20202020u) ^ __builtin_amdgcn_perm(0x67746361u, 0x67746361u, u);
     }
     V = 0xFFFFu;
     if ((y[0] | y[1] | y[2] | y[3]) != 0) {  // some byte is not a base (N, separator, padding): rare
@@ -126,6 +130,9 @@ __device__ inline void pack16(const uint4 w, uint32_t &G, uint32_t &V)
         }
     }
 }
+
+// scan code <-> BaseMap code of every 2-bit group (swaps 2 and 3; an involution)
+__host__ __device__ inline uint32_t to_base_code(uint32_t g) { return g ^ ((g >> 1) & 0x55555555u); }
 
 // 2-bit-group reversal: base i moves from bits 2i to bits 2(15-i) (the orientation of
 // `tuple`, src/sketch.cpp:498)
@@ -262,9 +269,10 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
                 const uint32_t x = __builtin_amdgcn_alignbit(wb, wa, sh & 31) & dim_mask;
                 const uint32_t ib = x >> a.hi_shift;
                 if (!((bmB[ib >> 5] >> (ib & 31)) & 1u)) continue;
-                const uint32_t F = rev2(G), F1 = rev2(G1), F2 = rev2(G2);   // forward strand words
+                const uint32_t B0 = to_base_code(G), B1 = to_base_code(G1), B2 = to_base_code(G2);  // BaseMap codes
+                const uint32_t F = rev2(B0), F1 = rev2(B1), F2 = rev2(B2);   // forward strand words
                 const uint64_t tuple = ext96(F2, F1, F, 2 * (15 - j)) & a.tupmask;          // :498
-                const uint64_t rvs = ext96(~G, ~G1, ~G2, 2 * (33 + j - k)) & a.tupmask;    // :499
+                const uint64_t rvs = ext96(~B0, ~B1, ~B2, 2 * (33 + j - k)) & a.tupmask;   // :499
                 const uint64_t uni = tuple < rvs ? tuple : rvs;                            // :508
                 const uint32_t dim = (uint32_t)(uni >> out2) & dim_mask;                   // :509
                 int32_t v = -1;
@@ -388,7 +396,8 @@ int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_di
     auto set_bits = [&](uint32_t dd) {
         // the kernel indexes with the COMPLEMENT of the reverse strand's inner bases.  The
         // shuffle is a random permutation, so both bit fields of a selected index are uniform
-        const uint32_t d = ~dd & dmask;
+        // ... and in scan code (pack16), hence to_base_code(), which maps either code to the other
+        const uint32_t d = to_base_code(~dd & dmask) & dmask;
         const uint32_t ia = d & ((1u << kBitsA) - 1), ib = d >> hi_shift;
         image[ia >> 5] |= 1u << (ia & 31);
         image[kWordsA + (ib >> 5)] |= 1u << (ib & 31);
