@@ -9,14 +9,14 @@
 //
 // Kernel: one wavefront walks a chunk of consecutive 1 KiB blocks.  Per block every lane
 // loads 16 contiguous bases (one coalesced global_load_dwordx4 per lane, 1 KiB per wave),
-// converts them with SWAR arithmetic into a 32-bit word of 2-bit codes plus a 16-bit
-// validity mask, and fetches the words of the two preceding lanes.  All 16 k-mer windows
-// that END inside the lane are then cut out of that 96-bit string with funnel shifts
-// (forward strand) and out of its 2-bit-reversed complement (reverse strand): no serial
-// rolling dependency, 16 independent windows per lane.  The inner 2*subk bases of the
-// canonical k-mer (dim_id, src/sketch.cpp:509) are tested against a bitmap of the
-// selected .shuf entries held in LDS; the ~1/16^drlevel survivors are confirmed against
-// the full .shuf table in HBM/L2 and appended as (genome << 32 | dr_tuple) keys.
+// converts them into a 32-bit word of 2-bit codes (shift + mask + v_dot4_u32_u8 per dword)
+// plus a 16-bit validity mask, and fetches the words of the two preceding lanes (DPP).  All
+// 16 k-mer windows that END inside the lane are then cut out of that 96-bit string with
+// funnel shifts: no serial rolling dependency, 16 independent windows per lane.  The inner
+// 2*subk bases of the window are tested against bitmaps of the (symmetrised) selected .shuf
+// entries held in LDS; only the ~0.05 % survivors build both strands, pick the canonical
+// k-mer (dim_id, src/sketch.cpp:508-509), confirm it in an exact LDS table (or the .shuf
+// table in HBM/L2) and are appended as (genome << key_shift | dr_tuple) keys.
 // Per-genome dedup (the reference's unordered_set) = device radix sort + unique.
 #include <cstring>
 #include <rocprim/rocprim.hpp>
