@@ -212,22 +212,20 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
             cV2 = __builtin_amdgcn_readlane(V, 0); cV1 = __builtin_amdgcn_readlane(V, 1);
         }
 
-        // two blocks of prefetch; the index is clamped instead of branching so the compiler
-        // keeps the loads in flight across the loop body
-        uint4 cur = *reinterpret_cast<const uint4 *>(base + 16 * lane);
-        uint4 nx1 = *reinterpret_cast<const uint4 *>(base + (size_t)min(1u, nb - 1) * 1024 + 16 * lane);
-        for (uint32_t b = 0; b < nb; b++) {
-            const uint4 nx2 = *reinterpret_cast<const uint4 *>(base + (size_t)min(b + 2, nb - 1) * 1024 + 16 * lane);
-
-            uint32_t G, V;
-            uint32_t emitted = 0;  // keys this lane staged in this step
-            pack16(cur, G, V);
-            const uint32_t G1 = wave_shr1(G, cG1), G2 = wave_shr1(G1, cG2);
-            const uint32_t V1 = wave_shr1(V, cV1), V2 = wave_shr1(V1, cV2);
-            cG2 = __builtin_amdgcn_readlane(G, 62); cG1 = __builtin_amdgcn_readlane(G, 63);
-            cV2 = __builtin_amdgcn_readlane(V, 62); cV1 = __builtin_amdgcn_readlane(V, 63);
-
-            // bad[j]: the window ending at base j of this lane contains an invalid base
+        // Two blocks per iteration: both are packed, exchanged and probed against bitmap A in one
+        // straight-line stretch (32 independent LDS reads per lane in flight), which is what hides
+        // the LDS latency with only four waves per SIMD.  Two more blocks are prefetched; the
+        // index is clamped instead of branching so the compiler keeps the loads in flight across
+        // the loop body.  A chunk with an odd number of blocks processes its last block twice and
+        // discards the second result.
+        auto load_block = [&](uint32_t blk) {
+            return *reinterpret_cast<const uint4 *>(base + (size_t)min(blk, nb - 1) * 1024 + 16 * lane);
+        };
+        struct Blk {
+            uint32_t G, G1, G2, bad, maybe;
+        };
+        // windows of a block that contain an invalid base (bit j: the window ending at base j)
+        auto bad_windows = [&](uint32_t V, uint32_t V1, uint32_t V2) -> uint32_t {
             uint32_t bad = 0;
             if ((V & V1 & V2) != 0xFFFFu) {
                 uint64_t inv = (uint64_t)(~V2 & 0xFFFFu) | ((uint64_t)(~V1 & 0xFFFFu) << 16) |
@@ -237,29 +235,34 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
                 if (k > covered) inv |= inv << (k - covered);
                 bad = (uint32_t)(inv >> 32) & 0xFFFFu;
             }
-            windows += __popc(~bad & 0xFFFFu);
-
-            // level 1 (all 16 windows, branch-free).  x = inner bases of the window ending at
-            // base j in the G orientation (= complement of the reverse strand's inner bases).
-            // The selection bitmaps are symmetric under reverse complement and stored
-            // pre-complemented, so x indexes them directly: bitmap A on the low bits.
+            return bad;
+        };
+        const uint32_t off_mask = (dim_mask & ((1u << kBitsA) - 1)) >> 5 << 2;  // dims may have < 19 bits
+        // level 1 (all 16 windows, branch-free).  x = inner bases of the window ending at base j in
+        // the G orientation (= complement of the reverse strand's inner bases).  The selection
+        // bitmaps are symmetric under reverse complement and stored pre-complemented, so x indexes
+        // them directly: bitmap A on the low bits.
+        auto probe_a = [&](const Blk &o) -> uint32_t {
             uint32_t maybe = 0;
-            const uint32_t off_mask = (dim_mask & ((1u << kBitsA) - 1)) >> 5 << 2;  // dims may have < 19 bits
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 // bit x[18:0] of bitmap A: the word's byte offset (x >> 5) * 4 is cut straight out of
                 // the base string (one funnel shift + mask), the bit position is x[4:0] (v_bfe reads
-                // only the low 5 bits of its offset operand): 5 VALU per window
+                // only the low 5 bits of its offset operand): 6 VALU per window
                 const int sh = 2 * (33 + j - k) + out2;
-                const uint32_t x = ext96_lo(G, G1, G2, sh);
-                const uint32_t off = ext96_lo(G, G1, G2, sh + 3) & off_mask;
+                const uint32_t x = ext96_lo(o.G, o.G1, o.G2, sh);
+                const uint32_t off = ext96_lo(o.G, o.G1, o.G2, sh + 3) & off_mask;
                 const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(bmA) + off);
                 maybe |= __builtin_amdgcn_ubfe(word, x, 1) << j;
             }
-            maybe &= ~bad;
-
-            // level 2 (1.6 % of the windows): bitmap B on the high bits, then the full
-            // reference arithmetic for the ~0.05 % that pass both
+            return maybe;
+        };
+        // level 2 (1.6 % of the windows): bitmap B on the high bits, then the full reference
+        // arithmetic for the ~0.05 % that pass both.  Returns the keys this lane staged.
+        auto survivors = [&](const Blk &o) -> uint32_t {
+            uint32_t emitted = 0;
+            uint32_t maybe = o.maybe;
+            const uint32_t G = o.G, G1 = o.G1, G2 = o.G2;
             while (maybe) {
                 const int j = __ffs((int)maybe) - 1;
                 maybe &= maybe - 1;
@@ -301,13 +304,43 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
                     }
                 }
             }
+            return emitted;
+        };
+
+        uint4 c0 = load_block(0), c1 = load_block(1);
+        for (uint32_t b = 0; b < nb; b += 2) {
+            const uint4 n0 = load_block(b + 2), n1 = load_block(b + 3);
+            const bool has1 = b + 1 < nb;  // uniform
+
+            Blk A, B;
+            uint32_t VA, VB;
+            pack16(c0, A.G, VA);
+            pack16(c1, B.G, VB);
+            A.G1 = wave_shr1(A.G, cG1); A.G2 = wave_shr1(A.G1, cG2);
+            const uint32_t VA1 = wave_shr1(VA, cV1), VA2 = wave_shr1(VA1, cV2);
+            cG2 = __builtin_amdgcn_readlane(A.G, 62); cG1 = __builtin_amdgcn_readlane(A.G, 63);
+            cV2 = __builtin_amdgcn_readlane(VA, 62); cV1 = __builtin_amdgcn_readlane(VA, 63);
+            B.G1 = wave_shr1(B.G, cG1); B.G2 = wave_shr1(B.G1, cG2);
+            const uint32_t VB1 = wave_shr1(VB, cV1), VB2 = wave_shr1(VB1, cV2);
+            cG2 = __builtin_amdgcn_readlane(B.G, 62); cG1 = __builtin_amdgcn_readlane(B.G, 63);
+            cV2 = __builtin_amdgcn_readlane(VB, 62); cV1 = __builtin_amdgcn_readlane(VB, 63);
+            A.bad = bad_windows(VA, VA1, VA2);
+            B.bad = has1 ? bad_windows(VB, VB1, VB2) : 0xFFFFu;
+            windows += __popc(~A.bad & 0xFFFFu) + __popc(~B.bad & 0xFFFFu);
+
+            const uint32_t ma = probe_a(A), mb = probe_a(B);
+            A.maybe = ma & ~A.bad;
+            B.maybe = mb & ~B.bad;
+
+            uint32_t emitted = survivors(A);
+            emitted += survivors(B);
             for (uint32_t lvl = 1; ; lvl++) {  // wave-uniform count of staged keys, no LDS round trip
                 const unsigned long long m = __ballot(emitted >= lvl);
                 if (!m) break;
                 staged += __popcll(m);
             }
-            cur = nx1;
-            nx1 = nx2;
+            c0 = n0;
+            c1 = n1;
             if (staged >= kStageCap / 2) { flush(); staged = 0; }
         }
         flush();
