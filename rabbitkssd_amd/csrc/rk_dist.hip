@@ -2,16 +2,19 @@
 // Replaces the row loops of index_tridist (src/dist.cpp:174-258) and index_dist
 // (src/dist.cpp:560-692).
 //
-// One workgroup per (run of consecutive query rows, reference tile).  The
-// counter row of the reference (`int intersectionArr[tid][numRef]`, src/dist.cpp:167) lives in
-// LDS, two 16-bit counters per word when no count can overflow.  Per row: the posting slices
-// of the row's hashes stream from HBM into registers one per thread (the next batch is always
-// in flight), the posting lists are gathered from HBM/L2 by 8-lane groups with 8-10
-// independent gathers in flight per lane and scattered into the LDS row with ds_add_u32.  The
-// epilogue scans the row 16 B per lane, compacts the non-zero cells into an LDS list and
-// evaluates the Jaccard/Mash (or containment/AafD) formula in FP64 one cell per lane; reported
-// pairs are staged in LDS and flushed with one device-scope atomic per workgroup.
-// Integer/index work: bound by VALU issue, LDS atomics and gather latency -- no MFMA.
+// A workgroup processes "units": one query row, or in the self join a pair of neighbouring rows
+// (see rk_dist_kernel).  The counter row of the reference (`int intersectionArr[tid][numRef]`,
+// src/dist.cpp:167) lives in LDS, two 16-bit counters per word when no count can overflow.  Per
+// unit: the posting slices of its hashes stream from HBM into registers one per thread (the next
+// batch is always in flight), quads gather the first 8 postings of each list with one 8-byte load
+// per lane and scatter them into the LDS row with ds_add_u32.  The epilogue scans the row 16 B per
+// lane, compacts the non-zero cells into an LDS list and evaluates the Jaccard/Mash (or
+// containment/AafD) formula in FP64 one cell per lane; reported pairs are staged in LDS and flushed
+// with one device-scope atomic per workgroup.
+// Integer/index work: bound by LDS atomics, L1 tag lookups and latency -- no MFMA.
+// Developer switches (environment, read per launch): RK_DIST_THREADS=256|512|1024, RK_DIST_ROWS=<units
+// per workgroup, non-persistent>, RK_DIST_PAIR=2 (no row pairs), RK_DIST_PAIR_MINWG, RK_DIST_PERSIST=2
+// (one run per workgroup), RK_DIST_CAND_CAP, RK_DIST_STAGE_HITS, RK_DIST_XCD_ROWS.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
