@@ -20,9 +20,19 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <rocprim/rocprim.hpp>
+
 #include "rk_internal.h"
 
 namespace {
+
+// (row, col) sort key of every hit: big results are ordered on the device (a 50 M-hit dense matrix
+// takes the host's std::sort more than a second)
+__global__ void k_hit_keys(const rk_hit *hits, unsigned long long n, unsigned long long *keys)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = ((unsigned long long)hits[i].row << 32) | hits[i].col;
+}
 
 constexpr int kGroup = 8;                      // postings per slice walked by a quad (4 lanes x 2 postings)
 constexpr uint32_t kRowsPerXcdChunk = 16;      // consecutive rows kept on one XCD (their L2 shares a clade's postings)
@@ -873,16 +883,36 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
         }
         rk_hit *out = (rk_hit *)malloc((n ? n : 1) * sizeof(rk_hit));
         if (!out) return rk_fail(ctx, RK_ERR_NOMEM, "host allocation of %llu hits failed", n);
+        const rk_hit *src = hits.p;
+        DevBuf<rk_hit> ordered;
+        bool on_device = false;
+        if (n > (1u << 20)) {  // order big results on the device; on any failure the host sorts
+            DevBuf<unsigned long long> keys, keys_out;
+            DevBuf<char> tmp;
+            size_t tb = 0;
+            int bits = 33;
+            while (bits < 64 && (1ULL << (bits - 32)) < n_query) bits++;
+            if (keys.alloc(n) == hipSuccess && keys_out.alloc(n) == hipSuccess && ordered.alloc(n) == hipSuccess &&
+                rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_out.p, hits.p, ordered.p, n, 0, (unsigned)bits) == hipSuccess &&
+                tmp.alloc(tb) == hipSuccess) {
+                hipLaunchKernelGGL(k_hit_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, hits.p, n, keys.p);
+                on_device = rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys_out.p, hits.p, ordered.p, n, 0, (unsigned)bits) == hipSuccess &&
+                            hipDeviceSynchronize() == hipSuccess;
+            }
+            if (on_device) src = ordered.p;
+            else (void)hipGetLastError();
+        }
         if (n) {
-            hipError_t e = hipMemcpy(out, hits.p, n * sizeof(rk_hit), hipMemcpyDeviceToHost);
+            hipError_t e = hipMemcpy(out, src, n * sizeof(rk_hit), hipMemcpyDeviceToHost);
             if (e != hipSuccess) {
                 free(out);
                 return rk_fail(ctx, RK_ERR_HIP, "hit download failed: %s", hipGetErrorString(e));
             }
         }
-        std::sort(out, out + n, [](const rk_hit &x, const rk_hit &y) {
-            return x.row != y.row ? x.row < y.row : x.col < y.col;
-        });
+        if (!on_device)
+            std::sort(out, out + n, [](const rk_hit &x, const rk_hit &y) {
+                return x.row != y.row ? x.row < y.row : x.col < y.col;
+            });
         *hits_out = out;
         *n_hits = n;
         if (common_dense)

@@ -450,7 +450,7 @@ static rk_index *build_index(Gpu &gpu, const SketchSet &s, const string &sketch_
 // writes the distance text exactly as src/dist.cpp:233,291 / :642,725 do; above 4 GiB the
 // rows are kept as sub-files in <out>.dir with an <out>.index map (src/dist.cpp:276-336)
 static void write_hits(const string &out, const rk_hit *hits, uint64_t n, bool alldist, const vector<string> &rows,
-                       const vector<string> &cols)
+                       const vector<string> &cols, int threads = 1)
 {
     const double t0 = get_sec();
     const uint64_t max_size = 1ULL << 32;
@@ -461,19 +461,61 @@ static void write_hits(const string &out, const rk_hit *hits, uint64_t n, bool a
         return rk_format_hit(buf, cap, a.c_str(), b.c_str(), &h);
     };
     vector<char> buf(1 << 16);
+    // the text of every line, formatted once by all threads (the role of the reference's per-thread
+    // sub-files, src/dist.cpp:207-255): pieces of consecutive hits, concatenated in order below
+    const uint64_t n_pieces = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, threads) * 4, (n + 65535) / 65536));
+    vector<string> piece(n_pieces);
+    {
+        std::atomic<uint64_t> next{0};
+        auto work = [&]() {
+            vector<char> lb(1 << 16);
+            for (;;) {
+                const uint64_t p = next.fetch_add(1);
+                if (p >= n_pieces) break;
+                const uint64_t i0 = n / n_pieces * p, i1 = p + 1 == n_pieces ? n : n / n_pieces * (p + 1);
+                string &t = piece[p];
+                t.reserve((size_t)(i1 - i0) * 72);
+                for (uint64_t i = i0; i < i1; i++) t.append(lb.data(), (size_t)line(hits[i], lb.data(), lb.size()));
+            }
+        };
+        vector<std::thread> pool;
+        for (int t = 1; t < std::max(1, threads) && (uint64_t)t < n_pieces; t++) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+    }
     uint64_t total = 0;
-    for (uint64_t i = 0; i < n; i++) total += (uint64_t)line(hits[i], buf.data(), buf.size());
+    for (const string &t : piece) total += t.size();
     if (total <= max_size) {
-        FILE *fp = fopen(out.c_str(), "w");
-        if (!fp) die("cannot write %s", out.c_str());
         cerr << "-----save the output distance file: " << out << endl;
-        fprintf(fp, " genome0\tgenome1\tcommon|size0|size1\tjaccard\tmashD\n");
-        for (uint64_t i = 0; i < n; i++) {
-            const int l = line(hits[i], buf.data(), buf.size());
-            fwrite(buf.data(), 1, (size_t)l, fp);
-        }
-        fclose(fp);
+        const char *head = " genome0\tgenome1\tcommon|size0|size1\tjaccard\tmashD\n";
+        const int fd = open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) die("cannot write %s", out.c_str());
+        bool good = pwrite(fd, head, strlen(head), 0) == (ssize_t)strlen(head);
+        vector<uint64_t> at(n_pieces);
+        uint64_t pos = strlen(head);
+        for (uint64_t p = 0; p < n_pieces; p++) { at[p] = pos; pos += piece[p].size(); }
+        std::atomic<uint64_t> next{0};
+        std::atomic<int> failed{0};
+        auto put = [&]() {
+            for (;;) {
+                const uint64_t p = next.fetch_add(1);
+                if (p >= n_pieces) break;
+                uint64_t done = 0;
+                while (done < piece[p].size()) {
+                    const ssize_t r = pwrite(fd, piece[p].data() + done, piece[p].size() - done, (off_t)(at[p] + done));
+                    if (r <= 0) { failed = 1; break; }
+                    done += (uint64_t)r;
+                }
+            }
+        };
+        vector<std::thread> pool;
+        for (int t = 1; t < std::min(8, std::max(1, threads)) && (uint64_t)t < n_pieces; t++) pool.emplace_back(put);
+        put();
+        for (auto &th : pool) th.join();
+        if (close(fd) || failed || !good) die("write error on %s", out.c_str());
     } else {
+        piece.clear();
+        piece.shrink_to_fit();
         const string dir = out + ".dir";
         if (mkdir(dir.c_str(), 0777) && errno != EEXIST) die("cannot create %s", dir.c_str());
         cerr << "-----the output distance file is too big to merge into one single file, saving the result into directory: "
@@ -598,7 +640,7 @@ static int cmd_alldist(const Args &a)
     cerr << "=====total: " << s.size() << endl;
     gpu.check(rk_dist_rows(gpu.ctx, idx, nullptr, &o, &hits, &n, nullptr), "rk_dist_rows");
     cerr << "===================time of multiple threads distance computing and save the subFile is: " << get_sec() - t1 << endl;
-    write_hits(out, hits, n, true, s.names, s.names);
+    write_hits(out, hits, n, true, s.names, s.names, threads);
     rk_free_host(hits);
     rk_index_free(idx);
     return 0;
@@ -639,7 +681,7 @@ static int cmd_dist(const Args &a)
     gpu.check(rk_dist_rows(gpu.ctx, idx, qs, &o, &hits, &n, nullptr), "rk_dist_rows");
     if (is_neighbor) rk_topn_rows(hits, &n, (uint64_t)max_neighbor);
     cerr << "===================time of multiple threads distance computing and save the subFile is: " << get_sec() - t1 << endl;
-    write_hits(out, hits, n, false, qry.names, ref.names);
+    write_hits(out, hits, n, false, qry.names, ref.names, threads);
     rk_free_host(hits);
     rk_sketches_free(qs);
     rk_index_free(idx);

@@ -94,6 +94,18 @@ def test_config3_alldist_50k_properties_and_exact(ctx):
     assert part.tobytes() == sel.tobytes()
 
 
+def test_dense_output_ordered_on_the_device(ctx):
+    """-D 1.5 reports every pair: 2,000 genomes -> 1,999,000 hits, more than the 2^20 above which the
+    result is ordered on the device; order and content equal the oracle's"""
+    names, h, off = synth.clade_sketches(2000, 200, 24, seed=5)
+    idx = ctx.index_build(ctx.sketches_from_host(h, off), 24)
+    postings, counts = ok.index_build32(h, off, 24)
+    want, _ = ok.index_dist32(counts, 24, postings, np.diff(off).astype(np.uint32), h, off, 1, 0, 20, 1.5, threads=CORES)
+    mine, _ = ctx.dist_rows(idx, None, 1, 0, 20, 1.5)
+    assert len(mine) == 2000 * 1999 // 2
+    check_hits(mine, want)
+
+
 def test_self_join_with_tiled_columns_90k(ctx):
     """more genomes than one LDS row holds (> ~78,000 columns): the self join runs tile by tile with
     range-checked postings; exact vs the oracle"""

@@ -71,7 +71,7 @@ def write_sketch_file(path, names, hashes, off, half_k=10, half_subk=6, drlevel=
             hashes[int(off[i]):int(off[i + 1])].astype(np.uint32).tofile(f)
 
 
-def alldist(n=10000, threads=16):
+def alldist(n=10000, threads=16, max_dist="0.05"):
     """configs[2]: alldist from a precomputed .sketch (and its .dict/.index after the first run)"""
     sys.path.insert(0, ROOT)
     from rabbitkssd_amd import synth
@@ -85,7 +85,7 @@ def alldist(n=10000, threads=16):
             os.remove(f)
     for rep in range(3):  # run 0 builds and writes .dict/.index, runs 1-2 load them
         t = time.time()
-        r = subprocess.run([TOOL, "alldist", "-i", sk, "-o", os.path.join(tmp, "syn.dist"), "-D", "0.05", "-t", str(threads)],
+        r = subprocess.run([TOOL, "alldist", "-i", sk, "-o", os.path.join(tmp, "syn.dist"), "-D", str(max_dist), "-t", str(threads)],
                            cwd=tmp, capture_output=True, text=True)
         dt = time.time() - t
         if r.returncode:
@@ -142,6 +142,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "big":
         big(*[int(x) for x in sys.argv[2:]])
     elif len(sys.argv) > 1 and sys.argv[1] == "alldist":
-        alldist(*[int(x) for x in sys.argv[2:]])
+        alldist(int(sys.argv[2]) if len(sys.argv) > 2 else 10000, int(sys.argv[3]) if len(sys.argv) > 3 else 16,
+                sys.argv[4] if len(sys.argv) > 4 else "0.05")
     else:
         main(*[int(x) for x in sys.argv[1:]])
