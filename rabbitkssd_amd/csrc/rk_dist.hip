@@ -628,11 +628,14 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // counter row in LDS; tile the reference range when it does not fit
     p->u16 = max_query_size < 65536;
     p->cand_cap = (envu("RK_DIST_CAND_CAP", kCandCapDefault) + 1) & ~1u;
-    // one tile: persistent workgroups that pull units from per-XCD queues; they live long, so they
-    // stage more hits before the one flush at their end
-    p->persist = idx->n_ref && (uint64_t)idx->n_ref * (p->u16 ? 2 : 4) + 8192 <= ctx->max_lds && envu("RK_DIST_PERSIST", 1) != 2;
-    p->stage_hits = envu("RK_DIST_STAGE_HITS", p->persist ? 4 * kStageHitsDefault : kStageHitsDefault);
-    const size_t fixed = (size_t)p->cand_cap * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
+    // Persistent workgroups (one tile, >= 512 threads: with 256-thread workgroups one run of two rows
+    // per workgroup measured better, 0.134 vs 0.145 ms) live long, so they stage more hits before the
+    // one flush at their end.  Capacity decisions below assume the bigger staging area.
+    const uint64_t one_row = (uint64_t)idx->n_ref * (p->u16 ? 2 : 4);
+    const bool small_rows = one_row + (size_t)p->cand_cap * sizeof(uint2) + kStageHitsDefault * sizeof(rk_hit) + 64 <= 24 * 1024;
+    p->persist = idx->n_ref && envu("RK_DIST_PERSIST", 1) != 2;
+    p->stage_hits = envu("RK_DIST_STAGE_HITS", 4 * kStageHitsDefault);
+    size_t fixed = (size_t)p->cand_cap * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
     const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - fixed;
     const uint32_t max_cols = (uint32_t)(p->u16 ? lds_cap / 2 : lds_cap / 4) & ~63u;
     uint32_t tile = idx->n_ref ? idx->n_ref : 1;
@@ -663,12 +666,18 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     const uint64_t my_blocks = p->row_first < n_blocks ? (n_blocks - p->row_first + p->row_step - 1) / p->row_step : 0;
     p->n_units = (uint32_t)std::min<uint64_t>(my_blocks * p->units_per_block, 0xFFFFFFF0u);
     p->cnt_words = p->row_words * unit_rows;
+    if (p->mode != kSelfPair && small_rows) {  // 7 workgroups of 256 threads per CU, not persistent
+        p->persist = false;
+        p->stage_hits = envu("RK_DIST_STAGE_HITS", kStageHitsDefault);
+        fixed = (size_t)p->cand_cap * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
+    }
     p->lds_bytes = (size_t)p->cnt_words * 4 + fixed;
     p->persist = p->persist && p->n_tiles == 1;
     p->units_per_wg = p->persist ? 1 : envu("RK_DIST_ROWS", p->mode == kSelfPair ? 1 : 2);
     // workgroup size by row size: 7 x 256 threads fit up to ~22 KiB rows; bigger rows leave room for
     // fewer workgroups, which then need more waves each
     p->threads = p->lds_bytes <= 24 * 1024 ? 256 : (p->lds_bytes <= 64 * 1024 ? 512 : 1024);
+    if (p->mode == kSelfPair && p->threads == 256) p->threads = 512;  // two rows' slices per unit: measured better
     const uint32_t forced = envu("RK_DIST_THREADS", 0);
     if (forced == 256 || forced == 512 || forced == 1024) p->threads = forced;
     // does a pair with distance exactly 1.0 (common == 0) pass the threshold?

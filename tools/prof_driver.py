@@ -42,15 +42,24 @@ def dist(n_genomes=10000, steps=5, row_step=1, row_block=0):
     names, hashes, off = synth.clade_sketches(n_genomes, 1220, 28)
     index = ctx.index_build(ctx.sketches_from_host(hashes, off), 28)
     hits = torch.empty((1 << 20) * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
-    counters = torch.zeros(steps, dtype=torch.int64, device="cuda")
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for i in range(steps):
-        ctx.dist_rows_dev(index, 1, 0, 20, 0.05, hits.data_ptr(), 1 << 20, counters.data_ptr() + 8 * i,
-                          row_first=0, row_step=row_step, row_block=row_block)
-    torch.cuda.synchronize()
-    print("dist %.3f ms/step, hits %d (row_step %d, row_block %d)" % ((time.time() - t0) * 1e3 / steps,
-                                                                      int(counters[0].item()), row_step, row_block))
+    counters = torch.zeros(steps + 1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        def launch(i):
+            ctx.dist_rows_dev(index, 1, 0, 20, 0.05, hits.data_ptr(), 1 << 20, counters.data_ptr() + 8 * i,
+                              row_first=0, row_step=row_step, row_block=row_block, stream=stream.cuda_stream)
+        launch(steps)  # warm-up
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.time()
+        ev0.record(stream)
+        for i in range(steps):
+            launch(i)
+        ev1.record(stream)
+        t_host = time.time() - t0   # time the host needed to enqueue everything
+        torch.cuda.synchronize()
+    print("dist %.3f ms/step (events; host enqueue %.3f ms/step), hits %d (row_step %d, row_block %d)" % (
+        ev0.elapsed_time(ev1) / steps, t_host * 1e3 / steps, int(counters[0].item()), row_step, row_block))
 
 
 def dist_rq(n_ref=100000, n_query=1000, steps=3):
