@@ -73,6 +73,16 @@ static int usage()
     return 2;
 }
 
+#ifdef RK_GPU_BINDING
+// oracle/_ref/ref_driver_gpu: the same driver over integration/gpu_backend.cpp (the reference-side
+// binding of librabbitkssd.so) instead of the reference's CPU loops
+void index_tridist_gpu(vector<sketch_t> &, sketchInfo_t &, string, string, int, double, int, int);
+void index_dist_gpu(vector<sketch_t> &, sketchInfo_t &, string, vector<sketch_t> &, string, int, double, uint64_t, bool,
+                    int, int);
+#define index_tridist index_tridist_gpu
+#define index_dist index_dist_gpu
+#endif
+
 int main(int argc, char **argv)
 {
     if (argc < 2) return usage();
@@ -104,6 +114,7 @@ int main(int argc, char **argv)
                       atoi(argv[7]));
         return 0;
     }
+#ifndef RK_GPU_BINDING
     if (cmd == "tridist" && argc == 7) {
         if (chdir(argv[2])) return 3;
         std::vector<sketch_t> sk;
@@ -112,6 +123,7 @@ int main(int argc, char **argv)
         tri_dist(sk, argv[4], 2 * info.half_k, atof(argv[5]), atoi(argv[6]));
         return 0;
     }
+#endif
     if (cmd == "dist" && argc == 11) {
         if (chdir(argv[2])) return 3;
         std::vector<sketch_t> rs, qs;
