@@ -15,10 +15,14 @@
  *   - the .dict/.index layout (I1) is pinned indirectly: the real index_tridist /
  *     index_dist consume files written by ok_index_build32 and must reproduce the
  *     real brute-force tri_dist (dist.cpp:345) results.
- *   - the sketch arithmetic (S3-S5), FASTA record reader (S0) and .sketch I/O (S8)
- *     live in sketch.cpp, which needs the un-vendored RabbitFX submodule and is
- *     therefore unbuildable here: PARITY UNPINNED by execution; restated
- *     line-by-line and cross-checked by an independent numpy restatement.
+ *   - the FASTA/FASTQ record reader (S0) is pinned against the reference's own kseq.h
+ *     (header-only, instantiated and looped like src/sketch.cpp:17,462-479 in
+ *     oracle/_ref/ref_driver kseq): 29 well-formed and malformed inputs under
+ *     tests/golden/kseq/.
+ *   - the sketch arithmetic (S3-S5) and .sketch I/O (S8) live in sketch.cpp, which needs
+ *     the un-vendored RabbitFX submodule and is therefore unbuildable here: PARITY
+ *     UNPINNED by execution; restated line-by-line and cross-checked by an independent
+ *     numpy restatement.
  */
 #ifndef KSSD_ORACLE_H
 #define KSSD_ORACLE_H

@@ -17,10 +17,15 @@
 #include <unistd.h>
 #include <vector>
 
+#include <zlib.h>
+
 #include "common.h"
 #include "dist.h"
+#include "kseq.h"     // the reference's record reader, instantiated exactly like src/sketch.cpp:17
 #include "shuffle.h"
 #include "sketch.h"
+
+KSEQ_INIT(gzFile, gzread)
 
 #include "kssd_oracle.h"
 
@@ -64,6 +69,7 @@ static int usage()
             "usage:\n"
             "  ref_driver param K S L\n"
             "  ref_driver shuffle K S L out.shuf\n"
+            "  ref_driver kseq FILE...        (records as the reference's kseq_read loop sees them)\n"
             "  ref_driver alldist WORKDIR in.sketch OUT maxDist isContainment threads\n"
             "  ref_driver tridist WORKDIR in.sketch OUT maxDist threads\n"
             "  ref_driver dist WORKDIR ref.sketch qry.sketch OUT maxDist maxNeighbor isNeighbor "
@@ -103,6 +109,37 @@ int main(int argc, char **argv)
         st.drlevel = atoi(argv[4]);
         st.id = 0;
         write_shuffle_dim_file(&st, argv[5]);
+        return 0;
+    }
+    if (cmd == "kseq" && argc >= 3) {
+        // the loop of src/sketch.cpp:462-479 (and :753-776 for FASTQ): gzopen, kseq_init, kseq_read until < 0.
+        // One line per file: name, records, bases, FNV-1a of all sequence bytes, FNV-1a of all quality
+        // bytes ('~' for records without qualities), then the end offset of every record.
+        for (int i = 2; i < argc; i++) {
+            gzFile fp = gzopen(argv[i], "r");
+            if (!fp) { fprintf(stderr, "ref_driver: cannot open %s\n", argv[i]); return 2; }
+            kseq_t *ks = kseq_init(fp);
+            unsigned long long h = 1469598103934665603ULL, hq = 1469598103934665603ULL, total = 0;
+            std::vector<unsigned long long> ends;
+            for (;;) {
+                const int length = kseq_read(ks);
+                if (length < 0) break;
+                for (int t = 0; t < length; t++) {
+                    h ^= (unsigned char)ks->seq.s[t];
+                    h *= 1099511628211ULL;
+                    const unsigned char q = ks->qual.l ? (unsigned char)ks->qual.s[t] : (unsigned char)'~';
+                    hq ^= q;
+                    hq *= 1099511628211ULL;
+                }
+                total += (unsigned long long)length;
+                ends.push_back(total);
+            }
+            kseq_destroy(ks);
+            gzclose(fp);
+            printf("%s\t%zu\t%llu\t%016llx\t%016llx", argv[i], ends.size(), total, h, hq);
+            for (unsigned long long e : ends) printf("\t%llu", e);
+            printf("\n");
+        }
         return 0;
     }
     if (cmd == "alldist" && argc == 8) {

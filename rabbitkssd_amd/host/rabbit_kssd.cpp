@@ -901,13 +901,16 @@ static int cmd_sub(const Args &a)
     return 0;
 }
 
-// test helper: record reader parity (prints records, bases and an FNV-1a hash of the bytes)
+// test helper: record reader parity (prints records, bases, FNV-1a hashes of the sequence and of the
+// quality bytes, record end offsets -- the format of oracle/_ref/ref_driver kseq)
 static int cmd_parse(int argc, char **argv)
 {
     for (int i = 2; i < argc; i++) {
-        vector<uint8_t> seq;
+        vector<uint8_t> seq, qual;
         vector<uint64_t> off;
-        if (!RecordReader::read_file(argv[i], seq, off)) die("cannot open %s", argv[i]);
+        if (!RecordReader::read_file(argv[i], seq, off, &qual)) die("cannot open %s", argv[i]);
+        if (off.empty()) off.push_back(0);
+        qual.resize(seq.size(), '~');
         {   // the packed sink must produce the same records, separated by 0x00
             vector<uint8_t> buf, packed;
             size_t n = 0;
@@ -932,9 +935,11 @@ static int cmd_parse(int argc, char **argv)
                     die("parallel packed parse differs from the serial parse for %s (%d threads)", argv[i], threads);
             }
         }
-        uint64_t h = 1469598103934665603ULL;
+        uint64_t h = 1469598103934665603ULL, hq = 1469598103934665603ULL;
         for (uint8_t c : seq) { h ^= c; h *= 1099511628211ULL; }
-        printf("%s\t%zu\t%zu\t%016llx", argv[i], off.size() - 1, seq.size(), (unsigned long long)h);
+        for (uint8_t c : qual) { hq ^= c; hq *= 1099511628211ULL; }
+        printf("%s\t%zu\t%zu\t%016llx\t%016llx", argv[i], off.size() - 1, seq.size(), (unsigned long long)h,
+               (unsigned long long)hq);
         for (size_t r = 1; r < off.size(); r++) printf("\t%llu", (unsigned long long)off[r]);
         printf("\n");
     }

@@ -46,7 +46,7 @@ def test_record_reader_matches_oracle_kseq_restatement():
             h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         assert int(cols[1]) == len(off) - 1 and int(cols[2]) == len(seq), f
         assert cols[3] == "%016x" % h, f
-        assert [int(x) for x in cols[4:]] == [int(x) for x in off[1:]], f
+        assert [int(x) for x in cols[5:]] == [int(x) for x in off[1:]], f
 
 
 def test_record_reader_edge_cases(tmp_path):
@@ -68,7 +68,21 @@ def test_record_reader_edge_cases(tmp_path):
         seq, off = ok.parse_fasta_bytes(data)
         assert int(cols[1]) == len(off) - 1, name
         assert int(cols[2]) == len(seq), name
-        assert [int(x) for x in cols[4:]] == [int(x) for x in off[1:]], name
+        assert [int(x) for x in cols[5:]] == [int(x) for x in off[1:]], name
+
+
+def test_record_reader_matches_the_real_kseq(tmp_path):
+    """tests/golden/kseq/expected.tsv was written by the reference's own kseq.h (src/kseq.h, looped like
+    src/sketch.cpp:462-479) through oracle/_ref/ref_driver kseq: records, bases, sequence bytes, quality
+    bytes and record boundaries of 29 well-formed and malformed inputs, plain and gzip'd"""
+    d = os.path.join(GOLDEN, "kseq")
+    want = [l.split("\t") for l in open(os.path.join(d, "expected.tsv")).read().split("\n") if l and not l.startswith("#")]
+    assert len(want) == 29
+    out = run(["_parse"] + [os.path.join(d, w[0]) for w in want]).stdout.decode().strip().split("\n")
+    for line, w in zip(out, want):
+        cols = line.split("\t")
+        assert os.path.basename(cols[0]) == w[0]
+        assert cols[1:] == w[1:], w[0]
 
 
 def test_info_and_merge(tmp_path):

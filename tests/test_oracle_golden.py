@@ -96,6 +96,41 @@ def test_index_files_roundtrip(tmp_path):
     assert np.array_equal(p2, postings) and np.array_equal(c2, counts)
 
 
+def _fnv(data):
+    h = 1469598103934665603
+    for c in bytes(data):
+        h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def test_record_reader_restatement_matches_the_real_kseq():
+    """S0 pinned: tests/golden/kseq/expected.tsv holds what the reference's own kseq.h returned (via
+    oracle/_ref/ref_driver kseq) for 29 inputs; the C restatement must agree on records, bases,
+    sequence bytes, quality bytes and boundaries"""
+    import gzip
+    d = os.path.join(GOLDEN, "kseq")
+    rows = [l.split("\t") for l in open(os.path.join(d, "expected.tsv")).read().split("\n") if l and not l.startswith("#")]
+    assert len(rows) == 29
+    for w in rows:
+        path = os.path.join(d, w[0])
+        seq, off = ok.read_fasta(path)                       # gzopen path, plain or compressed
+        assert len(off) - 1 == int(w[1]) and len(seq) == int(w[2]), w[0]
+        assert _fnv(seq) == w[3], w[0]
+        assert [int(x) for x in off[1:]] == [int(x) for x in w[5:]], w[0]
+        raw = open(path, "rb").read()
+        if w[0].endswith(".gz"):
+            import zlib
+            dec, raw2 = b"", raw
+            while raw2:                                      # every member, like gzread
+                z = zlib.decompressobj(31)
+                dec += z.decompress(raw2)
+                raw2 = z.unused_data
+            raw = dec
+        s2, q2, o2 = ok.parse_fastq_bytes(raw)
+        assert _fnv(s2) == w[3] and _fnv(q2) == w[4], w[0]
+        assert [int(x) for x in o2[1:]] == [int(x) for x in w[5:]], w[0]
+
+
 def test_sketch_fixture_hash_sets():
     """unpinned fixture: C restatement == expected.json (itself cross-checked by numpy)."""
     d = os.path.join(GOLDEN, "sketch")
