@@ -113,9 +113,9 @@ def cpu_baseline(names, hashes, off, n_pairs):
 
 def sketch_leg(ctx, capi, torch, n_genomes, length, steps=3):
     """secondary metric: sketch k-mers/s, sequence bytes resident in HBM."""
-    from oracle import oracle as ok  # only for the .shuf table generator (glibc rand())
+    from rabbitkssd_amd import synth
     params = capi.params_init(10, 6, 3)
-    table = ok.shuffle_table(10, 6, 3)
+    table = synth.shuf_table(10, 6, 3)  # the product's own `rabbit_kssd shuffle`
     flt = ctx.filter(params, table)
     stride = (length + 1023) // 1024 * 1024
     g = torch.Generator(device="cuda")

@@ -16,9 +16,8 @@ from rabbitkssd_amd import capi, synth  # noqa: E402
 
 
 def sketch(n_genomes=128, length=5_000_000, steps=3):
-    from oracle import oracle as ok  # .shuf generator only
     ctx = capi.Context(0)
-    flt = ctx.filter(capi.params_init(10, 6, 3), ok.shuffle_table(10, 6, 3))
+    flt = ctx.filter(capi.params_init(10, 6, 3), synth.shuf_table(10, 6, 3))
     stride = (length + 1023) // 1024 * 1024
     g = torch.Generator(device="cuda")
     g.manual_seed(1234)
