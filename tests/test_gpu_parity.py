@@ -169,6 +169,20 @@ def test_pair_kernel_equals_single_row_kernel(ctx, monkeypatch):
         assert_hits_equal(single, want)
 
 
+def test_self_join_of_big_sketches_uses_32bit_counters_in_pairs(ctx):
+    # sketches of >= 65536 hashes (3 Gb genomes): the self join runs the pair kernel with u32 LDS counters
+    names, h, off = synth.clade_sketches(41, 70000, 26, seed=31)
+    assert np.diff(off).max() >= 65536
+    idx = ctx.index_build(ctx.sketches_from_host(h, off), 26)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    for metric, D in ((0, 0.05), (1, 0.3), (0, 1.5)):
+        want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=4)
+        mine, _ = ctx.dist_rows(idx, None, 1, metric, 20, D)
+        assert len(want) > 0
+        assert_hits_equal(mine, want)
+
+
 def test_row_sharding_union_equals_full(ctx):
     names, h, off = synth.clade_sketches(500, 100, 22, seed=9)
     idx = ctx.index_build(ctx.sketches_from_host(h, off), 22)
