@@ -279,6 +279,9 @@ static int base_code(uint8_t ch)
     }
 }
 
+/* BaseMap, src/common.h:27-37, for the test that pins it against the reference's table */
+int ok_base_code(int ch) { return ch >= 0 && ch < 256 ? base_code((uint8_t)ch) : -1; }
+
 static int cmp_u64(const void *a, const void *b)
 {
     uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;

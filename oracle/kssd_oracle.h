@@ -87,6 +87,9 @@ int64_t ok_sketch_records_fastq(const ok_param_t *p, const int32_t *shuffled_dim
                                 const uint8_t *qual, int least_qual, int least_num,
                                 const uint64_t *rec_off, uint64_t n_rec, uint64_t **hashes_out);
 
+/* BaseMap of src/common.h:27-37: 0..3 for ACGT/acgt, -1 otherwise */
+int ok_base_code(int ch);
+
 /* S3-S5: src/sketch.cpp:487-550.  Windows never span records.  Output: sorted
  * unique dr_tuples (u64; the 32-bit path narrows them).  Returns count or <0. */
 int64_t ok_sketch_records(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq,

@@ -70,6 +70,7 @@ static int usage()
             "  ref_driver param K S L\n"
             "  ref_driver shuffle K S L out.shuf\n"
             "  ref_driver kseq FILE...        (records as the reference's kseq_read loop sees them)\n"
+            "  ref_driver basemap             (the BaseMap table of src/common.h)\n"
             "  ref_driver alldist WORKDIR in.sketch OUT maxDist isContainment threads\n"
             "  ref_driver tridist WORKDIR in.sketch OUT maxDist threads\n"
             "  ref_driver dist WORKDIR ref.sketch qry.sketch OUT maxDist maxNeighbor isNeighbor "
@@ -109,6 +110,10 @@ int main(int argc, char **argv)
         st.drlevel = atoi(argv[4]);
         st.id = 0;
         write_shuffle_dim_file(&st, argv[5]);
+        return 0;
+    }
+    if (cmd == "basemap" && argc == 2) {  // the reference's base coding table, src/common.h:27-37
+        for (int c = 0; c < 128; c++) printf("%d%c", BaseMap[c], c == 127 ? '\n' : ' ');
         return 0;
     }
     if (cmd == "kseq" && argc >= 3) {

@@ -62,6 +62,9 @@ def main():
         "# file\trecords\tbases\tfnv1a(sequence bytes)\tfnv1a(quality bytes, '~' where a record has none)\trecord end offsets...\n"
         "# produced by the reference's own kseq.h through oracle/_ref/ref_driver kseq (tests/golden/make_kseq_golden.py)\n" + out)
     print(out)
+    # the reference's base coding table (src/common.h:27-37)
+    bm = subprocess.run([DRIVER, "basemap"], check=True, stdout=subprocess.PIPE).stdout.decode()
+    open(os.path.join(HERE, "basemap.txt"), "w").write(bm)
 
 
 if __name__ == "__main__":

@@ -103,6 +103,15 @@ def _fnv(data):
     return "%016x" % h
 
 
+def test_base_code_matches_reference_basemap():
+    # tests/golden/basemap.txt: the BaseMap[128] table of src/common.h printed by oracle/_ref/ref_driver basemap
+    want = [int(x) for x in open(os.path.join(GOLDEN, "basemap.txt")).read().split()]
+    assert len(want) == 128 and sorted(set(want)) == [-1, 0, 1, 2, 3]
+    L = ok.lib()
+    assert [L.ok_base_code(c) for c in range(128)] == want
+    assert all(L.ok_base_code(c) == -1 for c in range(128, 256))
+
+
 def test_record_reader_restatement_matches_the_real_kseq():
     """S0 pinned: tests/golden/kseq/expected.tsv holds what the reference's own kseq.h returned (via
     oracle/_ref/ref_driver kseq) for 29 inputs; the C restatement must agree on records, bases,
