@@ -10,6 +10,7 @@
 //
 // sketch.cpp (sketchFastaFile/transSketches/readSketches) needs the un-vendored RabbitFX
 // submodule and is NOT built; .sketch/.dict/.index inputs are produced by the oracle.
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,6 +72,7 @@ static int usage()
             "  ref_driver shuffle K S L out.shuf\n"
             "  ref_driver kseq FILE...        (records as the reference's kseq_read loop sees them)\n"
             "  ref_driver basemap             (the BaseMap table of src/common.h)\n"
+            "  ref_driver layout              (sizeof/offsetof of the structs written to disk)\n"
             "  ref_driver alldist WORKDIR in.sketch OUT maxDist isContainment threads\n"
             "  ref_driver tridist WORKDIR in.sketch OUT maxDist threads\n"
             "  ref_driver dist WORKDIR ref.sketch qry.sketch OUT maxDist maxNeighbor isNeighbor "
@@ -110,6 +112,17 @@ int main(int argc, char **argv)
         st.drlevel = atoi(argv[4]);
         st.id = 0;
         write_shuffle_dim_file(&st, argv[5]);
+        return 0;
+    }
+    if (cmd == "layout" && argc == 2) {  // the structs the reference fwrite()s: name size offsets...
+        printf("sketchInfo_t %zu %zu %zu %zu %zu %zu\n", sizeof(sketchInfo_t), offsetof(sketchInfo_t, id),
+               offsetof(sketchInfo_t, half_k), offsetof(sketchInfo_t, half_subk), offsetof(sketchInfo_t, drlevel),
+               offsetof(sketchInfo_t, genomeNumber));
+        printf("dim_shuffle_stat_t %zu %zu %zu %zu %zu\n", sizeof(dim_shuffle_stat_t), offsetof(dim_shuffle_stat_t, id),
+               offsetof(dim_shuffle_stat_t, k), offsetof(dim_shuffle_stat_t, subk), offsetof(dim_shuffle_stat_t, drlevel));
+        printf("co_dstat_t %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(co_dstat_t), offsetof(co_dstat_t, shuf_id),
+               offsetof(co_dstat_t, koc), offsetof(co_dstat_t, kmerlen), offsetof(co_dstat_t, dim_rd_len),
+               offsetof(co_dstat_t, comp_num), offsetof(co_dstat_t, infile_num), offsetof(co_dstat_t, all_ctx_ct));
         return 0;
     }
     if (cmd == "basemap" && argc == 2) {  // the reference's base coding table, src/common.h:27-37

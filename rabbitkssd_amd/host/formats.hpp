@@ -54,6 +54,9 @@ inline bool exist_file(const std::string &f)
 }
 
 // ---- .shuf (src/shuffle.cpp:8-23, :25-104) -------------------------------------------
+struct ShufHeader {  // dim_shuffle_stat_t, src/shuffle.h:11-17 (16 bytes on disk)
+    int32_t id = 0, k = 0, subk = 0, drlevel = 0;
+};
 struct Shuf {
     int32_t id = 0, k = 0, subk = 0, drlevel = 0;
     std::vector<int32_t> table;
@@ -63,13 +66,13 @@ inline bool read_shuf(const std::string &path, Shuf &out, std::string &err)
 {
     FILE *fp = fopen(path.c_str(), "rb");
     if (!fp) { err = "cannot read shuffle file: " + path; return false; }
-    int32_t hdr[4];
-    if (fread(hdr, sizeof(hdr), 1, fp) != 1 || hdr[2] < 1 || hdr[2] >= 8) {
+    ShufHeader hdr;
+    if (fread(&hdr, sizeof(hdr), 1, fp) != 1 || hdr.subk < 1 || hdr.subk >= 8) {
         fclose(fp);
         err = "error read dim_shuffle header: " + path;
         return false;
     }
-    out.id = hdr[0]; out.k = hdr[1]; out.subk = hdr[2]; out.drlevel = hdr[3];
+    out.id = hdr.id; out.k = hdr.k; out.subk = hdr.subk; out.drlevel = hdr.drlevel;
     const size_t n = (size_t)1 << (4 * out.subk);
     out.table.resize(n);
     const size_t r = fread(out.table.data(), 4, n, fp);
@@ -99,8 +102,9 @@ inline bool write_shuf(const std::string &path, int k, int subk, int drlevel, st
     }
     FILE *fp = fopen(path.c_str(), "wb");
     if (!fp) { err = "error open shuffle file " + path; return false; }
-    const int32_t hdr[4] = {id, k, subk, drlevel};
-    fwrite(hdr, sizeof(hdr), 1, fp);
+    ShufHeader hdr;
+    hdr.id = id; hdr.k = k; hdr.subk = subk; hdr.drlevel = drlevel;
+    fwrite(&hdr, sizeof(hdr), 1, fp);
     fwrite(t.data(), 4, (size_t)n, fp);
     fclose(fp);
     return true;

@@ -974,6 +974,16 @@ int main(int argc, char **argv)
         {"-F", "F"}, {"--Fined", "F"}, {"--device", "device"}, {"--query", "q"}, {"-q", "q"},
         {"--reverse", "reverse"}, {"--rs", "rs"}, {"--qs", "qs"}};
     if (sub == "_parse") return cmd_parse(argc, argv);
+    if (sub == "_layout") {  // test helper: the on-disk structs of this tool, in the format of `ref_driver layout`
+        printf("sketchInfo_t %zu %zu %zu %zu %zu %zu\n", sizeof(SketchInfo), offsetof(SketchInfo, id), offsetof(SketchInfo, half_k),
+               offsetof(SketchInfo, half_subk), offsetof(SketchInfo, drlevel), offsetof(SketchInfo, genomeNumber));
+        printf("dim_shuffle_stat_t %zu %zu %zu %zu %zu\n", sizeof(ShufHeader), offsetof(ShufHeader, id), offsetof(ShufHeader, k),
+               offsetof(ShufHeader, subk), offsetof(ShufHeader, drlevel));
+        printf("co_dstat_t %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(CoDstat), offsetof(CoDstat, shuf_id), offsetof(CoDstat, koc),
+               offsetof(CoDstat, kmerlen), offsetof(CoDstat, dim_rd_len), offsetof(CoDstat, comp_num), offsetof(CoDstat, infile_num),
+               offsetof(CoDstat, all_ctx_ct));
+        return 0;
+    }
     if (sub == "shuffle") { cerr << "-----run the subcommand: shuffle" << endl; return cmd_shuffle(parse_args(argc, argv, 2, alias, {})); }
     if (sub == "sketch") { cerr << "-----run the subcommand: sketch" << endl; return cmd_sketch(parse_args(argc, argv, 2, alias, {"q"})); }
     if (sub == "alldist") { cerr << "-----run the subcommand: alldist" << endl; return cmd_alldist(parse_args(argc, argv, 2, alias, {})); }

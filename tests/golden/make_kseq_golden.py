@@ -50,12 +50,12 @@ def main():
         open(os.path.join(OUT, name), "wb").write(data)
         names.append(name)
     # gzip'd inputs: one member, and two concatenated members (gzread continues into the second)
-    with gzip.open(os.path.join(OUT, "two_records.fa.gz"), "wb") as f:
-        f.write(CASES["two_records.fa"])
+    with open(os.path.join(OUT, "two_records.fa.gz"), "wb") as f:   # mtime=0: reproducible bytes
+        f.write(gzip.compress(CASES["two_records.fa"], mtime=0))
     names.append("two_records.fa.gz")
     with open(os.path.join(OUT, "two_members.fa.gz"), "wb") as f:
-        f.write(gzip.compress(b">a\nACGT\nAC"))
-        f.write(gzip.compress(b"GT\n>b\nTTTT\n"))
+        f.write(gzip.compress(b">a\nACGT\nAC", mtime=0))
+        f.write(gzip.compress(b"GT\n>b\nTTTT\n", mtime=0))
     names.append("two_members.fa.gz")
     out = subprocess.run([DRIVER, "kseq"] + names, cwd=OUT, check=True, stdout=subprocess.PIPE).stdout.decode()
     open(os.path.join(OUT, "expected.tsv"), "w").write(
@@ -65,6 +65,9 @@ def main():
     # the reference's base coding table (src/common.h:27-37)
     bm = subprocess.run([DRIVER, "basemap"], check=True, stdout=subprocess.PIPE).stdout.decode()
     open(os.path.join(HERE, "basemap.txt"), "w").write(bm)
+    # sizeof / offsetof of the structs the reference writes to disk (sketch.h, shuffle.h)
+    lay = subprocess.run([DRIVER, "layout"], check=True, stdout=subprocess.PIPE).stdout.decode()
+    open(os.path.join(HERE, "layout.txt"), "w").write(lay)
 
 
 if __name__ == "__main__":

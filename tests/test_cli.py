@@ -71,6 +71,14 @@ def test_record_reader_edge_cases(tmp_path):
         assert [int(x) for x in cols[5:]] == [int(x) for x in off[1:]], name
 
 
+def test_on_disk_structs_match_the_reference_headers():
+    # tests/golden/layout.txt: sizeof / offsetof of sketchInfo_t, dim_shuffle_stat_t, co_dstat_t taken from the
+    # reference's own headers (oracle/_ref/ref_driver layout)
+    want = open(os.path.join(GOLDEN, "layout.txt")).read()
+    assert run(["_layout"]).stdout.decode() == want
+    assert want.splitlines()[0].split()[:2] == ["sketchInfo_t", "20"]
+
+
 def test_record_reader_matches_the_real_kseq(tmp_path):
     """tests/golden/kseq/expected.tsv was written by the reference's own kseq.h (src/kseq.h, looped like
     src/sketch.cpp:462-479) through oracle/_ref/ref_driver kseq: records, bases, sequence bytes, quality
