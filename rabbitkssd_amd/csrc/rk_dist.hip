@@ -155,10 +155,10 @@ __device__ unsigned long long g_prof[kProfWaves][16];  // one row per wave, summ
 // into the cell list | barrier | evaluate the cells.  Three barriers; the evaluation of unit u
 // overlaps the zeroing and scattering of unit u+1 in the faster waves (cell counters alternate).
 //
-// THREADS: a counter row of N columns occupies 2N (U16) or 4N bytes of the CU's 160 KiB, which
-// caps the resident workgroups; bigger rows get bigger workgroups so that the CU keeps 16-32
-// waves to hide the gather latency (measured at 28,284 / 50,000 columns: 512 / 1024 threads are
-// 1.25x / 1.9x faster than 256).
+// THREADS (256, 512, 768, 1024): a counter row of N columns occupies 2N (U16) or 4N bytes of the
+// CU's 160 KiB, which caps the resident workgroups; bigger rows get bigger workgroups so that the
+// CU keeps 16-28 waves to hide the gather latency (measured at 28,284 / 50,000 columns: 768 / 1024
+// threads are 1.8x / 2.2x faster than 256).
 enum { kFiltered = 0, kSelf = 1, kSelfPair = 2 };
 
 template <bool U16, int MODE, int THREADS>
@@ -676,10 +676,11 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     p->units_per_wg = p->persist ? 1 : envu("RK_DIST_ROWS", p->mode == kSelfPair ? 1 : 2);
     // workgroup size by row size: 7 x 256 threads fit up to ~22 KiB rows; bigger rows leave room for
     // fewer workgroups, which then need more waves each
-    p->threads = p->lds_bytes <= 24 * 1024 ? 256 : (p->lds_bytes <= 64 * 1024 ? 512 : 1024);
+    // 7 workgroups per CU: 4 waves each; 3: 8 waves; 2: 12 waves; 1: 16 waves (measured)
+    p->threads = p->lds_bytes <= 24 * 1024 ? 256 : (p->lds_bytes <= 53 * 1024 ? 512 : (p->lds_bytes <= 80 * 1024 ? 768 : 1024));
     if (p->mode == kSelfPair && p->threads == 256) p->threads = 512;  // two rows' slices per unit: measured better
     const uint32_t forced = envu("RK_DIST_THREADS", 0);
-    if (forced == 256 || forced == 512 || forced == 1024) p->threads = forced;
+    if (forced == 256 || forced == 512 || forced == 1024 || forced == 768) p->threads = forced;
     // does a pair with distance exactly 1.0 (common == 0) pass the threshold?
     p->dense_mode = o->triangle ? (1.0 < o->max_dist) : (1.0 <= o->max_dist);
     return RK_OK;
@@ -734,6 +735,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
                          : (p.mode == kSelf ? rk_dist_kernel<U, kSelf, T> : rk_dist_kernel<U, kFiltered, T>))
 #define RK_PICK(T) (p.u16 ? RK_PICK3(true, T) : RK_PICK3(false, T))
     if (p.threads == 256) kern = RK_PICK(256);
+    else if (p.threads == 768) kern = RK_PICK(768);
     else if (p.threads == 512) kern = RK_PICK(512);
     else kern = RK_PICK(1024);
 #undef RK_PICK
