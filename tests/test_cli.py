@@ -190,6 +190,41 @@ def test_cli_sketch_alldist_dist_end_to_end(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_sketch_streaming_pipeline_many_batches_and_a_big_file(tmp_path):
+    """the tool's sketch pipeline beyond one batch: 36 genomes of 5 Mb (several page-locked staging batches,
+    parser threads and the GPU thread overlapping) plus one 70 Mb genome of 7 records, which is read and parsed
+    by all threads and staged in ordinary memory; every hash set must equal the oracle's"""
+    from rabbitkssd_amd import synth
+    k, s, l = 10, 6, 3
+    shuf = tmp_path / "L3K10.shuf"
+    run(["shuffle", "-k", k, "-s", s, "-l", l, "-o", shuf])
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    files, seqs = [], []
+    for name, bases in synth.clade_genome_set(36, 5_000_000):
+        p = tmp_path / (name.replace("/", "_") + ".fa")
+        p.write_bytes(synth.fasta_text(name, bases))
+        files.append(str(p))
+        seqs.append([bases])
+    big = [synth.clade_genome(900 + r, 0, 10_000_000) for r in range(7)]      # 7 records of 10 Mb
+    p = tmp_path / "big.fa"
+    p.write_bytes(b"".join(synth.fasta_text("chr%d" % r, b, width=60) for r, b in enumerate(big)))
+    assert p.stat().st_size > (64 << 20)
+    files.insert(17, str(p))
+    seqs.insert(17, big)
+    lst = tmp_path / "g.list"
+    lst.write_text("".join(f + "\n" for f in files))
+    run(["sketch", "-i", lst, "-L", shuf, "-o", tmp_path / "g", "-t", 8], cwd=tmp_path)
+    info, names, h, off = ok.read_sketches32(str(tmp_path / "g.sketch"))
+    assert names == files and info.genomeNumber == len(files)
+    for g in (0, 5, 16, 17, 18, 36):
+        recs = seqs[g]
+        seq = np.concatenate(recs)
+        rec_off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+        want = ok.sketch_records(param, table, seq, rec_off)
+        assert np.array_equal(h[int(off[g]):int(off[g + 1])].astype(np.uint64), want), g
+
+
+@pytest.mark.gpu
 def test_cli_dist_matches_reference_text(tmp_path):
     d = os.path.join(GOLDEN, "dist")
     man = json.load(open(os.path.join(d, "manifest.json")))
