@@ -225,6 +225,43 @@ def test_cli_sketch_streaming_pipeline_many_batches_and_a_big_file(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_sketch_gzip_inputs_incl_multi_member(tmp_path):
+    """.gz genomes in the streaming pipeline: a single-member file (its trailer gives the slot size) and a
+    three-member file whose trailer understates the size -- the slot overflows and the genome takes the
+    whole-file path, spliced back in list order"""
+    import gzip
+    from rabbitkssd_amd import synth
+    k, s, l = 10, 6, 3
+    shuf = tmp_path / "L3K10.shuf"
+    run(["shuffle", "-k", k, "-s", s, "-l", l, "-o", shuf])
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    genomes = synth.clade_genome_set(5, 1_500_000)
+    files = []
+    for i, (name, bases) in enumerate(genomes):
+        text = synth.fasta_text(name, bases)
+        if i == 1:
+            p = tmp_path / (name + ".fa.gz")
+            p.write_bytes(gzip.compress(text, mtime=0))
+        elif i == 3:  # three members; the last one is the smallest
+            p = tmp_path / (name + ".fa.gz")
+            cut1, cut2 = len(text) // 2, len(text) - 1000
+            p.write_bytes(gzip.compress(text[:cut1], mtime=0) + gzip.compress(text[cut1:cut2], mtime=0) +
+                          gzip.compress(text[cut2:], mtime=0))
+        else:
+            p = tmp_path / (name + ".fa")
+            p.write_bytes(text)
+        files.append(str(p))
+    lst = tmp_path / "g.list"
+    lst.write_text("".join(f + "\n" for f in files))
+    run(["sketch", "-i", lst, "-L", shuf, "-o", tmp_path / "g", "-t", 4], cwd=tmp_path)
+    info, names, h, off = ok.read_sketches32(str(tmp_path / "g.sketch"))
+    assert names == files
+    for g, (name, bases) in enumerate(genomes):
+        want = ok.sketch_records(param, table, bases, np.array([0, len(bases)], dtype=np.uint64))
+        assert np.array_equal(h[int(off[g]):int(off[g + 1])].astype(np.uint64), want), g
+
+
+@pytest.mark.gpu
 def test_cli_dist_matches_reference_text(tmp_path):
     d = os.path.join(GOLDEN, "dist")
     man = json.load(open(os.path.join(d, "manifest.json")))
