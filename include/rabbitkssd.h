@@ -76,7 +76,12 @@ typedef struct rk_hit {
 /* ---- context ------------------------------------------------------------------- */
 int rk_device_count(void);
 int rk_ctx_create(int device, rk_ctx **out);
+/* Objects (rk_filter, rk_sketches, rk_index) must be freed before the context they were created on. */
 void rk_ctx_destroy(rk_ctx *ctx);
+/* Device memory released by the library's objects and temporaries is cached in the context and handed out
+ * again (steady-state calls allocate nothing: hipMalloc/hipFree cost 50-300 us each and hipFree synchronises the
+ * device); rk_ctx_trim returns the cached blocks to the driver. */
+void rk_ctx_trim(rk_ctx *ctx);
 const char *rk_last_error(const rk_ctx *ctx);
 const char *rk_version(void);
 void rk_free_host(void *p);

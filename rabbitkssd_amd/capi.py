@@ -3,6 +3,7 @@
 This is plumbing only: every call goes through the C ABI into the HIP kernels.  There is
 no Python or CPU fallback -- a missing library or a missing GPU raises."""
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -15,7 +16,7 @@ HIT_DTYPE = np.dtype([("row", "<u4"), ("col", "<u4"), ("common", "<i4"), ("size0
                       ("size1", "<i4"), ("pad", "<i4"), ("jorc", "<f8"), ("dist", "<f8")])
 
 EXPORTS = [
-    "rk_device_count", "rk_ctx_create", "rk_ctx_destroy", "rk_last_error", "rk_version",
+    "rk_device_count", "rk_ctx_create", "rk_ctx_destroy", "rk_ctx_trim", "rk_last_error", "rk_version",
     "rk_free_host", "rk_pinned_alloc", "rk_pinned_free", "rk_dev_alloc", "rk_dev_free", "rk_stream_create",
     "rk_stream_destroy", "rk_stream_sync", "rk_upload_async", "rk_params_init", "rk_hash_bits", "rk_filter_create", "rk_filter_free",
     "rk_sketch_batch", "rk_sketch_batch_ex", "rk_sketch_packed_dev", "rk_sketch_packed_dev_ex", "rk_pack_layout", "rk_pack_genomes",
@@ -65,6 +66,7 @@ def lib():
         L.rk_version.restype = C.c_char_p
         L.rk_free_host.argtypes = [C.c_void_p]
         L.rk_ctx_destroy.argtypes = [C.c_void_p]
+        L.rk_ctx_trim.argtypes = [C.c_void_p]
         for f in ("rk_filter_free", "rk_sketches_free", "rk_index_free"):
             getattr(L, f).argtypes = [C.c_void_p]
         for f in ("rk_sketches_total", "rk_sketches_windows", "rk_index_total", "rk_index_distinct",
@@ -106,11 +108,18 @@ class Context:
         if rc:
             raise RkError(rc, "rk_ctx_create(device=%d) failed -- a GPU is required" % device)
         self.device = device
+        self._objects = weakref.WeakSet()  # library objects must be freed before their context
 
     def close(self):
         if self._h:
+            for o in list(self._objects):
+                o.close()
             lib().rk_ctx_destroy(self._h)
             self._h = C.c_void_p()
+
+    def trim(self):
+        """returns the device memory cached by the context's allocator to the driver"""
+        lib().rk_ctx_trim(self._h)
 
     def __del__(self):
         try:
@@ -246,10 +255,12 @@ class _Obj:
 
     def __init__(self, ctx, h):
         self.ctx, self._h = ctx, h
+        ctx._objects.add(self)
 
     def close(self):
         if self._h:
-            getattr(lib(), self._free)(self._h)
+            if self.ctx._h:  # a destroyed context has already released the device memory
+                getattr(lib(), self._free)(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

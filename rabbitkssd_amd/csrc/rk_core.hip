@@ -16,6 +16,85 @@ int rk_fail(rk_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
+// ---- caching device allocator ----------------------------------------------------------------------
+static size_t pool_round(size_t bytes)
+{
+    if (bytes <= (1u << 16)) return (bytes + 511) & ~(size_t)511;
+    if (bytes <= (1u << 24)) return (bytes + 65535) & ~(size_t)65535;
+    return (bytes + ((1u << 21) - 1)) & ~(size_t)((1u << 21) - 1);
+}
+
+void *rk_pool_alloc(rk_ctx *ctx, size_t bytes)
+{
+    const size_t want = pool_round(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->free_blocks.lower_bound(want);
+        // best fit, but never hand a block far bigger than the request (it would be missing when its own size is asked for)
+        if (it != ctx->free_blocks.end() && (it->first <= 2 * want || it->first <= (1u << 16))) {
+            void *p = it->second;
+            ctx->free_blocks.erase(it);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        rk_ctx_trim(ctx);  // give cached blocks back and try once more
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->live[p] = want;
+    ctx->pool_bytes += want;
+    return p;
+}
+
+void rk_pool_free(rk_ctx *ctx, void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->live.find(p);
+    if (it == ctx->live.end()) {  // not from this pool
+        (void)hipFree(p);
+        return;
+    }
+    ctx->free_blocks.emplace(it->second, p);
+}
+
+int rk_read_back(rk_ctx *ctx, void *dst, const void *src_dev, size_t bytes, hipStream_t stream)
+{
+    if (bytes <= kPinnedBytes && ctx->pinned) {
+        RK_HIP(ctx, hipMemcpyAsync(ctx->pinned, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+        RK_HIP(ctx, hipStreamSynchronize(stream));
+        memcpy(dst, ctx->pinned, bytes);
+    } else {
+        RK_HIP(ctx, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+        RK_HIP(ctx, hipStreamSynchronize(stream));
+    }
+    return RK_OK;
+}
+
+int rk_occupancy(rk_ctx *ctx, const void *kernel, int threads, size_t lds_bytes)
+{
+    const auto key = std::make_tuple(kernel, threads, lds_bytes);
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->occupancy.find(key);
+        if (it != ctx->occupancy.end()) return it->second;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->occupancy[key] = per_cu;
+    return per_cu;
+}
+
 extern "C" {
 
 const char *rk_version(void) { return "rabbitkssd-amd 0.1.0 (gfx950)"; }
@@ -27,6 +106,12 @@ int rk_device_count(void)
     return n;
 }
 
+static uint32_t env_u32(const char *name, uint32_t dflt)
+{
+    const char *v = getenv(name);
+    return v && atoi(v) > 0 ? (uint32_t)atoi(v) : dflt;
+}
+
 int rk_ctx_create(int device, rk_ctx **out)
 {
     if (!out) return RK_ERR_ARG;
@@ -35,22 +120,66 @@ int rk_ctx_create(int device, rk_ctx **out)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RK_ERR_NO_DEVICE;
     if (device < 0 || device >= n) return RK_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return RK_ERR_HIP;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RK_ERR_HIP;
     rk_ctx *ctx = new (std::nothrow) rk_ctx;
     if (!ctx) return RK_ERR_NOMEM;
     ctx->device = device;
-    ctx->num_cu = prop.multiProcessorCount;
-    ctx->max_lds = prop.sharedMemPerBlock;  // 64 KiB by default; larger via opt-in attribute
-    int optin = 0;
-    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess &&
-        (size_t)optin > ctx->max_lds)
-        ctx->max_lds = (size_t)optin;
+    // single attributes instead of hipGetDeviceProperties (which fills ~100 fields, some of them slow to query)
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) {
+        delete ctx;
+        return RK_ERR_HIP;
+    }
+    ctx->num_cu = v;
+    ctx->max_lds = 64 * 1024;  // default limit; larger via opt-in attribute
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0)
+        ctx->max_lds = (size_t)v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess &&
+        (size_t)v > ctx->max_lds)
+        ctx->max_lds = (size_t)v;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc(&ctx->pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) {
+        rk_ctx_destroy(ctx);
+        return RK_ERR_HIP;
+    }
+    ctx->sw_dist_threads = env_u32("RK_DIST_THREADS", 0);
+    ctx->sw_dist_rows = env_u32("RK_DIST_ROWS", 0);
+    ctx->sw_dist_pair = env_u32("RK_DIST_PAIR", 1);
+    ctx->sw_dist_pair_minwg = env_u32("RK_DIST_PAIR_MINWG", 3);
+    ctx->sw_dist_persist = env_u32("RK_DIST_PERSIST", 1);
+    ctx->sw_dist_cand_cap = env_u32("RK_DIST_CAND_CAP", 0);
+    ctx->sw_dist_stage_hits = env_u32("RK_DIST_STAGE_HITS", 0);
+    ctx->sw_dist_xcd_rows = env_u32("RK_DIST_XCD_ROWS", 0);
     *out = ctx;
     return RK_OK;
 }
 
-void rk_ctx_destroy(rk_ctx *ctx) { delete ctx; }
+void rk_ctx_trim(rk_ctx *ctx)
+{
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    for (auto &b : ctx->free_blocks) {
+        ctx->live.erase(b.second);
+        ctx->pool_bytes -= b.first;
+        (void)hipFree(b.second);
+    }
+    ctx->free_blocks.clear();
+}
+
+void rk_ctx_destroy(rk_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    rk_ctx_trim(ctx);
+    // blocks still handed out belong to objects the caller has not freed: they are released with the context
+    for (auto &b : ctx->live) (void)hipFree(b.first);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    delete ctx;
+}
 
 const char *rk_last_error(const rk_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 

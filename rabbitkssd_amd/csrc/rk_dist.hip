@@ -12,7 +12,7 @@
 // containment/AafD) formula in FP64 one cell per lane; reported pairs are staged in LDS and flushed
 // with one device-scope atomic per workgroup.
 // Integer/index work: bound by LDS atomics, L1 tag lookups and latency -- no MFMA.
-// Developer switches (environment, read per launch): RK_DIST_THREADS=256|512|1024, RK_DIST_ROWS=<units
+// Developer switches (environment, read once when the context is created): RK_DIST_THREADS=256|512|1024, RK_DIST_ROWS=<units
 // per workgroup, non-persistent>, RK_DIST_PAIR=2 (no row pairs), RK_DIST_PAIR_MINWG, RK_DIST_PERSIST=2
 // (one run per workgroup), RK_DIST_CAND_CAP, RK_DIST_STAGE_HITS, RK_DIST_XCD_ROWS.
 #include <algorithm>
@@ -23,6 +23,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "rk_internal.h"
+#include "rk_dist_common.h"
 
 namespace {
 
@@ -59,48 +60,6 @@ struct DistArgs {
     unsigned long long cap;
     unsigned long long *n_hits;
     int32_t *common_dense;      // optional [n_query, n_ref]
-};
-
-// D3/D4: src/dist.cpp:218-231 and :238-250, FP64, same operation order.
-// noinline: one copy of the FP64 divide + log sequence (~600 instructions) instead of one per call
-// site keeps the kernel inside the instruction cache; the pair is returned in registers
-struct JorcDist {
-    double jorc, dist;
-};
-__device__ __noinline__ JorcDist rk_distance(int common, int size0, int size1, int metric, int kmer_size)
-{
-    JorcDist r;
-    if (!metric) {
-        const int denom = size0 + size1 - common;
-        double j = (size0 == 0 || size1 == 0) ? 0.0 : (double)common / (double)denom;
-        double d;
-        if (j == 1.0) d = 0.0;
-        else if (j == 0.0) d = 1.0;
-        else d = (-1.0 / (double)kmer_size) * log((2 * j) / (1.0 + j));
-        r.jorc = j;
-        r.dist = d;
-    } else {
-        const int denom = size0 < size1 ? size0 : size1;
-        double c = (size0 == 0 || size1 == 0) ? 0.0 : (double)common / (double)denom;
-        double d;
-        if (c == 1.0) d = 0.0;
-        else if (c == 0.0) d = 1.0;
-        else d = (-1.0 / (double)kmer_size) * log(c);
-        r.jorc = c;
-        r.dist = d;
-    }
-    return r;
-}
-
-// value held by lane J of the same quad (DPP quad_perm:[J,J,J,J]: full-rate VALU, no LDS)
-template <int J> __device__ inline uint32_t quad_bcast(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, J * 0x55, 0xF, 0xF, true);
-}
-
-// two consecutive postings; dword-aligned only (a slice starts anywhere)
-struct __attribute__((packed, aligned(4))) PostingPair {
-    uint32_t x, y;
 };
 
 #ifdef RK_DIST_PROFILE
@@ -602,12 +561,6 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         if (at0 + i / kW < a.cap) dst[at0 * kW + i] = src[i];
 }
 
-inline uint32_t envu(const char *name, uint32_t dflt)
-{
-    const char *v = getenv(name);
-    return v && atoi(v) > 0 ? (uint32_t)atoi(v) : dflt;
-}
-
 struct Plan {
     uint32_t n_units, tile_cols, n_tiles, cnt_words, row_words;
     uint32_t cand_cap, stage_hits, units_per_wg, threads;
@@ -623,18 +576,19 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
               const rk_dist_opts *o, bool want_self, Plan *p)
 {
     if (o->kmer_size <= 0) return rk_fail(ctx, RK_ERR_ARG, "kmer_size must be positive");
-    if (o->metric != 0 && o->metric != 1) return rk_fail(ctx, RK_ERR_ARG, "metric must be 0 or 1");
     if (o->row_block < 0) return rk_fail(ctx, RK_ERR_ARG, "row_block must be >= 0");
     // counter row in LDS; tile the reference range when it does not fit
-    p->u16 = max_query_size < 65536;
-    p->cand_cap = (envu("RK_DIST_CAND_CAP", kCandCapDefault) + 1) & ~1u;
+    // two 16-bit counters per word when no count can overflow: a count never exceeds the query sketch as long as
+    // no genome sits twice in a posting list (sketches with repeated hashes fall back to 32-bit counters)
+    p->u16 = idx->ref_sets && max_query_size < 65536;
+    p->cand_cap = ((ctx->sw_dist_cand_cap ? ctx->sw_dist_cand_cap : kCandCapDefault) + 1) & ~1u;
     // Persistent workgroups (one tile, >= 512 threads: with 256-thread workgroups one run of two rows
     // per workgroup measured better, 0.134 vs 0.145 ms) live long, so they stage more hits before the
     // one flush at their end.  Capacity decisions below assume the bigger staging area.
     const uint64_t one_row = (uint64_t)idx->n_ref * (p->u16 ? 2 : 4);
     const bool small_rows = one_row + (size_t)p->cand_cap * sizeof(uint2) + kStageHitsDefault * sizeof(rk_hit) + 64 <= 24 * 1024;
-    p->persist = idx->n_ref && envu("RK_DIST_PERSIST", 1) != 2;
-    p->stage_hits = envu("RK_DIST_STAGE_HITS", 4 * kStageHitsDefault);
+    p->persist = idx->n_ref && ctx->sw_dist_persist != 2;
+    p->stage_hits = ctx->sw_dist_stage_hits ? ctx->sw_dist_stage_hits : 4 * kStageHitsDefault;
     size_t fixed = (size_t)p->cand_cap * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
     const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - fixed;
     const uint32_t max_cols = (uint32_t)(p->u16 ? lds_cap / 2 : lds_cap / 4) & ~63u;
@@ -656,9 +610,10 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // pairs of neighbouring rows: blocks must hold whole pairs and two rows must fit in LDS next to
     // each other with room for at least three workgroups per CU (measured: with fewer, the lost
     // occupancy costs more than the saved walks: 14,142 columns 0.127 ms paired vs 0.113 single)
-    const bool pair_ok = p->mode == kSelf && p->row_block % 2 == 0 && idx->d_self_split &&
-                         (size_t)p->row_words * 8 + fixed <= lds_cap / envu("RK_DIST_PAIR_MINWG", 3) &&
-                         envu("RK_DIST_PAIR", 1) != 2;
+    // (pairs rest on set semantics: with a repeated hash inside a genome the "covered" test of the index build fails)
+    const bool pair_ok = p->mode == kSelf && p->row_block % 2 == 0 && idx->d_self_split && idx->ref_sets &&
+                         (size_t)p->row_words * 8 + fixed <= lds_cap / ctx->sw_dist_pair_minwg &&
+                         ctx->sw_dist_pair != 2;
     if (pair_ok) p->mode = kSelfPair;
     const uint32_t unit_rows = p->mode == kSelfPair ? 2 : 1;
     p->units_per_block = p->row_block / unit_rows;
@@ -668,21 +623,21 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     p->cnt_words = p->row_words * unit_rows;
     if (p->mode != kSelfPair && small_rows) {  // 7 workgroups of 256 threads per CU, not persistent
         p->persist = false;
-        p->stage_hits = envu("RK_DIST_STAGE_HITS", kStageHitsDefault);
+        p->stage_hits = ctx->sw_dist_stage_hits ? ctx->sw_dist_stage_hits : kStageHitsDefault;
         fixed = (size_t)p->cand_cap * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
     }
     p->lds_bytes = (size_t)p->cnt_words * 4 + fixed;
     p->persist = p->persist && p->n_tiles == 1;
-    p->units_per_wg = p->persist ? 1 : envu("RK_DIST_ROWS", p->mode == kSelfPair ? 1 : 2);
+    p->units_per_wg = p->persist ? 1 : (ctx->sw_dist_rows ? ctx->sw_dist_rows : (p->mode == kSelfPair ? 1u : 2u));
     // workgroup size by row size: 7 x 256 threads fit up to ~22 KiB rows; bigger rows leave room for
     // fewer workgroups, which then need more waves each
     // 7 workgroups per CU: 4 waves each; 3: 8 waves; 2: 12 waves; 1: 16 waves (measured)
     p->threads = p->lds_bytes <= 24 * 1024 ? 256 : (p->lds_bytes <= 53 * 1024 ? 512 : (p->lds_bytes <= 80 * 1024 ? 768 : 1024));
     if (p->mode == kSelfPair && p->threads == 256) p->threads = 512;  // two rows' slices per unit: measured better
-    const uint32_t forced = envu("RK_DIST_THREADS", 0);
+    const uint32_t forced = ctx->sw_dist_threads;
     if (forced == 256 || forced == 512 || forced == 1024 || forced == 768) p->threads = forced;
     // does a pair with distance exactly 1.0 (common == 0) pass the threshold?
-    p->dense_mode = o->triangle ? (1.0 < o->max_dist) : (1.0 <= o->max_dist);
+    p->dense_mode = rk_dense_mode(o) ? 1 : 0;
     return RK_OK;
 }
 
@@ -709,7 +664,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.cnt_words = p.cnt_words;
     a.pair_stride = p.row_words * (p.u16 ? 2 : 1);
     a.triangle = o->triangle;
-    a.metric = o->metric;
+    a.metric = o->metric != 0;  // the reference treats any non-zero isContainment as containment
     a.kmer_size = o->kmer_size;
     a.dense_mode = p.dense_mode;
     a.max_dist = o->max_dist;
@@ -718,7 +673,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.min_jorc = 0.0;
     if (!p.dense_mode && o->max_dist > 0.0) {
         const double t = exp(-(double)o->kmer_size * o->max_dist);
-        a.min_jorc = (o->metric ? t : t / (2.0 - t)) * (1.0 - 1e-6);
+        a.min_jorc = (a.metric ? t : t / (2.0 - t)) * (1.0 - 1e-6);
     }
     a.hits = hits_dev;
     a.cap = cap;
@@ -726,7 +681,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.common_dense = dense_dev;
     a.units_per_wg = p.units_per_wg;
     const uint32_t unit_rows = p.mode == kSelfPair ? 2 : 1;
-    a.runs_per_chunk = std::max<uint32_t>(1, envu("RK_DIST_XCD_ROWS", kRowsPerXcdChunk) / (p.units_per_wg * unit_rows));
+    a.runs_per_chunk = std::max<uint32_t>(1, (ctx->sw_dist_xcd_rows ? ctx->sw_dist_xcd_rows : kRowsPerXcdChunk) / (p.units_per_wg * unit_rows));
     a.cand_cap = p.cand_cap;
     a.stage_hits = p.stage_hits;
     void (*kern)(DistArgs) = nullptr;
@@ -750,8 +705,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.units_per_chunk = a.runs_per_chunk;  // units_per_wg == 1 in persistent mode
     a.units_per_xcd = gx / 8;
     if (p.persist) {
-        int per_cu = 0;
-        RK_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, (int)p.threads, p.lds_bytes));
+        const int per_cu = rk_occupancy(ctx, (const void *)kern, (int)p.threads, p.lds_bytes);
         const uint32_t resident = ((uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, ctx->num_cu) + 7) / 8 * 8;
         if (gx > resident) {  // otherwise every unit gets its own workgroup anyway
             a.persist = 1;
@@ -793,9 +747,14 @@ int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *querie
                      uint64_t *n_hits_dev, void *stream)
 {
     if (!ctx || !idx || !opts || !n_hits_dev || (!hits_dev && hits_cap)) return RK_ERR_ARG;
-    if (queries)
-        return rk_fail(ctx, RK_ERR_UNSUPPORTED,
-                       "rk_dist_rows_dev with explicit queries needs a workspace; use rk_dist_rows");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    if (queries) {  // ref-vs-query: look-up, counting and epilogue in one kernel (rk_distq.hip)
+        if (opts->triangle && queries->n != idx->n_ref)
+            return rk_fail(ctx, RK_ERR_ARG, "triangle mode needs the indexed sketches as queries (%u vs %u)",
+                           queries->n, idx->n_ref);
+        return rk_distq_launch(ctx, idx, queries, opts, hits_dev, hits_cap, (unsigned long long *)n_hits_dev, nullptr,
+                               (hipStream_t)stream);
+    }
     if (!opts->triangle || !idx->d_selfrange)
         return rk_fail(ctx, RK_ERR_ARG, "queries == NULL needs triangle=1 and an index built by rk_index_build");
     Plan p;
@@ -815,79 +774,55 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
     const bool self = (queries == nullptr);
     if (self && (!opts->triangle || !idx->d_selfrange))
         return rk_fail(ctx, RK_ERR_ARG, "queries == NULL needs triangle=1 and an index built by rk_index_build");
+    if (self && common_dense) return rk_fail(ctx, RK_ERR_ARG, "common_dense needs explicit query sketches");
     const uint32_t n_query = self ? idx->n_ref : queries->n;
     if (opts->triangle && n_query != idx->n_ref)
         return rk_fail(ctx, RK_ERR_ARG, "triangle mode needs the indexed sketches as queries (%u vs %u)",
                        n_query, idx->n_ref);
     Plan p;
-    uint64_t max_q = idx->max_src_size;
-    if (queries) {
-        max_q = 0;
-        for (uint32_t g = 0; g < queries->n; g++)
-            max_q = std::max<uint64_t>(max_q, queries->h_off[g + 1] - queries->h_off[g]);
-    }
-    int rc = make_plan(ctx, idx, n_query, max_q, opts, self && !common_dense, &p);
-    if (rc) return rc;
-
-    // posting ranges of every query hash: precomputed for the self join, resolved through
-    // the prefix directory otherwise (or when full counter rows are requested)
-    const uint2 *ranges = idx->d_selfrange;
-    const uint64_t *range_off = idx->d_self_off;
-    const uint64_t *size_off = idx->d_src_off;
-    DevBuf<uint2> resolved, kept;
-    DevBuf<uint64_t> kept_off;
-    if (!self || common_dense) {
-        const rk_sketches *qs = queries;
-        DevBuf<uint32_t> dummy;
-        const void *qh = qs ? (qs->wide ? (const void *)qs->d_hashes64 : (const void *)qs->d_hashes) : nullptr;
-        uint64_t qn = qs ? qs->total : idx->H;
-        if (!qs)
-            return rk_fail(ctx, RK_ERR_ARG, "common_dense needs explicit query sketches");
-        if (qs->wide != idx->wide)
-            return rk_fail(ctx, RK_ERR_ARG, "query sketches and index use different hash widths");
-        RK_HIP(ctx, resolved.alloc(qn));
-        rc = rk_resolve_ranges(ctx, idx, qh, qn, resolved.p, 0);
+    int rc = RK_OK;
+    if (self) {
+        rc = make_plan(ctx, idx, n_query, idx->max_src_size, opts, true, &p);
         if (rc) return rc;
-        // most query hashes of an unrelated genome are absent from the index: drop their empty
-        // slices so the kernel only walks real posting lists (size_off keeps the sketch sizes)
-        uint64_t n_kept = 0;
-        rc = rk_compact_ranges(ctx, resolved.p, qn, qs->d_off, qs->n, &kept.p, &kept_off.p, &n_kept, 0);
-        if (rc) return rc;
-        resolved.reset();
-        ranges = kept.p;
-        range_off = kept_off.p;
-        size_off = qs->d_off;
     }
+    const bool dense_mode = rk_dense_mode(opts);
+    hipStream_t stream = ctx->stream;
 
-    DevBuf<int32_t> dense;
+    DevBuf<int32_t> dense(ctx);
     if (common_dense) {
         RK_HIP(ctx, dense.alloc((size_t)n_query * idx->n_ref));
-        RK_HIP(ctx, hipMemset(dense.p, 0, (size_t)n_query * idx->n_ref * 4));
+        RK_HIP(ctx, hipMemsetAsync(dense.p, 0, (size_t)n_query * idx->n_ref * 4, stream));
     }
-    DevBuf<unsigned long long> counter;
+    DevBuf<unsigned long long> counter(ctx);
     RK_HIP(ctx, counter.alloc(1));
 
     // sparse mode: optimistic capacity, exact retry on overflow.  dense mode: every
     // selected (row, col) cell is a hit, so the count is known up front.
+    const uint64_t row_step = opts->row_step ? opts->row_step : 1;
+    uint64_t row_block = opts->row_block > 0 ? (uint64_t)opts->row_block : 1;
+    if (row_step == 1 && opts->row_first == 0) row_block = std::max<uint64_t>(1, n_query);
     uint64_t cap = 0, n_sel = 0;  // rows of this shard: blocks row_first, row_first + row_step, ... of row_block rows
-    for (uint64_t blk = p.row_first; blk * p.row_block < n_query; blk += p.row_step)
-        for (uint64_t r = blk * p.row_block; r < std::min<uint64_t>(n_query, (blk + 1) * p.row_block); r++) {
+    for (uint64_t blk = opts->row_first; blk * row_block < n_query; blk += row_step)
+        for (uint64_t r = blk * row_block; r < std::min<uint64_t>(n_query, (blk + 1) * row_block); r++) {
             n_sel++;
-            if (p.dense_mode) cap += opts->triangle ? idx->n_ref - 1 - r : idx->n_ref;
+            if (dense_mode) cap += opts->triangle ? idx->n_ref - 1 - r : idx->n_ref;
         }
-    if (!p.dense_mode) cap = std::max<uint64_t>(1 << 16, n_sel * 64);
-    std::vector<rk_hit> host;
+    if (!dense_mode) cap = std::max<uint64_t>(1 << 16, n_sel * 64);
     for (int attempt = 0; attempt < 2; attempt++) {
-        DevBuf<rk_hit> hits;
+        DevBuf<rk_hit> hits(ctx);
         if (hits.alloc(cap) != hipSuccess)
             return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu hit records on the device",
                            (unsigned long long)cap);
-        RK_HIP(ctx, hipMemset(counter.p, 0, 8));
-        rc = launch_dist(ctx, idx, ranges, range_off, size_off, n_query, opts, p, hits.p, cap, counter.p,
-                         common_dense ? dense.p : nullptr, 0);
+        RK_HIP(ctx, hipMemsetAsync(counter.p, 0, 8, stream));
+        if (self)
+            rc = launch_dist(ctx, idx, idx->d_selfrange, idx->d_self_off, idx->d_src_off, n_query, opts, p, hits.p, cap,
+                             counter.p, nullptr, stream);
+        else
+            rc = rk_distq_launch(ctx, idx, queries, opts, hits.p, cap, counter.p, common_dense ? dense.p : nullptr, stream);
         if (rc) return rc;
         unsigned long long n = 0;
-        RK_HIP(ctx, hipMemcpy(&n, counter.p, 8, hipMemcpyDeviceToHost));
+        rc = rk_read_back(ctx, &n, counter.p, 8, stream);
+        if (rc) return rc;
         if (n > cap) {  // overflow: rerun with the exact count
             cap = n;
             continue;
@@ -895,26 +830,27 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
         rk_hit *out = (rk_hit *)malloc((n ? n : 1) * sizeof(rk_hit));
         if (!out) return rk_fail(ctx, RK_ERR_NOMEM, "host allocation of %llu hits failed", n);
         const rk_hit *src = hits.p;
-        DevBuf<rk_hit> ordered;
+        DevBuf<rk_hit> ordered(ctx);
         bool on_device = false;
         if (n > (1u << 20)) {  // order big results on the device; on any failure the host sorts
-            DevBuf<unsigned long long> keys, keys_out;
-            DevBuf<char> tmp;
+            DevBuf<unsigned long long> keys(ctx), keys_out(ctx);
+            DevBuf<char> tmp(ctx);
             size_t tb = 0;
             int bits = 33;
             while (bits < 64 && (1ULL << (bits - 32)) < n_query) bits++;
             if (keys.alloc(n) == hipSuccess && keys_out.alloc(n) == hipSuccess && ordered.alloc(n) == hipSuccess &&
-                rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_out.p, hits.p, ordered.p, n, 0, (unsigned)bits) == hipSuccess &&
+                rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_out.p, hits.p, ordered.p, n, 0, (unsigned)bits, stream) == hipSuccess &&
                 tmp.alloc(tb) == hipSuccess) {
-                hipLaunchKernelGGL(k_hit_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, hits.p, n, keys.p);
-                on_device = rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys_out.p, hits.p, ordered.p, n, 0, (unsigned)bits) == hipSuccess &&
-                            hipDeviceSynchronize() == hipSuccess;
+                hipLaunchKernelGGL(k_hit_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, hits.p, n, keys.p);
+                on_device = rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys_out.p, hits.p, ordered.p, n, 0, (unsigned)bits, stream) == hipSuccess &&
+                            hipStreamSynchronize(stream) == hipSuccess;
             }
             if (on_device) src = ordered.p;
             else (void)hipGetLastError();
         }
         if (n) {
-            hipError_t e = hipMemcpy(out, src, n * sizeof(rk_hit), hipMemcpyDeviceToHost);
+            hipError_t e = hipMemcpyAsync(out, src, n * sizeof(rk_hit), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
             if (e != hipSuccess) {
                 free(out);
                 return rk_fail(ctx, RK_ERR_HIP, "hit download failed: %s", hipGetErrorString(e));
@@ -926,9 +862,10 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
             });
         *hits_out = out;
         *n_hits = n;
-        if (common_dense)
-            RK_HIP(ctx, hipMemcpy(common_dense, dense.p, (size_t)n_query * idx->n_ref * 4,
-                                  hipMemcpyDeviceToHost));
+        if (common_dense) {
+            RK_HIP(ctx, hipMemcpyAsync(common_dense, dense.p, (size_t)n_query * idx->n_ref * 4, hipMemcpyDeviceToHost, stream));
+            RK_HIP(ctx, hipStreamSynchronize(stream));
+        }
         return RK_OK;
     }
     return rk_fail(ctx, RK_ERR_CAPACITY, "hit buffer overflow persisted after resize");

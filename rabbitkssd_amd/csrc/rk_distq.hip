@@ -1,0 +1,507 @@
+// rk_distq.hip -- ref-vs-query distances in ONE pass (replaces the row loop of index_dist,
+// src/dist.cpp:560-692: per query `memset(row)`, for every query hash the index probe :565-570 and the
+// posting walk :571-588, then the epilogue :600-682).
+//
+// A workgroup owns one (query, reference tile) unit at a time; the reference's per-thread counter row
+// (`intersectionArr[tid][numRef]`, src/dist.cpp:541) is an LDS row of 8-, 16- or 32-bit counters -- as narrow as
+// the bound min(|largest query|, |largest reference|) on an intersection count allows, so that 100,000 reference
+// columns of 76-hash bacterial sketches are ONE 100 KB tile.
+//
+// Per unit:  zero the row | barrier | for every query hash: LOOK UP its posting list, keep the non-empty ones,
+//            WALK them with ds_add into the row | barrier | scan the row, evaluate, stage hits | barrier
+//
+// Look-up (fused; round 1 ran it as a separate pass that wrote 8 B per query hash to HBM and read them back
+// through flags/scan/compact passes): the index's distinct hashes as a RANK BITMAP over the hash space, one
+// {32 presence bits, rank} pair per 32 consecutive hash values (2^(bits-5) x 8 B: 4 MiB for the 24-bit hashes of
+// L4K10, 64 MiB for the 28 bits of L3K10).  One 8-byte load answers "is h indexed" and "which distinct hash is
+// it"; a query's hashes are sorted, so consecutive lanes read consecutive words (a 3 Gb genome's 45,776 hashes touch
+// every 128-byte line of the 4 MiB table ~1.4 times: streaming, mostly L1/L2 hits).  Only present hashes (~11 % for
+// an unrelated mammal against 100,000 bacteria) go on to load their posting range (8 B from upos).  Hash spaces
+// above 2^30 and 64-bit hashes use the prefix directory + binary search instead.
+//
+// Compaction and walk: present ranges are appended to a per-wave LDS queue (ballot + popcount, no atomics); whenever
+// 64 are queued the wave pops them and walks 4 steps: in step j quad q serves the range held by lane 4q+j, every lane
+// fetching two postings with one 8-byte load, i.e. the first 8 postings of 16 lists per step.  Lists longer than 8
+// re-enter the queue as (x+8, y): any length is walked at full quad efficiency and there is no serial long-list
+// loop.  Integer/index work: bound by L1/L2 gather rate and LDS atomics -- no MFMA.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "rk_dist_common.h"
+
+namespace {
+
+constexpr uint32_t kQueueCap = 128;     // ranges per wave: < 64 left over + <= 64 appended
+constexpr uint32_t kMaxThreads = 1024;
+constexpr uint32_t kLookups = 4;        // query hashes per lane and iteration (independent loads in flight)
+
+enum { kLookRank = 0, kLookDir32 = 1, kLookDir64 = 2 };
+
+struct DistQArgs {
+    const void *q_hashes;        // u32[] or u64[] (kLookDir64)
+    const uint64_t *q_off;       // u64[n_query+1]
+    const uint2 *rankbm;         // kLookRank
+    const void *uhash;           // kLookDir*: sorted distinct hashes
+    const uint32_t *dir;
+    const uint32_t *upos;        // u32[U+1] posting offsets of the distinct hashes
+    const uint32_t *postings;
+    const uint32_t *ref_sizes;
+    int32_t hash_bits, dir_shift;
+    uint32_t n_query, n_ref;
+    uint32_t row_first, row_step, row_block, n_units;   // block-cyclic row shard (rk_dist_opts)
+    uint32_t tile_cols, n_tiles, cnt_words;
+    uint32_t cand_cap, stage_hits;
+    int32_t triangle, metric, kmer_size, dense_mode;
+    double max_dist, min_jorc;
+    rk_hit *hits;
+    unsigned long long cap;
+    unsigned long long *n_hits;
+    int32_t *common_dense;
+};
+
+template <int CBITS, int LOOK>
+__global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
+{
+    typedef typename std::conditional<LOOK == kLookDir64, uint64_t, uint32_t>::type K;
+    constexpr uint32_t kPerWord = 32 / CBITS;
+    constexpr uint32_t kCellMask = CBITS == 32 ? 0xFFFFFFFFu : ((1u << (CBITS & 31)) - 1u);
+    const uint32_t nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 3;
+
+    // dynamic LDS: counter row | per-wave range queues | non-zero cell list | staged hits | scalars
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *cnt = lds;
+    uint2 *queue = reinterpret_cast<uint2 *>(lds + a.cnt_words) + wave * kQueueCap;
+    uint2 *cand = reinterpret_cast<uint2 *>(lds + a.cnt_words) + nwaves * kQueueCap;
+    rk_hit *stage = reinterpret_cast<rk_hit *>(cand + a.cand_cap);
+    uint32_t *scal = reinterpret_cast<uint32_t *>(stage + a.stage_hits);
+    unsigned long long &s_base = *reinterpret_cast<unsigned long long *>(scal);
+    uint32_t &s_total = scal[2];
+    uint32_t &s_cursor = scal[3];
+    if (tid == 0) s_cursor = 0;
+
+    const K *qh = reinterpret_cast<const K *>(a.q_hashes);
+    const K *uhash = reinterpret_cast<const K *>(a.uhash);
+    const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+
+    auto bump_cell = [&](uint32_t c) {  // src/dist.cpp:578 `intersectionArr[tid][curIndex]++`
+        if (CBITS == 32) atomicAdd(&cnt[c], 1u);
+        else atomicAdd(&cnt[c / kPerWord], 1u << ((c % kPerWord) * CBITS));
+    };
+    auto cell = [&](uint32_t c) -> uint32_t {
+        return CBITS == 32 ? cnt[c] : (cnt[c / kPerWord] >> ((c % kPerWord) * CBITS)) & kCellMask;
+    };
+
+    // units: (row slot, tile).  The tiles of a row are consecutive queue positions of one XCD (workgroups b, b+8, ...
+    // share an L2: they repeat the same look-ups), rows are dealt round-robin over the XCDs.
+    const uint32_t total = a.n_units * a.n_tiles;
+    const uint32_t per_round = 8 * a.n_tiles;
+    const uint32_t total_padded = (total + per_round - 1) / per_round * per_round;
+    for (uint32_t it = blockIdx.x; it < total_padded; it += gridDim.x) {
+        const uint32_t x = it & 7, p = it >> 3;
+        const uint32_t u = ((p / a.n_tiles) * 8 + x) * a.n_tiles + p % a.n_tiles;
+        if (u >= total) continue;
+        const uint32_t slot = u / a.n_tiles, tile = u % a.n_tiles;
+        // block-cyclic rows: this shard owns blocks row_first, row_first + row_step, ... of row_block rows
+        const uint32_t blk = slot / a.row_block;
+        const uint64_t row64 = ((uint64_t)a.row_first + (uint64_t)blk * a.row_step) * a.row_block + slot % a.row_block;
+        if (row64 >= a.n_query) continue;
+        const uint32_t row = (uint32_t)row64;
+        const uint32_t col0 = tile * a.tile_cols;
+        const uint32_t col1 = min(a.n_ref, col0 + a.tile_cols);
+        const uint32_t ncol = col1 - col0;
+        const bool tri_filter = a.triangle && !a.common_dense;
+        if (tri_filter && col1 <= row + 1) continue;       // nothing right of the diagonal in this tile
+        const uint32_t lo_id = tri_filter ? row + 1 : 0;   // src/dist.cpp:207: j > i
+
+        uint4 *z4 = reinterpret_cast<uint4 *>(cnt);        // memset(row), src/dist.cpp:563
+        for (uint32_t i = tid; i < a.cnt_words / 4; i += nthreads) z4[i] = make_uint4(0, 0, 0, 0);
+        if (tid == 0) s_total = 0;
+        __syncthreads();
+
+        auto bump = [&](uint32_t id, bool valid) {
+            const uint32_t c = id - col0;
+            if (valid && c < ncol && id >= lo_id) bump_cell(c);
+        };
+        uint32_t qn = 0;  // wave-uniform: ranges in this wave's queue
+        // pops up to 64 ranges and walks the first 8 postings of each; longer lists re-enter the queue
+        auto walk = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t take = min(qn, 64u);
+            qn -= take;
+            uint2 rg = make_uint2(0, 0);
+            if (lane < take) rg = queue[qn + lane];
+            PostingPair id[4];
+            bool ok0[4], ok1[4];
+            auto step = [&](int j, uint32_t rx, uint32_t ry) {
+                const uint32_t k = rx + 2 * sub;
+                ok0[j] = k < ry;
+                ok1[j] = k + 1 < ry;
+                id[j] = *reinterpret_cast<const PostingPair *>(a.postings + (ok0[j] ? k : 0));  // postings[0..1] are mapped
+            };
+            step(0, quad_bcast<0>(rg.x), quad_bcast<0>(rg.y));
+            step(1, quad_bcast<1>(rg.x), quad_bcast<1>(rg.y));
+            step(2, quad_bcast<2>(rg.x), quad_bcast<2>(rg.y));
+            step(3, quad_bcast<3>(rg.x), quad_bcast<3>(rg.y));
+            const bool more = rg.y - rg.x > 8u;
+            const unsigned long long m = __ballot(more);
+            if (m) {  // uniform
+                if (more) queue[qn + __popcll(m & lt_mask)] = make_uint2(rg.x + 8, rg.y);
+                qn += __popcll(m);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bump(id[j].x, ok0[j]);
+                bump(id[j].y, ok1[j]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        };
+
+        const uint64_t qb = a.q_off[row], qe = a.q_off[row + 1];
+        for (uint64_t e0 = qb; e0 < qe; e0 += (uint64_t)kLookups * nthreads) {
+            K h[kLookups];
+            bool inb[kLookups];
+#pragma unroll
+            for (uint32_t i = 0; i < kLookups; i++) {
+                const uint64_t e = e0 + (uint64_t)i * nthreads + tid;
+                inb[i] = e < qe;
+                h[i] = inb[i] ? qh[e] : (K)0;
+                // a query hash outside the reference's hash space cannot be indexed
+                if (a.hash_bits < (int)(8 * sizeof(K))) inb[i] = inb[i] && (h[i] >> a.hash_bits) == 0;
+            }
+            uint32_t pos[kLookups];
+            bool present[kLookups];
+            if (LOOK == kLookRank) {
+                uint2 w[kLookups];
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) w[i] = a.rankbm[inb[i] ? (uint32_t)(h[i] >> 5) : 0u];
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    const uint32_t b = (uint32_t)h[i] & 31u;
+                    present[i] = inb[i] && ((w[i].x >> b) & 1u);
+                    pos[i] = w[i].y + __popc(w[i].x & ((1u << b) - 1u));
+                }
+            } else {
+                // prefix directory + binary search in the sorted distinct hashes (k_resolve of round 1, inlined)
+                uint32_t lo[kLookups], hi[kLookups];
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    const uint32_t b = inb[i] ? (uint32_t)(h[i] >> a.dir_shift) : 0u;
+                    lo[i] = a.dir[b];
+                    hi[i] = inb[i] ? a.dir[b + 1] : lo[i];
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    const uint32_t end = hi[i];
+                    while (lo[i] < hi[i]) {
+                        const uint32_t mid = (lo[i] + hi[i]) >> 1;
+                        if (uhash[mid] < h[i]) lo[i] = mid + 1; else hi[i] = mid;
+                    }
+                    present[i] = inb[i] && lo[i] < end && uhash[lo[i]] == h[i];
+                    pos[i] = lo[i];
+                }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kLookups; i++) {
+                const unsigned long long m = __ballot(present[i]);
+                if (m) {  // uniform
+                    if (present[i]) {
+                        const PostingPair r = *reinterpret_cast<const PostingPair *>(a.upos + pos[i]);
+                        queue[qn + __popcll(m & lt_mask)] = make_uint2(r.x, r.y);
+                    }
+                    qn += __popcll(m);
+                    if (qn >= 64) walk();
+                }
+            }
+        }
+        while (qn) walk();
+        __syncthreads();  // all scatters of the unit done
+
+        // ---- epilogue (src/dist.cpp:600-682; :207-255 in triangle mode) -------------------------------------
+        if (a.common_dense) {
+            int32_t *dst = a.common_dense + (size_t)row * a.n_ref + col0;
+            for (uint32_t i = tid; i < ncol; i += nthreads) dst[i] = (int32_t)cell(i);
+        }
+        const int qsize = (int)(qe - qb);
+        const uint32_t jbeg = a.triangle ? max(col0, row + 1) : col0;  // :207 / :600
+        auto evaluate = [&](uint32_t j, int common, rk_hit &hrec) -> bool {
+            const int rs = (int)a.ref_sizes[j];
+            const int size0 = a.triangle ? qsize : rs;  // :215-216 / :607-608
+            const int size1 = a.triangle ? rs : qsize;
+            // exact-safe reject before the FP64 divide + log (the distance is monotone in jaccard/containment
+            // and min_jorc sits strictly below the value at the threshold)
+            const int denom = a.metric ? min(size0, size1) : size0 + size1 - common;
+            if ((double)common < a.min_jorc * (double)denom) return false;
+            const JorcDist jd = rk_distance(common, size0, size1, a.metric, a.kmer_size);
+            hrec.row = row;
+            hrec.col = j;
+            hrec.common = common;
+            hrec.size0 = size0;
+            hrec.size1 = size1;
+            hrec.pad_ = 0;
+            hrec.jorc = jd.jorc;
+            hrec.dist = jd.dist;
+            return a.triangle ? (jd.dist < a.max_dist) : (jd.dist <= a.max_dist);  // :232 / :624
+        };
+        auto stage_hit = [&](const rk_hit &hrec) {
+            const uint32_t sl = atomicAdd(&s_cursor, 1u);
+            if (sl < a.stage_hits) stage[sl] = hrec;
+            else {  // staging full: pay the device-scope atomic per hit
+                const unsigned long long at = atomicAdd(a.n_hits, 1ULL);
+                if (at < a.cap) a.hits[at] = hrec;
+            }
+        };
+        if (!a.dense_mode) {
+            // the threshold excludes distance 1.0 (== common 0): scan the row 16 B per lane skipping all-zero
+            // quads, compact the non-zero cells into an LDS list, evaluate the list one cell per lane
+            const uint4 *c4 = reinterpret_cast<const uint4 *>(cnt);
+            const uint32_t q_first = ((jbeg - col0) / kPerWord) / 4;
+            const uint32_t q_end = ((ncol + kPerWord - 1) / kPerWord + 3) / 4;
+            for (uint32_t q = q_first + tid; q < q_end; q += nthreads) {
+                const uint4 v = c4[q];
+                if ((v.x | v.y | v.z | v.w) == 0) continue;
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                uint32_t n = 0;
+#pragma unroll
+                for (int wi = 0; wi < 4; wi++)
+#pragma unroll
+                    for (uint32_t s = 0; s < kPerWord; s++) n += ((w[wi] >> (s * CBITS % 32)) & kCellMask) != 0;
+                uint32_t at = atomicAdd(&s_total, n);
+                const uint32_t cq = q * 4 * kPerWord;
+#pragma unroll
+                for (int wi = 0; wi < 4; wi++)
+#pragma unroll
+                    for (uint32_t s = 0; s < kPerWord; s++) {
+                        const uint32_t common = (w[wi] >> (s * CBITS % 32)) & kCellMask;
+                        if (common) {
+                            if (at < a.cand_cap) cand[at] = make_uint2(cq + wi * kPerWord + s, common);
+                            at++;
+                        }
+                    }
+            }
+            __syncthreads();
+            const uint32_t n_cells = s_total;
+            if (n_cells <= a.cand_cap) {
+                for (uint32_t i = tid; i < n_cells; i += nthreads) {
+                    const uint2 cj = cand[i];
+                    const uint32_t j = col0 + cj.x;
+                    rk_hit hrec;
+                    if (j >= jbeg && j < col1 && evaluate(j, (int)cj.y, hrec)) stage_hit(hrec);
+                }
+            } else {  // more sharing columns than the list holds: walk the row, one cell per lane
+                for (uint32_t c = (jbeg - col0) + tid; c < ncol; c += nthreads) {
+                    const uint32_t common = cell(c);
+                    rk_hit hrec;
+                    if (common && evaluate(col0 + c, (int)common, hrec)) stage_hit(hrec);
+                }
+            }
+        } else {
+            // every cell of [jbeg, col1) can be reported: pass 0 counts the unit's reports, one atomic reserves
+            // their slots, pass 1 re-evaluates and writes them
+            for (int pass_no = 0; pass_no < 2; pass_no++) {
+                uint32_t mine = 0;
+                for (uint32_t j = jbeg + tid; j < col1; j += nthreads) {
+                    rk_hit hrec;
+                    if (!evaluate(j, (int)cell(j - col0), hrec)) continue;
+                    if (pass_no == 0) { mine++; continue; }
+                    const unsigned long long at = s_base + atomicAdd(&s_total, 1u);
+                    if (at < a.cap) a.hits[at] = hrec;
+                }
+                if (pass_no == 0) {
+                    if (mine) atomicAdd(&s_total, mine);
+                    __syncthreads();
+                    const uint32_t tot = s_total;
+                    __syncthreads();
+                    if (tot == 0) break;  // uniform
+                    if (tid == 0) { s_base = atomicAdd(a.n_hits, (unsigned long long)tot); s_total = 0; }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();  // the row is zeroed next
+    }
+
+    // flush the staged hits of this workgroup: one device-scope atomic, coalesced 8-byte stores
+    __syncthreads();
+    const uint32_t n_st = min(s_cursor, a.stage_hits);
+    if (n_st == 0) return;
+    if (tid == 0) s_base = atomicAdd(a.n_hits, (unsigned long long)n_st);
+    __syncthreads();
+    const unsigned long long at0 = s_base;
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(stage);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.hits);
+    constexpr uint32_t kW = sizeof(rk_hit) / 8;
+    for (uint32_t i = tid; i < n_st * kW; i += nthreads)
+        if (at0 + i / kW < a.cap) dst[at0 * kW + i] = src[i];
+}
+
+// ---- rank bitmap over the hash space --------------------------------------------------------------------
+__global__ void k_rank_set(const uint32_t *uhash, uint64_t U, uint32_t *bits)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < U) atomicOr(&bits[uhash[i] >> 5], 1u << (uhash[i] & 31));
+}
+
+// rank of a word = index of the first distinct hash >= 32 * word: uhash is sorted, so a binary search replaces
+// the scan of the popcounts (no temporary, one pass)
+__global__ void k_rank_fill(const uint32_t *uhash, uint64_t U, const uint32_t *bits, uint64_t n_words, uint2 *out)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const uint64_t key = w << 5;
+    uint64_t lo = 0, hi = U;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)uhash[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    out[w] = make_uint2(bits[w], (uint32_t)lo);
+}
+
+constexpr int kRankMaxBits = 30;  // 2^25 words x 8 B = 256 MiB; above that: directory + binary search
+
+int ensure_rankbm(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
+{
+    if (idx->d_rankbm || idx->wide || idx->hash_bits > kRankMaxBits) return RK_OK;
+    const uint64_t n_words = idx->hash_bits > 5 ? 1ULL << (idx->hash_bits - 5) : 1ULL;
+    DevBuf<uint32_t> bits(ctx);
+    DevBuf<uint2> out(ctx);
+    if (bits.alloc(n_words) != hipSuccess || out.alloc(n_words) != hipSuccess)
+        return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate the %llu-word rank bitmap", (unsigned long long)n_words);
+    RK_HIP(ctx, hipMemsetAsync(bits.p, 0, n_words * 4, stream));
+    if (idx->U)
+        hipLaunchKernelGGL(k_rank_set, dim3((unsigned)((idx->U + 255) / 256)), dim3(256), 0, stream, idx->d_uhash, idx->U, bits.p);
+    hipLaunchKernelGGL(k_rank_fill, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, idx->d_uhash, idx->U,
+                       bits.p, n_words, out.p);
+    RK_HIP(ctx, hipGetLastError());
+    RK_HIP(ctx, hipStreamSynchronize(stream));  // `bits` dies with this scope
+    idx->d_rankbm = out.release();
+    return RK_OK;
+}
+
+struct PlanQ {
+    int cbits, look;
+    uint32_t tile_cols, n_tiles, cnt_words, threads, cand_cap, stage_hits, n_units, grid;
+    uint32_t row_first, row_step, row_block;
+    size_t lds_bytes;
+};
+
+typedef void (*distq_kernel_t)(DistQArgs);
+distq_kernel_t pick_kernel(int cbits, int look)
+{
+#define RK_Q(C)                                                                                                  \
+    (look == kLookRank ? rk_distq_kernel<C, kLookRank>                                                           \
+                       : (look == kLookDir32 ? rk_distq_kernel<C, kLookDir32> : rk_distq_kernel<C, kLookDir64>))
+    return cbits == 8 ? RK_Q(8) : (cbits == 16 ? RK_Q(16) : RK_Q(32));
+#undef RK_Q
+}
+
+}  // namespace
+
+int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, const rk_dist_opts *o, rk_hit *hits_dev,
+                    uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev, hipStream_t stream)
+{
+    if (o->kmer_size <= 0) return rk_fail(ctx, RK_ERR_ARG, "kmer_size must be positive");
+    if (o->row_block < 0) return rk_fail(ctx, RK_ERR_ARG, "row_block must be >= 0");
+    if (qs->wide != idx->wide) return rk_fail(ctx, RK_ERR_ARG, "query sketches and index use different hash widths");
+    if (!qs->n || !idx->n_ref) return RK_OK;
+    PlanQ p;
+    // an intersection count never exceeds the smaller sketch when both sides are sets; a query with repeated
+    // hashes still cannot exceed its own length as long as the references are sets
+    uint64_t bound = ~0ULL;
+    if (idx->ref_sets) bound = qs->is_set ? std::min<uint64_t>(qs->max_size, idx->max_ref_size) : qs->max_size;
+    p.cbits = bound < 256 ? 8 : (bound < 65536 ? 16 : 32);
+    int rc = ensure_rankbm(ctx, const_cast<rk_index *>(idx), stream);  // lazily built, cached in the index
+    if (rc) return rc;
+    p.look = idx->wide ? kLookDir64 : (idx->d_rankbm ? kLookRank : kLookDir32);
+    if (p.look != kLookRank) {  // prefix directory, lazily built like the rank bitmap
+        rc = rk_index_ensure_dir(ctx, const_cast<rk_index *>(idx), stream);
+        if (rc) return rc;
+    }
+    p.cand_cap = 256;
+    p.stage_hits = 96;
+    // one tile if the row fits next to the queues of a 1024-thread workgroup, else equal tiles
+    const size_t lds_max = std::min<size_t>(ctx->max_lds, 160 * 1024);
+    auto fixed_bytes = [&](uint32_t threads) {
+        return (size_t)(threads / 64) * kQueueCap * sizeof(uint2) + (size_t)p.cand_cap * sizeof(uint2) +
+               (size_t)p.stage_hits * sizeof(rk_hit) + 64;
+    };
+    const size_t row_cap = lds_max - fixed_bytes(kMaxThreads);
+    const uint32_t max_cols = (uint32_t)(row_cap * 8 / p.cbits) & ~127u;
+    uint32_t tile = idx->n_ref;
+    if (tile > max_cols) {
+        const uint32_t nt = (idx->n_ref + max_cols - 1) / max_cols;
+        tile = ((idx->n_ref + nt - 1) / nt + 127) & ~127u;
+    }
+    p.tile_cols = tile;
+    p.n_tiles = (idx->n_ref + tile - 1) / tile;
+    p.cnt_words = (uint32_t)((((uint64_t)tile * p.cbits + 31) / 32 + 3) & ~3ULL);  // whole 16-byte quads
+    // workgroup size follows the LDS footprint (it caps the resident workgroups): 7 x 256, 3 x 512, 2 x 768, 1 x 1024
+    const size_t row_bytes = (size_t)p.cnt_words * 4;
+    p.threads = row_bytes + fixed_bytes(256) <= 22 * 1024 ? 256
+              : (row_bytes + fixed_bytes(512) <= 52 * 1024 ? 512 : (row_bytes + fixed_bytes(768) <= 79 * 1024 ? 768 : 1024));
+    p.lds_bytes = row_bytes + fixed_bytes(p.threads);
+    p.row_step = o->row_step ? o->row_step : 1;
+    p.row_first = o->row_first;
+    p.row_block = o->row_block > 0 ? (uint32_t)o->row_block : 1;
+    const uint64_t n_blocks = ((uint64_t)qs->n + p.row_block - 1) / p.row_block;
+    const uint64_t my_blocks = p.row_first < n_blocks ? (n_blocks - p.row_first + p.row_step - 1) / p.row_step : 0;
+    p.n_units = (uint32_t)std::min<uint64_t>(my_blocks * p.row_block, 0xFFFFFFF0u / p.n_tiles);
+    if (!p.n_units) return RK_OK;
+
+    DistQArgs a;
+    a.q_hashes = qs->wide ? (const void *)qs->d_hashes64 : (const void *)qs->d_hashes;
+    a.q_off = qs->d_off;
+    a.rankbm = idx->d_rankbm;
+    a.uhash = idx->wide ? (const void *)idx->d_uhash64 : (const void *)idx->d_uhash;
+    a.dir = idx->d_dir;
+    a.upos = idx->d_upos;
+    a.postings = idx->d_postings;
+    a.ref_sizes = idx->d_sizes;
+    a.hash_bits = idx->hash_bits;
+    a.dir_shift = idx->dir_shift;
+    a.n_query = qs->n;
+    a.n_ref = idx->n_ref;
+    a.row_first = p.row_first;
+    a.row_step = p.row_step;
+    a.row_block = p.row_block;
+    a.n_units = p.n_units;
+    a.tile_cols = p.tile_cols;
+    a.n_tiles = p.n_tiles;
+    a.cnt_words = p.cnt_words;
+    a.cand_cap = p.cand_cap;
+    a.stage_hits = p.stage_hits;
+    a.triangle = o->triangle;
+    a.metric = o->metric != 0;  // the reference treats any non-zero isContainment as containment
+    a.kmer_size = o->kmer_size;
+    a.dense_mode = rk_dense_mode(o) ? 1 : 0;
+    a.max_dist = o->max_dist;
+    a.min_jorc = 0.0;
+    if (!a.dense_mode && o->max_dist > 0.0) {
+        // distance < D  <=>  jaccard > t/(2-t), t = exp(-k D)  (containment: c > t); 1e-6 relative slack keeps the
+        // reject conservative, the exact formula still decides
+        const double t = exp(-(double)o->kmer_size * o->max_dist);
+        a.min_jorc = (a.metric ? t : t / (2.0 - t)) * (1.0 - 1e-6);
+    }
+    a.hits = hits_dev;
+    a.cap = cap;
+    a.n_hits = n_hits_dev;
+    a.common_dense = dense_dev;
+
+    distq_kernel_t kern = pick_kernel(p.cbits, p.look);
+    if (p.lds_bytes > 48 * 1024)
+        RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+    // persistent grid: as many workgroups as the chip holds, in whole rounds of 8 XCDs x n_tiles
+    const int per_cu = rk_occupancy(ctx, (const void *)kern, (int)p.threads, p.lds_bytes);
+    const uint32_t per_round = 8 * p.n_tiles;
+    const uint32_t total = p.n_units * p.n_tiles;
+    const uint32_t total_padded = (total + per_round - 1) / per_round * per_round;
+    uint32_t resident = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, ctx->num_cu);
+    resident = std::max(per_round, resident / per_round * per_round);
+    p.grid = std::min(total_padded, resident);
+    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(p.threads), p.lds_bytes, stream, a);
+    RK_HIP(ctx, hipGetLastError());
+    return RK_OK;
+}

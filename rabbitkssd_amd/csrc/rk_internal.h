@@ -5,7 +5,11 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
+#include <mutex>
 #include <string>
+#include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "rabbitkssd.h"
@@ -15,9 +19,31 @@ struct rk_ctx {
     int num_cu = 0;
     size_t max_lds = 0;  // bytes of LDS one workgroup may use
     std::string err;
+    // the context's own stream: every synchronous API call enqueues here (never on the null stream, whose implicit
+    // synchronisation would serialise the caller's other streams) and synchronises it before returning
+    hipStream_t stream = nullptr;
+    void *pinned = nullptr;  // kPinnedBytes of page-locked scratch for small read-backs / uploads
+    // caching device allocator: hipMalloc / hipFree cost 50-300 us each (hipFree also synchronises the device) and the
+    // index build alone needs ~25 buffers, so freed blocks are kept and handed out again; steady-state calls
+    // allocate nothing.  Blocks return to the driver in rk_ctx_trim / rk_ctx_destroy.
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;
+    std::unordered_map<void *, size_t> live;  // every block handed out or cached -> its size
+    size_t pool_bytes = 0;
+    std::map<std::tuple<const void *, int, size_t>, int> occupancy;  // hipOccupancy... costs 10-70 us per query
+    // developer switches (environment), read once at context creation
+    uint32_t sw_dist_threads = 0, sw_dist_rows = 0, sw_dist_pair = 1, sw_dist_pair_minwg = 3, sw_dist_persist = 1;
+    uint32_t sw_dist_cand_cap = 0, sw_dist_stage_hits = 0, sw_dist_xcd_rows = 0;
 };
+constexpr size_t kPinnedBytes = 1 << 16;
 
 int rk_fail(rk_ctx *ctx, int code, const char *fmt, ...);
+void *rk_pool_alloc(rk_ctx *ctx, size_t bytes);  // nullptr when the device is out of memory
+void rk_pool_free(rk_ctx *ctx, void *p);
+// device -> host copy of a few bytes through the pinned scratch (a pageable hipMemcpy costs 20-30 us more);
+// synchronises `stream`
+int rk_read_back(rk_ctx *ctx, void *dst, const void *src_dev, size_t bytes, hipStream_t stream);
+int rk_occupancy(rk_ctx *ctx, const void *kernel, int threads, size_t lds_bytes);
 
 #define RK_HIP(ctx, call)                                                                   \
     do {                                                                                    \
@@ -27,19 +53,22 @@ int rk_fail(rk_ctx *ctx, int code, const char *fmt, ...);
                            hipGetErrorString(e__), __FILE__, __LINE__);                     \
     } while (0)
 
-// owning device pointer; freed on scope exit unless release()d
+// owning device pointer from the context's pool; returned to it on scope exit unless release()d.  Work that uses
+// the buffer must be enqueued on ctx->stream (reuse is stream-ordered) or be complete before the scope ends.
 template <class T> struct DevBuf {
+    rk_ctx *ctx;
     T *p = nullptr;
-    DevBuf() = default;
+    explicit DevBuf(rk_ctx *c) : ctx(c) {}
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { reset(); }
     hipError_t alloc(size_t n) {
         reset();
-        return hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T));
+        p = static_cast<T *>(rk_pool_alloc(ctx, (n ? n : 1) * sizeof(T)));
+        return p ? hipSuccess : hipErrorOutOfMemory;
     }
     void reset() {
-        if (p) (void)hipFree(p);
+        if (p) rk_pool_free(ctx, p);
         p = nullptr;
     }
     T *release() {
@@ -70,6 +99,8 @@ struct rk_sketches {
     uint64_t *d_hashes64 = nullptr; // u64[total] when wide
     uint64_t *d_off = nullptr;
     std::vector<uint64_t> h_off;  // host mirror of d_off (n+1)
+    bool is_set = false;          // every genome's hashes are strictly ascending (sorted, no repeats)
+    uint64_t max_size = 0;        // largest sketch
 };
 
 struct rk_index {
@@ -79,8 +110,14 @@ struct rk_index {
     uint64_t U = 0;         // distinct hashes
     int hash_bits = 0;
     int dir_bits = 0, dir_shift = 0;
-    uint64_t sum_sq = 0;
+    uint64_t sum_sq = 0;             // sum of squared list lengths, computed on first request
+    bool sum_sq_known = false;
     uint64_t max_src_size = 0;       // largest source sketch (built index only)
+    uint64_t max_ref_size = 0;       // largest reference sketch (every index)
+    bool ref_sets = false;           // no genome appears twice in a posting list (the sketches are sets): an
+                                     // intersection count is then bounded by the smaller sketch
+    uint2 *d_rankbm = nullptr;       // lazily built by the query path (rk_distq.hip): per 32 consecutive hash values
+                                     // {presence bits, number of distinct indexed hashes below}; u32[2 * 2^(bits-5)]
     uint32_t *d_postings = nullptr;  // u32[H]   (.dict order)
     bool wide = false;               // 64-bit hashes: d_uhash64 instead of d_uhash
     uint32_t *d_uhash = nullptr;     // u32[U]   sorted distinct hashes
@@ -97,10 +134,14 @@ struct rk_index {
     uint64_t *d_src_off = nullptr;   // u64[n_ref+1] offsets of the source sketches (built only)
 };
 
-// kernels/launchers implemented in the .hip files
-// drops the empty slices of `ranges` (rows delimited by off_dev[n_rows+1]); outputs are hipMalloc'd
-int rk_compact_ranges(rk_ctx *ctx, const uint2 *ranges_dev, uint64_t n, const uint64_t *off_dev, uint32_t n_rows,
-                      uint2 **out_ranges_dev, uint64_t **out_off_dev, uint64_t *n_out, hipStream_t stream);
-// q_hashes_dev: u32[] or u64[] matching idx->wide
-int rk_resolve_ranges(rk_ctx *ctx, const rk_index *idx, const void *q_hashes_dev, uint64_t n,
-                      uint2 *ranges_dev, hipStream_t stream);
+// prefix directory into the sorted distinct hashes, built on first use (rk_index.hip)
+int rk_index_ensure_dir(rk_ctx *ctx, rk_index *idx, hipStream_t stream);
+// explicit queries (index_dist): lookup + counting + epilogue in one kernel (rk_distq.hip).  Enqueues on `stream`,
+// allocates nothing once the index's rank bitmap exists.  dense_dev: optional int32[n_query * n_ref].
+int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries, const rk_dist_opts *opts,
+                    rk_hit *hits_dev, uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev,
+                    hipStream_t stream);
+// true when every posting is reportable regardless of its count (the threshold admits distance 1.0)
+inline bool rk_dense_mode(const rk_dist_opts *o) { return o->triangle ? (1.0 < o->max_dist) : (1.0 <= o->max_dist); }
+// sets s->is_set / s->max_size from the device arrays (one small kernel + a 4-byte read-back)
+int rk_sketches_classify(rk_ctx *ctx, rk_sketches *s);

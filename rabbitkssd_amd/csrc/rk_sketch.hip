@@ -27,6 +27,13 @@
 
 #include "rk_internal.h"
 
+#define RK_TRY(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
+template <class T> static int pool_array(rk_ctx *ctx, T **out, size_t n)
+{
+    *out = static_cast<T *>(rk_pool_alloc(ctx, (n ? n : 1) * sizeof(T)));
+    return *out ? RK_OK : rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu bytes on the device", (unsigned long long)(n * sizeof(T)));
+}
+
 namespace {
 
 constexpr int kSketchThreads = 1024;           // 16 waves share one LDS filter image
@@ -70,10 +77,12 @@ struct SketchArgs {
     const int32_t *table;          // int32[16^half_subk]
     uint64_t tupmask, undomask0, undomask1;
     int32_t kmer, out2, dim_bits, hi_shift, dim_start, dim_end, dr_shift, und1_shift;
-    int32_t key_shift;             // emitted key = genome << key_shift | dr_tuple (32, or hash_bits when > 32)
+    // emitted dr_tuples go to the candidate region of their genome: cand[reg_off[g] .. + reg_cap[g]); gcount[g]
+    // counts every emitted key, also those beyond the capacity (overflow is detected, the host retries)
     unsigned long long *cand;
-    unsigned long long cand_cap;
-    unsigned long long *n_cand;
+    const uint64_t *reg_off;
+    const uint32_t *reg_cap;
+    uint32_t *gcount;
     unsigned long long *n_windows;
 };
 
@@ -178,16 +187,17 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
     unsigned long long windows = 0;
     uint32_t staged = 0;  // wave-uniform: keys in this wave's staging buffer
 
-    // wave-level flush of the staged keys (all 64 lanes call it together)
-    auto flush = [&]() {
+    // wave-level flush of the staged keys into the genome's candidate region (all 64 lanes call it together):
+    // one device-scope atomic on the genome's counter + one coalesced burst
+    auto flush = [&](uint32_t gid, unsigned long long *region, uint32_t region_cap) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint32_t n = min(*(volatile uint32_t *)stage_n, kStageCap);
         if (n) {
-            unsigned long long basep = 0;
-            if (lane == 0) basep = atomicAdd(a.n_cand, (unsigned long long)n);
+            uint32_t basep = 0;
+            if (lane == 0) basep = atomicAdd(a.gcount + gid, n);
             basep = __shfl(basep, 0);
             for (uint32_t i = lane; i < n; i += 64)
-                if (basep + i < a.cand_cap) a.cand[basep + i] = stage[i];
+                if (basep + i < region_cap) region[basep + i] = stage[i];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (lane == 0) *(volatile uint32_t *)stage_n = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -200,6 +210,8 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
         const uint32_t nbf = a.chunk_blocks[c];
         const uint32_t nb = nbf & 0x7FFFFFFFu;
         const uint8_t *base = a.packed + beg;
+        unsigned long long *region = a.cand + a.reg_off[gid];
+        const uint32_t region_cap = a.reg_cap[gid];
 
         // words of the two 16-base groups before the chunk (lanes "-2" and "-1")
         uint32_t cG2 = 0, cG1 = 0, cV2 = 0, cV1 = 0;
@@ -294,13 +306,13 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
                     const uint64_t pf = (uint64_t)(v - a.dim_start);            // :519-521
                     const uint64_t dr = (((uni & a.undomask0) | ((uni & a.undomask1) << a.und1_shift)) >>
                                          a.dr_shift) | pf;                      // :524
-                    const unsigned long long key = ((unsigned long long)gid << a.key_shift) | dr;
+                    const unsigned long long key = dr;
                     const uint32_t sl = atomicAdd(stage_n, 1u);
                     emitted++;
                     if (sl < kStageCap) stage[sl] = key;
                     else {  // staging full inside one block (low-complexity sequence): go direct
-                        const unsigned long long slot = atomicAdd(a.n_cand, 1ULL);
-                        if (slot < a.cand_cap) a.cand[slot] = key;
+                        const uint32_t slot = atomicAdd(a.gcount + gid, 1u);
+                        if (slot < region_cap) region[slot] = key;
                     }
                 }
             }
@@ -341,47 +353,158 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
             }
             c0 = n0;
             c1 = n1;
-            if (staged >= kStageCap / 2) { flush(); staged = 0; }
+            if (staged >= kStageCap / 2) { flush(gid, region, region_cap); staged = 0; }
         }
-        flush();
+        flush(gid, region, region_cap);
         staged = 0;
     }
     for (int o = 32; o > 0; o >>= 1) windows += __shfl_down(windows, o);
     if (lane == 0 && windows) atomicAdd(a.n_windows, windows);
 }
 
+// ---- per-genome dedup (the reference's unordered_set, src/sketch.cpp:470,526-529,537-550) -------------------
+// One workgroup per genome: its candidate region (~1,250 dr_tuples for a 5 Mb genome at L3) is sorted in LDS
+// (bitonic), equal neighbours collapse (FASTQ: a hash survives only with >= min_count occurrences, :828-845), and
+// the sorted distinct hashes are written back coalesced together with their number.  Replaces the ~20 launches
+// of a device-wide radix sort + unique + split that doubled the device time of a batch in round 1.
+constexpr uint32_t kDedupThreads = 256;
+constexpr uint32_t kDedupMaxBytes = 64 * 1024;  // LDS sort capacity: 16,384 32-bit or 8,192 64-bit keys
+
+enum : uint32_t { kFlagOverflow = 1 };
+
+struct SketchTail {  // device-side results of one sketch pass, read back in one copy
+    unsigned long long windows, flags;
+};
+
+template <class K>
+__global__ __launch_bounds__(kDedupThreads) void k_dedup(const unsigned long long *cand, const uint64_t *reg_off,
+                                                        const uint32_t *reg_cap, const uint32_t *gcount,
+                                                        const uint8_t *is_big, uint32_t min_count, K *sorted_out,
+                                                        uint32_t *usize, SketchTail *tail)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dedup_lds[];
+    K *a = reinterpret_cast<K *>(dedup_lds);
+    __shared__ uint32_t wave_tot[kDedupThreads / 64];
+    const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (is_big[g]) return;  // sorted by the device-wide path
+    const uint32_t n = gcount[g];
+    if (n > reg_cap[g]) {   // the region overflowed: the host reruns the pass with the exact capacities
+        if (tid == 0) {
+            usize[g] = 0;
+            atomicOr(&tail->flags, (unsigned long long)kFlagOverflow);
+        }
+        return;
+    }
+    uint32_t P = 1;
+    while (P < n) P <<= 1;
+    const unsigned long long *src = cand + reg_off[g];
+    // padding keys are all ones: they sort behind every real key (or tie with it), so the first n are the real ones
+    for (uint32_t i = tid; i < P; i += kDedupThreads) a[i] = i < n ? (K)src[i] : (K)~(K)0;
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < P / 2; t += kDedupThreads) {
+                const uint32_t i = 2 * t - (t & (j - 1));  // partner pairs (i, i + j)
+                const bool up = (i & k) == 0;
+                const K x = a[i], y = a[i + j];
+                if ((x > y) == up) {
+                    a[i] = y;
+                    a[i + j] = x;
+                }
+            }
+            __syncthreads();
+        }
+    // run heads that are kept; every thread owns a contiguous stretch so that the output stays sorted
+    const uint32_t per = (n + kDedupThreads - 1) / kDedupThreads;
+    const uint32_t i0 = min(n, tid * per), i1 = min(n, i0 + per);
+    auto kept = [&](uint32_t i) -> bool {
+        if (i && a[i] == a[i - 1]) return false;
+        if (min_count <= 1) return true;
+        uint32_t len = 1;
+        while (len < min_count && i + len < n && a[i + len] == a[i]) len++;
+        return len >= min_count;
+    };
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; i++) mine += kept(i);
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t at = incl - mine;
+    for (uint32_t w = 0; w < wave; w++) at += wave_tot[w];
+    K *dst = sorted_out + reg_off[g];
+    for (uint32_t i = i0; i < i1; i++)
+        if (kept(i)) dst[at++] = a[i];
+    if (tid == kDedupThreads - 1) usize[g] = at;
+}
+
+// single workgroup: off = exclusive scan of the per-genome sizes
+__global__ void k_size_scan(const uint32_t *usize, uint32_t n_genomes, uint64_t *off)
+{
+    __shared__ unsigned long long part[1024 / 64];
+    __shared__ unsigned long long carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_genomes; base += blockDim.x) {
+        const uint32_t g = base + tid;
+        const unsigned long long len = g < n_genomes ? usize[g] : 0ULL;
+        unsigned long long incl = len;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += t;
+        }
+        if (lane == 63) part[wave] = incl;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (uint32_t w = 0; w < wave; w++) before += part[w];
+        if (g < n_genomes) off[g] = before + incl - len;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = carry;
+            for (uint32_t w = 0; w < nw; w++) t += part[w];
+            carry = t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) off[n_genomes] = carry;
+}
+
+// one workgroup per genome: its sorted distinct hashes move to their place in the CSR
+template <class K>
+__global__ void k_csr_place(const K *sorted_out, const uint64_t *reg_off, const uint32_t *usize, const uint64_t *off, K *hashes)
+{
+    const uint32_t g = blockIdx.x;
+    const K *src = sorted_out + reg_off[g];
+    K *dst = hashes + off[g];
+    for (uint32_t i = threadIdx.x; i < usize[g]; i += blockDim.x) dst[i] = src[i];
+}
+
+// big genomes (candidate region beyond the LDS sort capacity): device-wide sort + unique, then narrow the keys
 __global__ void k_count_flags(const unsigned int *counts, uint64_t n, uint32_t min_count, unsigned char *flags)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = counts[i] >= min_count ? 1 : 0;
 }
 
-__global__ void k_split_keys(const unsigned long long *ukeys, uint64_t n, uint32_t *hashes)
+template <class K> __global__ void k_narrow_keys(const unsigned long long *ukeys, uint64_t n, K *out)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hashes[i] = (uint32_t)ukeys[i];
+    if (i < n) out[i] = (K)ukeys[i];
 }
 
-__global__ void k_split_keys64(const unsigned long long *ukeys, uint64_t n, int key_shift, uint64_t *hashes)
+// every genome's hashes strictly ascending?  (one wave per genome)
+template <class K> __global__ void k_check_sets(const K *hashes, const uint64_t *off, uint32_t n_genomes, uint32_t *bad)
 {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hashes[i] = ukeys[i] & ((1ULL << key_shift) - 1);
-}
-
-__global__ void k_genome_offsets(const unsigned long long *ukeys, uint64_t n, uint32_t n_genomes,
-                                 int key_shift, uint64_t *off)
-{
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > n_genomes) return;
-    // first key of genome g; g == n_genomes may not fit next to the hash bits: everything is below it
-    if (g == n_genomes) { off[g] = n; return; }
-    const unsigned long long key = (unsigned long long)g << key_shift;
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-        uint64_t mid = (lo + hi) >> 1;
-        if (ukeys[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    off[g] = lo;
+    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= n_genomes) return;
+    const uint64_t e1 = off[g + 1];
+    bool b = false;
+    for (uint64_t e = off[g] + 1 + (threadIdx.x & 63); e < e1; e += 64) b |= hashes[e] <= hashes[e - 1];
+    if (__ballot(b) && (threadIdx.x & 63) == 0) *bad = 1;
 }
 
 inline unsigned blocks_for(uint64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
@@ -450,12 +573,13 @@ int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_di
             vals[slot] = (uint16_t)sel_val[i];
         }
     }
-    DevBuf<int32_t> table;
-    DevBuf<uint32_t> d_image;
+    DevBuf<int32_t> table(ctx);
+    DevBuf<uint32_t> d_image(ctx);
     RK_HIP(ctx, table.alloc(n));
     RK_HIP(ctx, d_image.alloc(kFilterLdsBytes / 4));
-    RK_HIP(ctx, hipMemcpy(table.p, shuffled_dim, n * 4, hipMemcpyHostToDevice));
-    RK_HIP(ctx, hipMemcpy(d_image.p, image.data(), kFilterLdsBytes, hipMemcpyHostToDevice));
+    RK_HIP(ctx, hipMemcpyAsync(table.p, shuffled_dim, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP(ctx, hipMemcpyAsync(d_image.p, image.data(), kFilterLdsBytes, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rk_filter *f = new (std::nothrow) rk_filter;
     if (!f) return RK_ERR_NOMEM;
     f->ctx = ctx;
@@ -472,17 +596,17 @@ int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_di
 void rk_filter_free(rk_filter *f)
 {
     if (!f) return;
-    (void)hipFree(f->d_table);
-    (void)hipFree(f->d_bitmap);
+    rk_pool_free(f->ctx, f->d_table);
+    rk_pool_free(f->ctx, f->d_bitmap);
     delete f;
 }
 
 void rk_sketches_free(rk_sketches *s)
 {
     if (!s) return;
-    (void)hipFree(s->d_hashes);
-    (void)hipFree(s->d_hashes64);
-    (void)hipFree(s->d_off);
+    rk_pool_free(s->ctx, s->d_hashes);
+    rk_pool_free(s->ctx, s->d_hashes64);
+    rk_pool_free(s->ctx, s->d_off);
     delete s;
 }
 
@@ -508,10 +632,11 @@ int rk_sketches_from_host(rk_ctx *ctx, const uint32_t *hashes, const uint64_t *o
     s->total = off[n];
     s->h_off.assign(off, off + n + 1);
     struct Guard { rk_sketches *p; ~Guard() { if (p) rk_sketches_free(p); } } guard{s};
-    RK_HIP(ctx, hipMalloc((void **)&s->d_hashes, (s->total + 1) * 4));
-    RK_HIP(ctx, hipMalloc((void **)&s->d_off, ((size_t)n + 1) * 8));
-    if (s->total) RK_HIP(ctx, hipMemcpy(s->d_hashes, hashes, s->total * 4, hipMemcpyHostToDevice));
-    RK_HIP(ctx, hipMemcpy(s->d_off, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+    RK_TRY(pool_array(ctx, &s->d_hashes, s->total + 1));
+    RK_TRY(pool_array(ctx, &s->d_off, (size_t)n + 1));
+    if (s->total) RK_HIP(ctx, hipMemcpyAsync(s->d_hashes, hashes, s->total * 4, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP(ctx, hipMemcpyAsync(s->d_off, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    RK_TRY(rk_sketches_classify(ctx, s));  // synchronises the stream
     guard.p = nullptr;
     *out = s;
     return RK_OK;
@@ -529,13 +654,15 @@ int rk_sketches_from_dev(rk_ctx *ctx, const uint32_t *hashes_dev, const uint64_t
     s->n = n;
     struct Guard { rk_sketches *p; ~Guard() { if (p) rk_sketches_free(p); } } guard{s};
     s->h_off.resize((size_t)n + 1);
-    RK_HIP(ctx, hipMemcpy(s->h_off.data(), off_dev, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+    RK_HIP(ctx, hipMemcpyAsync(s->h_off.data(), off_dev, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     s->total = s->h_off[n];
     if (!hashes_dev && s->total) return rk_fail(ctx, RK_ERR_ARG, "hashes_dev is NULL");
-    RK_HIP(ctx, hipMalloc((void **)&s->d_hashes, (s->total + 1) * 4));
-    RK_HIP(ctx, hipMalloc((void **)&s->d_off, ((size_t)n + 1) * 8));
-    if (s->total) RK_HIP(ctx, hipMemcpy(s->d_hashes, hashes_dev, s->total * 4, hipMemcpyDeviceToDevice));
-    RK_HIP(ctx, hipMemcpy(s->d_off, off_dev, ((size_t)n + 1) * 8, hipMemcpyDeviceToDevice));
+    RK_TRY(pool_array(ctx, &s->d_hashes, s->total + 1));
+    RK_TRY(pool_array(ctx, &s->d_off, (size_t)n + 1));
+    if (s->total) RK_HIP(ctx, hipMemcpyAsync(s->d_hashes, hashes_dev, s->total * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    RK_HIP(ctx, hipMemcpyAsync(s->d_off, off_dev, ((size_t)n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    RK_TRY(rk_sketches_classify(ctx, s));
     guard.p = nullptr;
     *out = s;
     return RK_OK;
@@ -559,10 +686,11 @@ int rk_sketches_from_host64(rk_ctx *ctx, const uint64_t *hashes, const uint64_t 
     s->total = off[n];
     s->h_off.assign(off, off + n + 1);
     struct Guard { rk_sketches *p; ~Guard() { if (p) rk_sketches_free(p); } } guard{s};
-    RK_HIP(ctx, hipMalloc((void **)&s->d_hashes64, (s->total + 1) * 8));
-    RK_HIP(ctx, hipMalloc((void **)&s->d_off, ((size_t)n + 1) * 8));
-    if (s->total) RK_HIP(ctx, hipMemcpy(s->d_hashes64, hashes, s->total * 8, hipMemcpyHostToDevice));
-    RK_HIP(ctx, hipMemcpy(s->d_off, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+    RK_TRY(pool_array(ctx, &s->d_hashes64, s->total + 1));
+    RK_TRY(pool_array(ctx, &s->d_off, (size_t)n + 1));
+    if (s->total) RK_HIP(ctx, hipMemcpyAsync(s->d_hashes64, hashes, s->total * 8, hipMemcpyHostToDevice, ctx->stream));
+    RK_HIP(ctx, hipMemcpyAsync(s->d_off, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    RK_TRY(rk_sketches_classify(ctx, s));
     guard.p = nullptr;
     *out = s;
     return RK_OK;
@@ -575,7 +703,10 @@ int rk_sketches_download64(const rk_sketches *s, uint64_t *hashes, uint64_t *off
     if (!s->wide) return rk_fail(ctx, RK_ERR_ARG, "32-bit sketches: use rk_sketches_download");
     RK_HIP(ctx, hipSetDevice(ctx->device));
     if (off) memcpy(off, s->h_off.data(), ((size_t)s->n + 1) * 8);
-    if (hashes && s->total) RK_HIP(ctx, hipMemcpy(hashes, s->d_hashes64, s->total * 8, hipMemcpyDeviceToHost));
+    if (hashes && s->total) {
+        RK_HIP(ctx, hipMemcpyAsync(hashes, s->d_hashes64, s->total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return RK_OK;
 }
 
@@ -586,8 +717,10 @@ int rk_sketches_download(const rk_sketches *s, uint32_t *hashes, uint64_t *off)
     if (s->wide && hashes) return rk_fail(ctx, RK_ERR_ARG, "64-bit sketches: use rk_sketches_download64");
     RK_HIP(ctx, hipSetDevice(ctx->device));
     if (off) memcpy(off, s->h_off.data(), ((size_t)s->n + 1) * 8);
-    if (hashes && s->total)
-        RK_HIP(ctx, hipMemcpy(hashes, s->d_hashes, s->total * 4, hipMemcpyDeviceToHost));
+    if (hashes && s->total) {
+        RK_HIP(ctx, hipMemcpyAsync(hashes, s->d_hashes, s->total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return RK_OK;
 }
 
@@ -597,6 +730,62 @@ int rk_sketch_packed_dev(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_
 {
     return rk_sketch_packed_dev_ex(ctx, f, packed_dev, packed_bytes, gbeg, gend, n_genomes, 1, stream_v, out);
 }
+
+}  // extern "C"
+
+// one big genome's candidate region: device-wide radix sort + unique (or run-length select), narrowed into its
+// slot of sorted_out; returns the number of distinct hashes kept
+template <class K>
+static int dedup_big(rk_ctx *ctx, unsigned long long *region, uint32_t n, int hash_bits, uint32_t min_count, K *dst,
+                     uint32_t *n_out, hipStream_t stream)
+{
+    *n_out = 0;
+    if (!n) return RK_OK;
+    DevBuf<unsigned long long> sorted(ctx), uniq(ctx), d_n(ctx);
+    DevBuf<char> tmp(ctx);
+    RK_HIP(ctx, sorted.alloc(n));
+    RK_HIP(ctx, uniq.alloc(n));
+    RK_HIP(ctx, d_n.alloc(1));
+    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t1, region, sorted.p, n, 0, (unsigned)hash_bits, stream));
+    RK_HIP(ctx, tmp.alloc(t1));
+    RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, t1, region, sorted.p, n, 0, (unsigned)hash_bits, stream));
+    unsigned long long nu = 0;
+    if (min_count <= 1) {  // set semantics (FASTA, src/sketch.cpp:526-529)
+        RK_HIP(ctx, rocprim::unique(nullptr, t2, sorted.p, uniq.p, d_n.p, n, rocprim::equal_to<unsigned long long>(), stream));
+        DevBuf<char> tmp2(ctx);
+        RK_HIP(ctx, tmp2.alloc(t2));
+        RK_HIP(ctx, rocprim::unique(tmp2.p, t2, sorted.p, uniq.p, d_n.p, n, rocprim::equal_to<unsigned long long>(), stream));
+        RK_TRY(rk_read_back(ctx, &nu, d_n.p, 8, stream));
+    } else {  // FASTQ: keep a hash only if it occurred >= min_count times (src/sketch.cpp:828-845)
+        DevBuf<unsigned long long> runs(ctx);
+        DevBuf<unsigned int> counts(ctx);
+        DevBuf<unsigned char> flags(ctx);
+        DevBuf<char> tmp3(ctx), tmp4(ctx);
+        RK_HIP(ctx, runs.alloc(n));
+        RK_HIP(ctx, counts.alloc(n));
+        RK_HIP(ctx, flags.alloc(n));
+        RK_HIP(ctx, rocprim::run_length_encode(nullptr, t3, sorted.p, n, runs.p, counts.p, d_n.p, stream));
+        RK_HIP(ctx, tmp3.alloc(t3));
+        RK_HIP(ctx, rocprim::run_length_encode(tmp3.p, t3, sorted.p, n, runs.p, counts.p, d_n.p, stream));
+        unsigned long long n_runs = 0;
+        RK_TRY(rk_read_back(ctx, &n_runs, d_n.p, 8, stream));
+        if (n_runs) {
+            hipLaunchKernelGGL(k_count_flags, dim3(blocks_for(n_runs)), dim3(256), 0, stream, counts.p, n_runs, min_count, flags.p);
+            RK_HIP(ctx, rocprim::select(nullptr, t4, runs.p, flags.p, uniq.p, d_n.p, n_runs, stream));
+            RK_HIP(ctx, tmp4.alloc(t4));
+            RK_HIP(ctx, rocprim::select(tmp4.p, t4, runs.p, flags.p, uniq.p, d_n.p, n_runs, stream));
+            RK_TRY(rk_read_back(ctx, &nu, d_n.p, 8, stream));
+        }
+    }
+    if (nu) hipLaunchKernelGGL(k_narrow_keys<K>, dim3(blocks_for(nu)), dim3(256), 0, stream, uniq.p, nu, dst);
+    RK_HIP(ctx, hipGetLastError());
+    RK_HIP(ctx, hipStreamSynchronize(stream));  // the temporaries above return to the pool
+    *n_out = (uint32_t)nu;
+    return RK_OK;
+}
+
+extern "C" {
 
 int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *packed_dev,
                             uint64_t packed_bytes, const uint64_t *gbeg, const uint64_t *gend,
@@ -608,26 +797,18 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
     hipStream_t stream = (hipStream_t)stream_v;
     RK_HIP(ctx, hipSetDevice(ctx->device));
     const rk_params &P = f->params;
-
-    // key = genome << key_shift | dr_tuple; the 64-bit layout (use64) needs room for the genome id
     const int hash_bits = rk_hash_bits(&P);
-    const bool wide = hash_bits > 32;
-    const int key_shift = wide ? hash_bits : 32;
-    int gbits = 1;
-    while ((1ULL << gbits) < n_genomes) gbits++;
-    if (key_shift + gbits > 64)
-        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "%d-bit hashes leave no room for %u genome ids in one batch",
-                       hash_bits, n_genomes);
+    const bool wide = hash_bits > 32;  // use64 layout
+    const size_t key_bytes = wide ? 8 : 4;
 
     // ---- chunk table: one wave per chunk of up to `cb` consecutive 1 KiB blocks
-    uint64_t total_blocks = 0, total_len = 0;
+    uint64_t total_blocks = 0;
     for (uint32_t g = 0; g < n_genomes; g++) {
         if (gend[g] < gbeg[g] || (gbeg[g] & 1023) || gend[g] > packed_bytes)
             return rk_fail(ctx, RK_ERR_ARG, "genome %u: bad packed range", g);
         if (((gend[g] + 1023) & ~1023ULL) > packed_bytes && gend[g] > gbeg[g])
             return rk_fail(ctx, RK_ERR_ARG, "packed buffer must be padded to a multiple of 1024 bytes");
         total_blocks += (gend[g] - gbeg[g] + 1023) >> 10;
-        total_len += gend[g] - gbeg[g];
     }
     // aim for >= 4 rounds of 16 chunks per CU (256 CUs x 16 waves), 16..256 blocks each
     uint64_t cb = total_blocks / ((uint64_t)ctx->num_cu * 16 * 4 + 1);
@@ -644,30 +825,74 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
     }
     const uint32_t n_chunks = (uint32_t)c_gid.size();
 
-    DevBuf<uint32_t> d_gid, d_blocks;
-    DevBuf<uint64_t> d_beg;
-    DevBuf<unsigned long long> d_counters;  // [0]=n_cand [1]=n_windows
+    // ---- per-genome candidate regions: expected survivors = windows / 16^drlevel; x2 + slack, exact retry
+    std::vector<uint64_t> reg_off((size_t)n_genomes + 1, 0);
+    std::vector<uint32_t> reg_cap(n_genomes, 0);
+    std::vector<uint8_t> is_big(n_genomes, 0);
+    for (uint32_t g = 0; g < n_genomes; g++) {
+        const uint64_t want = 2 * ((gend[g] - gbeg[g]) >> (4 * P.drlevel)) + 192;
+        if (want > 0xFFFFFFF0ULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "genome %u is too long for one sketch pass", g);
+        reg_cap[g] = (uint32_t)want;
+    }
+
+    DevBuf<uint32_t> d_gid(ctx), d_blocks(ctx), d_cap(ctx), d_gcount(ctx), d_usize(ctx);
+    DevBuf<uint64_t> d_beg(ctx), d_regoff(ctx);
+    DevBuf<uint8_t> d_big(ctx);
+    DevBuf<SketchTail> d_tail(ctx);
     RK_HIP(ctx, d_gid.alloc(n_chunks));
     RK_HIP(ctx, d_blocks.alloc(n_chunks));
     RK_HIP(ctx, d_beg.alloc(n_chunks));
-    RK_HIP(ctx, d_counters.alloc(2));
+    RK_HIP(ctx, d_cap.alloc(n_genomes));
+    RK_HIP(ctx, d_regoff.alloc((size_t)n_genomes + 1));
+    RK_HIP(ctx, d_big.alloc(n_genomes));
+    RK_HIP(ctx, d_gcount.alloc(n_genomes));
+    RK_HIP(ctx, d_usize.alloc(n_genomes));
+    RK_HIP(ctx, d_tail.alloc(1));
     if (n_chunks) {
         RK_HIP(ctx, hipMemcpyAsync(d_gid.p, c_gid.data(), (size_t)n_chunks * 4, hipMemcpyHostToDevice, stream));
         RK_HIP(ctx, hipMemcpyAsync(d_blocks.p, c_blocks.data(), (size_t)n_chunks * 4, hipMemcpyHostToDevice, stream));
         RK_HIP(ctx, hipMemcpyAsync(d_beg.p, c_beg.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, stream));
     }
 
-    // candidate capacity: expected survivors = windows / 16^drlevel; x2 + slack, exact retry
-    uint64_t cap = 2 * (total_len >> (4 * P.drlevel)) + (uint64_t)n_genomes * 64 + 65536;
-    const size_t lds = 0;  // the kernel's LDS is static
-    sketch_kernel_t kern = pick_kernel((int)P.kmer_size, 2 * P.half_outctx_len, f->exact);
+    rk_sketches *s = new (std::nothrow) rk_sketches;
+    if (!s) return RK_ERR_NOMEM;
+    s->ctx = ctx;
+    s->n = n_genomes;
+    s->wide = wide;
+    s->is_set = true;  // sorted, distinct
+    struct Guard { rk_sketches *p; ~Guard() { if (p) rk_sketches_free(p); } } guard{s};
+    RK_TRY(pool_array(ctx, &s->d_off, (size_t)n_genomes + 1));
+    s->h_off.assign((size_t)n_genomes + 1, 0);
 
-    DevBuf<unsigned long long> cand;
-    unsigned long long counters[2] = {0, 0};
+    sketch_kernel_t kern = pick_kernel((int)P.kmer_size, 2 * P.half_outctx_len, f->exact);
+    DevBuf<unsigned long long> cand(ctx);
+    DevBuf<char> sorted_out(ctx);
+    std::vector<uint32_t> gcount(n_genomes, 0);
+    SketchTail tail{0, 0};
     for (int attempt = 0; attempt < 2; attempt++) {
-        if (cand.alloc(cap) != hipSuccess)
-            return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu candidate slots", (unsigned long long)cap);
-        RK_HIP(ctx, hipMemsetAsync(d_counters.p, 0, 16, stream));
+        uint64_t total_cap = 0;
+        size_t small_lds = key_bytes;
+        bool any_big = false;
+        for (uint32_t g = 0; g < n_genomes; g++) {
+            reg_off[g] = total_cap;
+            total_cap += reg_cap[g];
+            size_t p2 = 1;
+            while (p2 < reg_cap[g]) p2 <<= 1;
+            is_big[g] = p2 * key_bytes > kDedupMaxBytes;
+            if (is_big[g]) any_big = true;
+            else small_lds = std::max(small_lds, p2 * key_bytes);
+        }
+        reg_off[n_genomes] = total_cap;
+        if (cand.alloc(total_cap) != hipSuccess || sorted_out.alloc(total_cap * key_bytes) != hipSuccess)
+            return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu candidate slots", (unsigned long long)total_cap);
+        if (n_genomes) {
+            RK_HIP(ctx, hipMemcpyAsync(d_cap.p, reg_cap.data(), (size_t)n_genomes * 4, hipMemcpyHostToDevice, stream));
+            RK_HIP(ctx, hipMemcpyAsync(d_regoff.p, reg_off.data(), ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice, stream));
+            RK_HIP(ctx, hipMemcpyAsync(d_big.p, is_big.data(), (size_t)n_genomes, hipMemcpyHostToDevice, stream));
+            RK_HIP(ctx, hipMemsetAsync(d_gcount.p, 0, (size_t)n_genomes * 4, stream));
+            RK_HIP(ctx, hipMemsetAsync(d_usize.p, 0, (size_t)n_genomes * 4, stream));
+        }
+        RK_HIP(ctx, hipMemsetAsync(d_tail.p, 0, sizeof(SketchTail), stream));
         if (n_chunks) {
             SketchArgs a;
             a.packed = packed_dev;
@@ -688,102 +913,84 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             a.dim_end = P.dim_end;
             a.dr_shift = 4 * P.drlevel;
             a.und1_shift = (int32_t)P.kmer_size * 2 - P.half_outctx_len * 4;
-            a.key_shift = key_shift;
             a.cand = cand.p;
-            a.cand_cap = cap;
-            a.n_cand = d_counters.p;
-            a.n_windows = d_counters.p + 1;
+            a.reg_off = d_regoff.p;
+            a.reg_cap = d_cap.p;
+            a.gcount = d_gcount.p;
+            a.n_windows = &d_tail.p->windows;
             const uint32_t want = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
             // persistent: one workgroup per CU (the 156 KiB LDS image admits only one), each
             // striding over the chunk table, so the filter image is staged once per CU
             const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kSketchThreads), lds, stream, a);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kSketchThreads), 0, stream, a);
             RK_HIP(ctx, hipGetLastError());
         }
-        RK_HIP(ctx, hipMemcpyAsync(counters, d_counters.p, 16, hipMemcpyDeviceToHost, stream));
-        RK_HIP(ctx, hipStreamSynchronize(stream));
-        if (counters[0] <= cap) break;
-        cap = counters[0];  // overflow: rerun with the exact count
-        if (attempt == 1) return rk_fail(ctx, RK_ERR_CAPACITY, "candidate overflow persisted");
-    }
-    const uint64_t n_cand = counters[0];
-
-    // ---- per-genome dedup: sort (genome, hash) keys, unique, split into CSR
-    rk_sketches *s = new (std::nothrow) rk_sketches;
-    if (!s) return RK_ERR_NOMEM;
-    s->ctx = ctx;
-    s->n = n_genomes;
-    s->windows = counters[1];
-    struct Guard { rk_sketches *p; ~Guard() { if (p) rk_sketches_free(p); } } guard{s};
-    RK_HIP(ctx, hipMalloc((void **)&s->d_off, ((size_t)n_genomes + 1) * 8));
-    uint64_t n_unique = 0;
-    DevBuf<unsigned long long> sorted, uniq;
-    s->wide = wide;
-    if (n_cand) {
-        RK_HIP(ctx, sorted.alloc(n_cand));
-        RK_HIP(ctx, uniq.alloc(n_cand));
-        DevBuf<unsigned long long> d_nuniq;
-        RK_HIP(ctx, d_nuniq.alloc(1));
-        size_t t1 = 0, t2 = 0;
-        RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t1, cand.p, sorted.p, n_cand, 0, (unsigned)(key_shift + gbits), stream));
-        RK_HIP(ctx, rocprim::unique(nullptr, t2, sorted.p, uniq.p, d_nuniq.p, n_cand,
-                                    rocprim::equal_to<unsigned long long>(), stream));
-        DevBuf<char> tmp;
-        RK_HIP(ctx, tmp.alloc(std::max(t1, t2)));
-        RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, t1, cand.p, sorted.p, n_cand, 0, (unsigned)(key_shift + gbits), stream));
-        if (min_count <= 1) {  // set semantics (FASTA, src/sketch.cpp:526-529)
-            RK_HIP(ctx, rocprim::unique(tmp.p, t2, sorted.p, uniq.p, d_nuniq.p, n_cand,
-                                        rocprim::equal_to<unsigned long long>(), stream));
-        } else {  // FASTQ: keep a hash only if it occurred >= min_count times (src/sketch.cpp:828-845)
-            DevBuf<unsigned long long> runs;
-            DevBuf<unsigned int> counts;
-            DevBuf<unsigned char> flags;
-            RK_HIP(ctx, runs.alloc(n_cand));
-            RK_HIP(ctx, counts.alloc(n_cand));
-            RK_HIP(ctx, flags.alloc(n_cand));
-            size_t t3 = 0, t4 = 0;
-            RK_HIP(ctx, rocprim::run_length_encode(nullptr, t3, sorted.p, n_cand, runs.p, counts.p, d_nuniq.p, stream));
-            DevBuf<char> tmp3;
-            RK_HIP(ctx, tmp3.alloc(t3));
-            RK_HIP(ctx, rocprim::run_length_encode(tmp3.p, t3, sorted.p, n_cand, runs.p, counts.p, d_nuniq.p, stream));
-            unsigned long long n_runs = 0;
-            RK_HIP(ctx, hipMemcpyAsync(&n_runs, d_nuniq.p, 8, hipMemcpyDeviceToHost, stream));
-            RK_HIP(ctx, hipStreamSynchronize(stream));
-            if (n_runs) {
-                hipLaunchKernelGGL(k_count_flags, dim3(blocks_for(n_runs)), dim3(256), 0, stream, counts.p, n_runs,
-                                   min_count, flags.p);
-                RK_HIP(ctx, rocprim::select(nullptr, t4, runs.p, flags.p, uniq.p, d_nuniq.p, n_runs, stream));
-                DevBuf<char> tmp4;
-                RK_HIP(ctx, tmp4.alloc(t4));
-                RK_HIP(ctx, rocprim::select(tmp4.p, t4, runs.p, flags.p, uniq.p, d_nuniq.p, n_runs, stream));
-                RK_HIP(ctx, hipStreamSynchronize(stream));
+        if (n_genomes) {
+            // ---- per-genome dedup in LDS, sizes -> offsets, CSR placement: three launches, no host round trip
+            if (wide) {
+                if (small_lds > 48 * 1024)
+                    RK_HIP(ctx, hipFuncSetAttribute((const void *)k_dedup<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+                hipLaunchKernelGGL(k_dedup<uint64_t>, dim3(n_genomes), dim3(kDedupThreads), small_lds, stream, cand.p, d_regoff.p,
+                                   d_cap.p, d_gcount.p, d_big.p, min_count, (uint64_t *)sorted_out.p, d_usize.p, d_tail.p);
             } else {
-                RK_HIP(ctx, hipMemsetAsync(d_nuniq.p, 0, 8, stream));
+                if (small_lds > 48 * 1024)
+                    RK_HIP(ctx, hipFuncSetAttribute((const void *)k_dedup<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+                hipLaunchKernelGGL(k_dedup<uint32_t>, dim3(n_genomes), dim3(kDedupThreads), small_lds, stream, cand.p, d_regoff.p,
+                                   d_cap.p, d_gcount.p, d_big.p, min_count, (uint32_t *)sorted_out.p, d_usize.p, d_tail.p);
+            }
+            RK_HIP(ctx, hipGetLastError());
+        }
+        if (any_big) {  // 3 Gb genomes: their regions exceed the LDS sort; needs their candidate counts on the host
+            RK_HIP(ctx, hipMemcpyAsync(gcount.data(), d_gcount.p, (size_t)n_genomes * 4, hipMemcpyDeviceToHost, stream));
+            RK_HIP(ctx, hipStreamSynchronize(stream));
+            bool overflow = false;
+            for (uint32_t g = 0; g < n_genomes && !overflow; g++) overflow = is_big[g] && gcount[g] > reg_cap[g];
+            for (uint32_t g = 0; g < n_genomes && !overflow; g++) {
+                if (!is_big[g]) continue;
+                uint32_t nu = 0;
+                if (wide)
+                    RK_TRY(dedup_big<uint64_t>(ctx, cand.p + reg_off[g], gcount[g], hash_bits, min_count,
+                                               (uint64_t *)sorted_out.p + reg_off[g], &nu, stream));
+                else
+                    RK_TRY(dedup_big<uint32_t>(ctx, cand.p + reg_off[g], gcount[g], hash_bits, min_count,
+                                               (uint32_t *)sorted_out.p + reg_off[g], &nu, stream));
+                memcpy(ctx->pinned, &nu, 4);
+                RK_HIP(ctx, hipMemcpyAsync(d_usize.p + g, ctx->pinned, 4, hipMemcpyHostToDevice, stream));
+                RK_HIP(ctx, hipStreamSynchronize(stream));  // the pinned word is reused
             }
         }
-        unsigned long long nu = 0;
-        RK_HIP(ctx, hipMemcpyAsync(&nu, d_nuniq.p, 8, hipMemcpyDeviceToHost, stream));
-        RK_HIP(ctx, hipStreamSynchronize(stream));
-        n_unique = nu;
+        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, stream, d_usize.p, n_genomes, s->d_off);
+        RK_HIP(ctx, hipGetLastError());
+        // ---- the one read-back of the common case: offsets, candidate counts (for the retry), window count
+        RK_HIP(ctx, hipMemcpyAsync(s->h_off.data(), s->d_off, ((size_t)n_genomes + 1) * 8, hipMemcpyDeviceToHost, stream));
+        if (n_genomes)
+            RK_HIP(ctx, hipMemcpyAsync(gcount.data(), d_gcount.p, (size_t)n_genomes * 4, hipMemcpyDeviceToHost, stream));
+        RK_TRY(rk_read_back(ctx, &tail, d_tail.p, sizeof(tail), stream));
+        bool overflow = (tail.flags & kFlagOverflow) != 0;
+        for (uint32_t g = 0; g < n_genomes; g++)
+            if (gcount[g] > reg_cap[g]) {
+                overflow = true;
+                reg_cap[g] = gcount[g];  // exact on the second pass
+            }
+        if (!overflow) break;
+        if (attempt == 1) return rk_fail(ctx, RK_ERR_CAPACITY, "candidate overflow persisted");
     }
-    s->total = n_unique;
+    s->windows = tail.windows;
+    s->total = s->h_off[n_genomes];
+    for (uint32_t g = 0; g < n_genomes; g++) s->max_size = std::max<uint64_t>(s->max_size, s->h_off[g + 1] - s->h_off[g]);
     if (wide) {
-        RK_HIP(ctx, hipMalloc((void **)&s->d_hashes64, (n_unique + 1) * 8));
-        if (n_unique)
-            hipLaunchKernelGGL(k_split_keys64, dim3(blocks_for(n_unique)), dim3(256), 0, stream, uniq.p, n_unique,
-                               key_shift, s->d_hashes64);
+        RK_TRY(pool_array(ctx, &s->d_hashes64, s->total + 1));
+        if (n_genomes)
+            hipLaunchKernelGGL(k_csr_place<uint64_t>, dim3(n_genomes), dim3(256), 0, stream, (const uint64_t *)sorted_out.p,
+                               d_regoff.p, d_usize.p, s->d_off, s->d_hashes64);
     } else {
-        RK_HIP(ctx, hipMalloc((void **)&s->d_hashes, (n_unique + 1) * 4));
-        if (n_unique)
-            hipLaunchKernelGGL(k_split_keys, dim3(blocks_for(n_unique)), dim3(256), 0, stream, uniq.p, n_unique,
-                               s->d_hashes);
+        RK_TRY(pool_array(ctx, &s->d_hashes, s->total + 1));
+        if (n_genomes)
+            hipLaunchKernelGGL(k_csr_place<uint32_t>, dim3(n_genomes), dim3(256), 0, stream, (const uint32_t *)sorted_out.p,
+                               d_regoff.p, d_usize.p, s->d_off, s->d_hashes);
     }
-    hipLaunchKernelGGL(k_genome_offsets, dim3(blocks_for((uint64_t)n_genomes + 1)), dim3(256), 0, stream,
-                       uniq.p, n_unique, n_genomes, key_shift, s->d_off);
     RK_HIP(ctx, hipGetLastError());
-    s->h_off.resize((size_t)n_genomes + 1);
-    RK_HIP(ctx, hipMemcpyAsync(s->h_off.data(), s->d_off, ((size_t)n_genomes + 1) * 8, hipMemcpyDeviceToHost, stream));
-    RK_HIP(ctx, hipStreamSynchronize(stream));
+    RK_HIP(ctx, hipStreamSynchronize(stream));  // temporaries return to the pool; the result is complete
     guard.p = nullptr;
     *out = s;
     return RK_OK;
@@ -824,14 +1031,39 @@ int rk_sketch_batch_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *seq, cons
             }
         }
     }
-    DevBuf<uint8_t> d_packed;
+    DevBuf<uint8_t> d_packed(ctx);
     if (!rc && d_packed.alloc(bytes) != hipSuccess) rc = rk_fail(ctx, RK_ERR_NOMEM, "device alloc of %llu bytes failed", (unsigned long long)bytes);
-    if (!rc && hipMemcpy(d_packed.p, h_packed, bytes, hipMemcpyHostToDevice) != hipSuccess)
+    if (!rc && (hipMemcpyAsync(d_packed.p, h_packed, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess))
         rc = rk_fail(ctx, RK_ERR_HIP, "sequence upload failed");
     (void)hipHostFree(h_packed);
     if (rc) return rc;
     return rk_sketch_packed_dev_ex(ctx, f, d_packed.p, bytes, gbeg.data(), gend.data(), n_genomes,
-                                   min_count ? min_count : 1, nullptr, out);
+                                   min_count ? min_count : 1, ctx->stream, out);
 }
 
 }  // extern "C"
+
+// sketches that crossed the boundary from the host (or from caller-owned device arrays): are they sets in
+// ascending order?  An intersection count is then bounded by the smaller sketch (narrow LDS counters,
+// rk_distq.hip) and the index build needs no duplicate check.  Synchronises ctx->stream.
+int rk_sketches_classify(rk_ctx *ctx, rk_sketches *s)
+{
+    s->max_size = 0;
+    for (uint32_t g = 0; g < s->n; g++) s->max_size = std::max<uint64_t>(s->max_size, s->h_off[g + 1] - s->h_off[g]);
+    DevBuf<uint32_t> bad(ctx);
+    RK_HIP(ctx, bad.alloc(1));
+    RK_HIP(ctx, hipMemsetAsync(bad.p, 0, 4, ctx->stream));
+    if (s->n && s->total) {
+        const unsigned blocks = (s->n + 3) / 4;
+        if (s->wide)
+            hipLaunchKernelGGL(k_check_sets<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream, s->d_hashes64, s->d_off, s->n, bad.p);
+        else
+            hipLaunchKernelGGL(k_check_sets<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream, s->d_hashes, s->d_off, s->n, bad.p);
+        RK_HIP(ctx, hipGetLastError());
+    }
+    uint32_t b = 0;
+    RK_TRY(rk_read_back(ctx, &b, bad.p, 4, ctx->stream));
+    s->is_set = b == 0;
+    return RK_OK;
+}
