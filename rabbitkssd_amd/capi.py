@@ -242,10 +242,10 @@ class Context:
         return np.frombuffer(buf, dtype=HIT_DTYPE).copy(), dense
 
     def dist_rows_dev(self, index, triangle, metric, kmer_size, max_dist, hits_dev_ptr, hits_cap,
-                      n_hits_dev_ptr, row_first=0, row_step=1, stream=0, row_block=0):
+                      n_hits_dev_ptr, row_first=0, row_step=1, stream=0, row_block=0, queries=None):
         opts = DistOpts(int(triangle), int(metric), int(kmer_size), int(row_block), float(max_dist),
                         int(row_first), int(row_step))
-        self.check(lib().rk_dist_rows_dev(self._h, index._h, None, C.byref(opts),
+        self.check(lib().rk_dist_rows_dev(self._h, index._h, queries._h if queries is not None else None, C.byref(opts),
                                           C.c_void_p(hits_dev_ptr), C.c_uint64(hits_cap),
                                           C.c_void_p(n_hits_dev_ptr), C.c_void_p(stream)))
 

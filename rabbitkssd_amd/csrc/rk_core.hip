@@ -64,9 +64,25 @@ void rk_pool_free(rk_ctx *ctx, void *p)
     ctx->free_blocks.emplace(it->second, p);
 }
 
+void *rk_pinned_scratch(rk_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pinned_bytes) return ctx->pinned;
+    size_t want = std::max<size_t>(kPinnedBytes, ctx->pinned_bytes);
+    while (want < bytes) want *= 2;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = p;
+    ctx->pinned_bytes = want;
+    return p;
+}
+
 int rk_read_back(rk_ctx *ctx, void *dst, const void *src_dev, size_t bytes, hipStream_t stream)
 {
-    if (bytes <= kPinnedBytes && ctx->pinned) {
+    if (bytes <= ctx->pinned_bytes && ctx->pinned) {
         RK_HIP(ctx, hipMemcpyAsync(ctx->pinned, src_dev, bytes, hipMemcpyDeviceToHost, stream));
         RK_HIP(ctx, hipStreamSynchronize(stream));
         memcpy(dst, ctx->pinned, bytes);
@@ -136,8 +152,7 @@ int rk_ctx_create(int device, rk_ctx **out)
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess &&
         (size_t)v > ctx->max_lds)
         ctx->max_lds = (size_t)v;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc(&ctx->pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || !rk_pinned_scratch(ctx, kPinnedBytes)) {
         rk_ctx_destroy(ctx);
         return RK_ERR_HIP;
     }

@@ -22,7 +22,8 @@ struct rk_ctx {
     // the context's own stream: every synchronous API call enqueues here (never on the null stream, whose implicit
     // synchronisation would serialise the caller's other streams) and synchronises it before returning
     hipStream_t stream = nullptr;
-    void *pinned = nullptr;  // kPinnedBytes of page-locked scratch for small read-backs / uploads
+    void *pinned = nullptr;  // page-locked scratch for small read-backs / uploads (grow-only, see rk_pinned_scratch)
+    size_t pinned_bytes = 0;
     // caching device allocator: hipMalloc / hipFree cost 50-300 us each (hipFree also synchronises the device) and the
     // index build alone needs ~25 buffers, so freed blocks are kept and handed out again; steady-state calls
     // allocate nothing.  Blocks return to the driver in rk_ctx_trim / rk_ctx_destroy.
@@ -44,6 +45,8 @@ void rk_pool_free(rk_ctx *ctx, void *p);
 // synchronises `stream`
 int rk_read_back(rk_ctx *ctx, void *dst, const void *src_dev, size_t bytes, hipStream_t stream);
 int rk_occupancy(rk_ctx *ctx, const void *kernel, int threads, size_t lds_bytes);
+// the context's page-locked scratch, grown to at least `bytes` (contents are not preserved); nullptr on failure
+void *rk_pinned_scratch(rk_ctx *ctx, size_t bytes);
 
 #define RK_HIP(ctx, call)                                                                   \
     do {                                                                                    \

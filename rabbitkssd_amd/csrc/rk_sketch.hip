@@ -67,12 +67,22 @@ constexpr size_t kStageLdsBytes = kWavesPerBlock * (kStageCap * 8 + 8);
 constexpr size_t kSketchLdsBytes = kFilterLdsBytes + kStageLdsBytes;
 static_assert(kSketchLdsBytes <= 160 * 1024, "LDS image must fit one CU");
 
+// per-genome row of the pass table (one small upload per pass): where the genome lies in the packed buffer, which
+// chunks (runs of `chunk_blocks` consecutive 1 KiB blocks, one wave each) are its own, and its candidate region
+struct GenomeRow {
+    uint64_t beg;          // byte offset in the packed buffer (multiple of 1024)
+    uint64_t reg_off;      // first slot of the candidate region
+    uint32_t nblk;         // 1 KiB blocks
+    uint32_t first_chunk;  // global index of its first chunk; row[n_genomes].first_chunk = number of chunks
+    uint32_t reg_cap;      // slots in the candidate region
+    uint32_t is_big;       // region beyond the LDS sort capacity: device-wide sort
+};
+static_assert(sizeof(GenomeRow) == 32, "GenomeRow is uploaded as raw bytes");
+
 struct SketchArgs {
     const uint8_t *packed;
-    const uint32_t *chunk_gid;
-    const uint64_t *chunk_beg;     // byte offset of the chunk (multiple of 1024)
-    const uint32_t *chunk_blocks;  // number of 1 KiB blocks; bit 31 = first chunk of its genome
-    uint32_t n_chunks;
+    const GenomeRow *rows;
+    uint32_t n_genomes, n_chunks, chunk_blocks;
     const uint32_t *filter_image;  // kFilterLdsBytes, copied to LDS by every workgroup
     const int32_t *table;          // int32[16^half_subk]
     uint64_t tupmask, undomask0, undomask1;
@@ -80,8 +90,6 @@ struct SketchArgs {
     // emitted dr_tuples go to the candidate region of their genome: cand[reg_off[g] .. + reg_cap[g]); gcount[g]
     // counts every emitted key, also those beyond the capacity (overflow is detected, the host retries)
     unsigned long long *cand;
-    const uint64_t *reg_off;
-    const uint32_t *reg_cap;
     uint32_t *gcount;
     unsigned long long *n_windows;
 };
@@ -205,13 +213,19 @@ __global__ __launch_bounds__(kSketchThreads) void rk_sketch_kernel(SketchArgs a)
     };
 
     for (uint32_t c = blockIdx.x * kWavesPerBlock + wave; c < a.n_chunks; c += gridDim.x * kWavesPerBlock) {
-        const uint32_t gid = a.chunk_gid[c];
-        const uint64_t beg = a.chunk_beg[c];
-        const uint32_t nbf = a.chunk_blocks[c];
-        const uint32_t nb = nbf & 0x7FFFFFFFu;
-        const uint8_t *base = a.packed + beg;
-        unsigned long long *region = a.cand + a.reg_off[gid];
-        const uint32_t region_cap = a.reg_cap[gid];
+        // the genome of chunk c: largest g with first_chunk[g] <= c (wave-uniform binary search, scalar loads)
+        uint32_t gid = 0;
+        for (uint32_t hi = a.n_genomes; hi - gid > 1;) {
+            const uint32_t mid = (gid + hi) >> 1;
+            if (a.rows[mid].first_chunk <= c) gid = mid; else hi = mid;
+        }
+        const GenomeRow row = a.rows[gid];
+        const uint32_t b0 = (c - row.first_chunk) * a.chunk_blocks;
+        const uint32_t nb = min(a.chunk_blocks, row.nblk - b0);
+        const uint32_t nbf = b0 == 0 ? 0x80000000u : 0u;  // bit 31: first chunk of its genome
+        const uint8_t *base = a.packed + row.beg + (size_t)b0 * 1024;
+        unsigned long long *region = a.cand + row.reg_off;
+        const uint32_t region_cap = row.reg_cap;
 
         // words of the two 16-base groups before the chunk (lanes "-2" and "-1")
         uint32_t cG2 = 0, cG1 = 0, cV2 = 0, cV1 = 0;
@@ -377,18 +391,18 @@ struct SketchTail {  // device-side results of one sketch pass, read back in one
 };
 
 template <class K>
-__global__ __launch_bounds__(kDedupThreads) void k_dedup(const unsigned long long *cand, const uint64_t *reg_off,
-                                                        const uint32_t *reg_cap, const uint32_t *gcount,
-                                                        const uint8_t *is_big, uint32_t min_count, K *sorted_out,
+__global__ __launch_bounds__(kDedupThreads) void k_dedup(const unsigned long long *cand, const GenomeRow *rows,
+                                                        const uint32_t *gcount, uint32_t min_count, K *sorted_out,
                                                         uint32_t *usize, SketchTail *tail)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dedup_lds[];
     K *a = reinterpret_cast<K *>(dedup_lds);
     __shared__ uint32_t wave_tot[kDedupThreads / 64];
     const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (is_big[g]) return;  // sorted by the device-wide path
+    const GenomeRow row = rows[g];
+    if (row.is_big) return;  // sorted by the device-wide path
     const uint32_t n = gcount[g];
-    if (n > reg_cap[g]) {   // the region overflowed: the host reruns the pass with the exact capacities
+    if (n > row.reg_cap) {  // the region overflowed: the host reruns the pass with the exact capacities
         if (tid == 0) {
             usize[g] = 0;
             atomicOr(&tail->flags, (unsigned long long)kFlagOverflow);
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(kDedupThreads) void k_dedup(const unsigned long lon
     }
     uint32_t P = 1;
     while (P < n) P <<= 1;
-    const unsigned long long *src = cand + reg_off[g];
+    const unsigned long long *src = cand + row.reg_off;
     // padding keys are all ones: they sort behind every real key (or tie with it), so the first n are the real ones
     for (uint32_t i = tid; i < P; i += kDedupThreads) a[i] = i < n ? (K)src[i] : (K)~(K)0;
     __syncthreads();
@@ -435,14 +449,14 @@ __global__ __launch_bounds__(kDedupThreads) void k_dedup(const unsigned long lon
     __syncthreads();
     uint32_t at = incl - mine;
     for (uint32_t w = 0; w < wave; w++) at += wave_tot[w];
-    K *dst = sorted_out + reg_off[g];
+    K *dst = sorted_out + row.reg_off;
     for (uint32_t i = i0; i < i1; i++)
         if (kept(i)) dst[at++] = a[i];
     if (tid == kDedupThreads - 1) usize[g] = at;
 }
 
 // single workgroup: off = exclusive scan of the per-genome sizes
-__global__ void k_size_scan(const uint32_t *usize, uint32_t n_genomes, uint64_t *off)
+__global__ void k_size_scan(const uint32_t *usize, uint32_t n_genomes, uint64_t *off, uint64_t *off_copy)
 {
     __shared__ unsigned long long part[1024 / 64];
     __shared__ unsigned long long carry;
@@ -461,7 +475,7 @@ __global__ void k_size_scan(const uint32_t *usize, uint32_t n_genomes, uint64_t 
         __syncthreads();
         unsigned long long before = carry;
         for (uint32_t w = 0; w < wave; w++) before += part[w];
-        if (g < n_genomes) off[g] = before + incl - len;
+        if (g < n_genomes) off[g] = off_copy[g] = before + incl - len;
         __syncthreads();
         if (tid == 0) {
             unsigned long long t = carry;
@@ -470,15 +484,15 @@ __global__ void k_size_scan(const uint32_t *usize, uint32_t n_genomes, uint64_t 
         }
         __syncthreads();
     }
-    if (tid == 0) off[n_genomes] = carry;
+    if (tid == 0) off[n_genomes] = off_copy[n_genomes] = carry;
 }
 
 // one workgroup per genome: its sorted distinct hashes move to their place in the CSR
 template <class K>
-__global__ void k_csr_place(const K *sorted_out, const uint64_t *reg_off, const uint32_t *usize, const uint64_t *off, K *hashes)
+__global__ void k_csr_place(const K *sorted_out, const GenomeRow *rows, const uint32_t *usize, const uint64_t *off, K *hashes)
 {
     const uint32_t g = blockIdx.x;
-    const K *src = sorted_out + reg_off[g];
+    const K *src = sorted_out + rows[g].reg_off;
     K *dst = hashes + off[g];
     for (uint32_t i = threadIdx.x; i < usize[g]; i += blockDim.x) dst[i] = src[i];
 }
@@ -496,15 +510,18 @@ template <class K> __global__ void k_narrow_keys(const unsigned long long *ukeys
     if (i < n) out[i] = (K)ukeys[i];
 }
 
-// every genome's hashes strictly ascending?  (one wave per genome)
-template <class K> __global__ void k_check_sets(const K *hashes, const uint64_t *off, uint32_t n_genomes, uint32_t *bad)
+// every genome's hashes strictly ascending?  A descent may only sit where a new genome starts: the rare candidates
+// look their position up in the offsets
+template <class K> __global__ void k_check_sets(const K *hashes, uint64_t total, const uint64_t *off, uint32_t n_genomes, uint32_t *bad)
 {
-    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (g >= n_genomes) return;
-    const uint64_t e1 = off[g + 1];
-    bool b = false;
-    for (uint64_t e = off[g] + 1 + (threadIdx.x & 63); e < e1; e += 64) b |= hashes[e] <= hashes[e - 1];
-    if (__ballot(b) && (threadIdx.x & 63) == 0) *bad = 1;
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (e >= total || hashes[e] > hashes[e - 1]) return;
+    uint32_t lo = 0, hi = n_genomes;  // largest g with off[g] <= e
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= e) lo = mid; else hi = mid;
+    }
+    if (off[lo] != e) *bad = 1;
 }
 
 inline unsigned blocks_for(uint64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
@@ -801,58 +818,50 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
     const bool wide = hash_bits > 32;  // use64 layout
     const size_t key_bytes = wide ? 8 : 4;
 
-    // ---- chunk table: one wave per chunk of up to `cb` consecutive 1 KiB blocks
+    // ---- the pass table: one row per genome (one wave walks one chunk of `cb` consecutive 1 KiB blocks)
     uint64_t total_blocks = 0;
     for (uint32_t g = 0; g < n_genomes; g++) {
         if (gend[g] < gbeg[g] || (gbeg[g] & 1023) || gend[g] > packed_bytes)
             return rk_fail(ctx, RK_ERR_ARG, "genome %u: bad packed range", g);
         if (((gend[g] + 1023) & ~1023ULL) > packed_bytes && gend[g] > gbeg[g])
             return rk_fail(ctx, RK_ERR_ARG, "packed buffer must be padded to a multiple of 1024 bytes");
+        if (((gend[g] - gbeg[g] + 1023) >> 10) > 0x7FFFFFFFULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "genome %u is too long", g);
         total_blocks += (gend[g] - gbeg[g] + 1023) >> 10;
     }
     // aim for >= 4 rounds of 16 chunks per CU (256 CUs x 16 waves), 16..256 blocks each
     uint64_t cb = total_blocks / ((uint64_t)ctx->num_cu * 16 * 4 + 1);
     cb = std::min<uint64_t>(256, std::max<uint64_t>(16, cb));
-    std::vector<uint32_t> c_gid, c_blocks;
-    std::vector<uint64_t> c_beg;
+    std::vector<GenomeRow> rows((size_t)n_genomes + 1);
+    uint64_t n_chunks64 = 0;
     for (uint32_t g = 0; g < n_genomes; g++) {
-        const uint64_t nblk = (gend[g] - gbeg[g] + 1023) >> 10;
-        for (uint64_t b = 0; b < nblk; b += cb) {
-            c_gid.push_back(g);
-            c_beg.push_back(gbeg[g] + (b << 10));
-            c_blocks.push_back((uint32_t)std::min<uint64_t>(cb, nblk - b) | (b == 0 ? 0x80000000u : 0));
-        }
-    }
-    const uint32_t n_chunks = (uint32_t)c_gid.size();
-
-    // ---- per-genome candidate regions: expected survivors = windows / 16^drlevel; x2 + slack, exact retry
-    std::vector<uint64_t> reg_off((size_t)n_genomes + 1, 0);
-    std::vector<uint32_t> reg_cap(n_genomes, 0);
-    std::vector<uint8_t> is_big(n_genomes, 0);
-    for (uint32_t g = 0; g < n_genomes; g++) {
+        GenomeRow &r = rows[g];
+        r.beg = gbeg[g];
+        r.nblk = (uint32_t)((gend[g] - gbeg[g] + 1023) >> 10);
+        r.first_chunk = (uint32_t)n_chunks64;
+        n_chunks64 += (r.nblk + cb - 1) / cb;
+        // candidate region: expected survivors = windows / 16^drlevel; x2 + slack, exact retry on overflow
         const uint64_t want = 2 * ((gend[g] - gbeg[g]) >> (4 * P.drlevel)) + 192;
-        if (want > 0xFFFFFFF0ULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "genome %u is too long for one sketch pass", g);
-        reg_cap[g] = (uint32_t)want;
+        if (want > 0xFFFFFFF0ULL || n_chunks64 > 0xFFFFFFF0ULL)
+            return rk_fail(ctx, RK_ERR_UNSUPPORTED, "genome %u is too long for one sketch pass", g);
+        r.reg_cap = (uint32_t)want;
     }
+    const uint32_t n_chunks = (uint32_t)n_chunks64;
+    rows[n_genomes] = GenomeRow{0, 0, 0, n_chunks, 0, 0};
 
-    DevBuf<uint32_t> d_gid(ctx), d_blocks(ctx), d_cap(ctx), d_gcount(ctx), d_usize(ctx);
-    DevBuf<uint64_t> d_beg(ctx), d_regoff(ctx);
-    DevBuf<uint8_t> d_big(ctx);
-    DevBuf<SketchTail> d_tail(ctx);
-    RK_HIP(ctx, d_gid.alloc(n_chunks));
-    RK_HIP(ctx, d_blocks.alloc(n_chunks));
-    RK_HIP(ctx, d_beg.alloc(n_chunks));
-    RK_HIP(ctx, d_cap.alloc(n_genomes));
-    RK_HIP(ctx, d_regoff.alloc((size_t)n_genomes + 1));
-    RK_HIP(ctx, d_big.alloc(n_genomes));
-    RK_HIP(ctx, d_gcount.alloc(n_genomes));
+    // device side of the pass: table in, results out -- one upload and one read-back through the pinned scratch
+    const size_t rows_bytes = rows.size() * sizeof(GenomeRow);
+    const size_t res_bytes = sizeof(SketchTail) + ((size_t)n_genomes + 1) * 8 + (size_t)n_genomes * 4;  // tail | off | gcount
+    char *pinned = static_cast<char *>(rk_pinned_scratch(ctx, std::max(rows_bytes, res_bytes)));
+    if (!pinned) return rk_fail(ctx, RK_ERR_NOMEM, "cannot pin %llu bytes", (unsigned long long)std::max(rows_bytes, res_bytes));
+    DevBuf<GenomeRow> d_rows(ctx);
+    DevBuf<char> d_res(ctx);
+    DevBuf<uint32_t> d_usize(ctx);
+    RK_HIP(ctx, d_rows.alloc(rows.size()));
+    RK_HIP(ctx, d_res.alloc(res_bytes));
     RK_HIP(ctx, d_usize.alloc(n_genomes));
-    RK_HIP(ctx, d_tail.alloc(1));
-    if (n_chunks) {
-        RK_HIP(ctx, hipMemcpyAsync(d_gid.p, c_gid.data(), (size_t)n_chunks * 4, hipMemcpyHostToDevice, stream));
-        RK_HIP(ctx, hipMemcpyAsync(d_blocks.p, c_blocks.data(), (size_t)n_chunks * 4, hipMemcpyHostToDevice, stream));
-        RK_HIP(ctx, hipMemcpyAsync(d_beg.p, c_beg.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice, stream));
-    }
+    SketchTail *d_tail = reinterpret_cast<SketchTail *>(d_res.p);
+    uint64_t *d_off_copy = reinterpret_cast<uint64_t *>(d_res.p + sizeof(SketchTail));
+    uint32_t *d_gcount = reinterpret_cast<uint32_t *>(d_res.p + sizeof(SketchTail) + ((size_t)n_genomes + 1) * 8);
 
     rk_sketches *s = new (std::nothrow) rk_sketches;
     if (!s) return RK_ERR_NOMEM;
@@ -874,32 +883,31 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
         size_t small_lds = key_bytes;
         bool any_big = false;
         for (uint32_t g = 0; g < n_genomes; g++) {
-            reg_off[g] = total_cap;
-            total_cap += reg_cap[g];
+            rows[g].reg_off = total_cap;
+            total_cap += rows[g].reg_cap;
             size_t p2 = 1;
-            while (p2 < reg_cap[g]) p2 <<= 1;
-            is_big[g] = p2 * key_bytes > kDedupMaxBytes;
-            if (is_big[g]) any_big = true;
+            while (p2 < rows[g].reg_cap) p2 <<= 1;
+            rows[g].is_big = p2 * key_bytes > kDedupMaxBytes;
+            if (rows[g].is_big) any_big = true;
             else small_lds = std::max(small_lds, p2 * key_bytes);
         }
-        reg_off[n_genomes] = total_cap;
         if (cand.alloc(total_cap) != hipSuccess || sorted_out.alloc(total_cap * key_bytes) != hipSuccess)
             return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu candidate slots", (unsigned long long)total_cap);
-        if (n_genomes) {
-            RK_HIP(ctx, hipMemcpyAsync(d_cap.p, reg_cap.data(), (size_t)n_genomes * 4, hipMemcpyHostToDevice, stream));
-            RK_HIP(ctx, hipMemcpyAsync(d_regoff.p, reg_off.data(), ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice, stream));
-            RK_HIP(ctx, hipMemcpyAsync(d_big.p, is_big.data(), (size_t)n_genomes, hipMemcpyHostToDevice, stream));
-            RK_HIP(ctx, hipMemsetAsync(d_gcount.p, 0, (size_t)n_genomes * 4, stream));
-            RK_HIP(ctx, hipMemsetAsync(d_usize.p, 0, (size_t)n_genomes * 4, stream));
-        }
-        RK_HIP(ctx, hipMemsetAsync(d_tail.p, 0, sizeof(SketchTail), stream));
+        // the CSR is allocated for the capacity (distinct hashes <= candidates), so that its placement needs no
+        // count on the host: the whole pass runs without an intermediate synchronisation
+        if (wide) { rk_pool_free(ctx, s->d_hashes64); s->d_hashes64 = nullptr; RK_TRY(pool_array(ctx, &s->d_hashes64, total_cap + 1)); }
+        else { rk_pool_free(ctx, s->d_hashes); s->d_hashes = nullptr; RK_TRY(pool_array(ctx, &s->d_hashes, total_cap + 1)); }
+        memcpy(pinned, rows.data(), rows_bytes);
+        RK_HIP(ctx, hipMemcpyAsync(d_rows.p, pinned, rows_bytes, hipMemcpyHostToDevice, stream));
+        RK_HIP(ctx, hipMemsetAsync(d_res.p, 0, res_bytes, stream));
+        if (n_genomes) RK_HIP(ctx, hipMemsetAsync(d_usize.p, 0, (size_t)n_genomes * 4, stream));
         if (n_chunks) {
             SketchArgs a;
             a.packed = packed_dev;
-            a.chunk_gid = d_gid.p;
-            a.chunk_beg = d_beg.p;
-            a.chunk_blocks = d_blocks.p;
+            a.rows = d_rows.p;
+            a.n_genomes = n_genomes;
             a.n_chunks = n_chunks;
+            a.chunk_blocks = (uint32_t)cb;
             a.filter_image = f->d_bitmap;
             a.table = f->d_table;
             a.tupmask = P.tupmask;
@@ -914,13 +922,11 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             a.dr_shift = 4 * P.drlevel;
             a.und1_shift = (int32_t)P.kmer_size * 2 - P.half_outctx_len * 4;
             a.cand = cand.p;
-            a.reg_off = d_regoff.p;
-            a.reg_cap = d_cap.p;
-            a.gcount = d_gcount.p;
-            a.n_windows = &d_tail.p->windows;
+            a.gcount = d_gcount;
+            a.n_windows = &d_tail->windows;
             const uint32_t want = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
             // persistent: one workgroup per CU (the 156 KiB LDS image admits only one), each
-            // striding over the chunk table, so the filter image is staged once per CU
+            // striding over the chunks, so the filter image is staged once per CU
             const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kSketchThreads), 0, stream, a);
             RK_HIP(ctx, hipGetLastError());
@@ -930,47 +936,56 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             if (wide) {
                 if (small_lds > 48 * 1024)
                     RK_HIP(ctx, hipFuncSetAttribute((const void *)k_dedup<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
-                hipLaunchKernelGGL(k_dedup<uint64_t>, dim3(n_genomes), dim3(kDedupThreads), small_lds, stream, cand.p, d_regoff.p,
-                                   d_cap.p, d_gcount.p, d_big.p, min_count, (uint64_t *)sorted_out.p, d_usize.p, d_tail.p);
+                hipLaunchKernelGGL(k_dedup<uint64_t>, dim3(n_genomes), dim3(kDedupThreads), small_lds, stream, cand.p, d_rows.p,
+                                   d_gcount, min_count, (uint64_t *)sorted_out.p, d_usize.p, d_tail);
             } else {
                 if (small_lds > 48 * 1024)
                     RK_HIP(ctx, hipFuncSetAttribute((const void *)k_dedup<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
-                hipLaunchKernelGGL(k_dedup<uint32_t>, dim3(n_genomes), dim3(kDedupThreads), small_lds, stream, cand.p, d_regoff.p,
-                                   d_cap.p, d_gcount.p, d_big.p, min_count, (uint32_t *)sorted_out.p, d_usize.p, d_tail.p);
+                hipLaunchKernelGGL(k_dedup<uint32_t>, dim3(n_genomes), dim3(kDedupThreads), small_lds, stream, cand.p, d_rows.p,
+                                   d_gcount, min_count, (uint32_t *)sorted_out.p, d_usize.p, d_tail);
             }
             RK_HIP(ctx, hipGetLastError());
         }
+        bool big_overflow = false;
         if (any_big) {  // 3 Gb genomes: their regions exceed the LDS sort; needs their candidate counts on the host
-            RK_HIP(ctx, hipMemcpyAsync(gcount.data(), d_gcount.p, (size_t)n_genomes * 4, hipMemcpyDeviceToHost, stream));
+            RK_HIP(ctx, hipMemcpyAsync(gcount.data(), d_gcount, (size_t)n_genomes * 4, hipMemcpyDeviceToHost, stream));
             RK_HIP(ctx, hipStreamSynchronize(stream));
-            bool overflow = false;
-            for (uint32_t g = 0; g < n_genomes && !overflow; g++) overflow = is_big[g] && gcount[g] > reg_cap[g];
-            for (uint32_t g = 0; g < n_genomes && !overflow; g++) {
-                if (!is_big[g]) continue;
+            for (uint32_t g = 0; g < n_genomes && !big_overflow; g++) big_overflow = rows[g].is_big && gcount[g] > rows[g].reg_cap;
+            for (uint32_t g = 0; g < n_genomes && !big_overflow; g++) {
+                if (!rows[g].is_big) continue;
                 uint32_t nu = 0;
                 if (wide)
-                    RK_TRY(dedup_big<uint64_t>(ctx, cand.p + reg_off[g], gcount[g], hash_bits, min_count,
-                                               (uint64_t *)sorted_out.p + reg_off[g], &nu, stream));
+                    RK_TRY(dedup_big<uint64_t>(ctx, cand.p + rows[g].reg_off, gcount[g], hash_bits, min_count,
+                                               (uint64_t *)sorted_out.p + rows[g].reg_off, &nu, stream));
                 else
-                    RK_TRY(dedup_big<uint32_t>(ctx, cand.p + reg_off[g], gcount[g], hash_bits, min_count,
-                                               (uint32_t *)sorted_out.p + reg_off[g], &nu, stream));
-                memcpy(ctx->pinned, &nu, 4);
-                RK_HIP(ctx, hipMemcpyAsync(d_usize.p + g, ctx->pinned, 4, hipMemcpyHostToDevice, stream));
+                    RK_TRY(dedup_big<uint32_t>(ctx, cand.p + rows[g].reg_off, gcount[g], hash_bits, min_count,
+                                               (uint32_t *)sorted_out.p + rows[g].reg_off, &nu, stream));
+                memcpy(pinned, &nu, 4);
+                RK_HIP(ctx, hipMemcpyAsync(d_usize.p + g, pinned, 4, hipMemcpyHostToDevice, stream));
                 RK_HIP(ctx, hipStreamSynchronize(stream));  // the pinned word is reused
             }
         }
-        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, stream, d_usize.p, n_genomes, s->d_off);
+        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(1024), 0, stream, d_usize.p, n_genomes, s->d_off, d_off_copy);
+        if (n_genomes) {
+            if (wide)
+                hipLaunchKernelGGL(k_csr_place<uint64_t>, dim3(n_genomes), dim3(256), 0, stream, (const uint64_t *)sorted_out.p,
+                                   d_rows.p, d_usize.p, s->d_off, s->d_hashes64);
+            else
+                hipLaunchKernelGGL(k_csr_place<uint32_t>, dim3(n_genomes), dim3(256), 0, stream, (const uint32_t *)sorted_out.p,
+                                   d_rows.p, d_usize.p, s->d_off, s->d_hashes);
+        }
         RK_HIP(ctx, hipGetLastError());
-        // ---- the one read-back of the common case: offsets, candidate counts (for the retry), window count
-        RK_HIP(ctx, hipMemcpyAsync(s->h_off.data(), s->d_off, ((size_t)n_genomes + 1) * 8, hipMemcpyDeviceToHost, stream));
-        if (n_genomes)
-            RK_HIP(ctx, hipMemcpyAsync(gcount.data(), d_gcount.p, (size_t)n_genomes * 4, hipMemcpyDeviceToHost, stream));
-        RK_TRY(rk_read_back(ctx, &tail, d_tail.p, sizeof(tail), stream));
-        bool overflow = (tail.flags & kFlagOverflow) != 0;
+        // ---- the one read-back of the common case: window count, offsets, candidate counts (for the retry)
+        RK_HIP(ctx, hipMemcpyAsync(pinned, d_res.p, res_bytes, hipMemcpyDeviceToHost, stream));
+        RK_HIP(ctx, hipStreamSynchronize(stream));
+        memcpy(&tail, pinned, sizeof(tail));
+        memcpy(s->h_off.data(), pinned + sizeof(SketchTail), ((size_t)n_genomes + 1) * 8);
+        if (n_genomes) memcpy(gcount.data(), pinned + sizeof(SketchTail) + ((size_t)n_genomes + 1) * 8, (size_t)n_genomes * 4);
+        bool overflow = big_overflow || (tail.flags & kFlagOverflow) != 0;
         for (uint32_t g = 0; g < n_genomes; g++)
-            if (gcount[g] > reg_cap[g]) {
+            if (gcount[g] > rows[g].reg_cap) {
                 overflow = true;
-                reg_cap[g] = gcount[g];  // exact on the second pass
+                rows[g].reg_cap = gcount[g];  // exact on the second pass
             }
         if (!overflow) break;
         if (attempt == 1) return rk_fail(ctx, RK_ERR_CAPACITY, "candidate overflow persisted");
@@ -978,19 +993,6 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
     s->windows = tail.windows;
     s->total = s->h_off[n_genomes];
     for (uint32_t g = 0; g < n_genomes; g++) s->max_size = std::max<uint64_t>(s->max_size, s->h_off[g + 1] - s->h_off[g]);
-    if (wide) {
-        RK_TRY(pool_array(ctx, &s->d_hashes64, s->total + 1));
-        if (n_genomes)
-            hipLaunchKernelGGL(k_csr_place<uint64_t>, dim3(n_genomes), dim3(256), 0, stream, (const uint64_t *)sorted_out.p,
-                               d_regoff.p, d_usize.p, s->d_off, s->d_hashes64);
-    } else {
-        RK_TRY(pool_array(ctx, &s->d_hashes, s->total + 1));
-        if (n_genomes)
-            hipLaunchKernelGGL(k_csr_place<uint32_t>, dim3(n_genomes), dim3(256), 0, stream, (const uint32_t *)sorted_out.p,
-                               d_regoff.p, d_usize.p, s->d_off, s->d_hashes);
-    }
-    RK_HIP(ctx, hipGetLastError());
-    RK_HIP(ctx, hipStreamSynchronize(stream));  // temporaries return to the pool; the result is complete
     guard.p = nullptr;
     *out = s;
     return RK_OK;
@@ -1054,12 +1056,12 @@ int rk_sketches_classify(rk_ctx *ctx, rk_sketches *s)
     DevBuf<uint32_t> bad(ctx);
     RK_HIP(ctx, bad.alloc(1));
     RK_HIP(ctx, hipMemsetAsync(bad.p, 0, 4, ctx->stream));
-    if (s->n && s->total) {
-        const unsigned blocks = (s->n + 3) / 4;
+    if (s->n && s->total > 1) {
+        const unsigned blocks = blocks_for(s->total - 1);
         if (s->wide)
-            hipLaunchKernelGGL(k_check_sets<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream, s->d_hashes64, s->d_off, s->n, bad.p);
+            hipLaunchKernelGGL(k_check_sets<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream, s->d_hashes64, s->total, s->d_off, s->n, bad.p);
         else
-            hipLaunchKernelGGL(k_check_sets<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream, s->d_hashes, s->d_off, s->n, bad.p);
+            hipLaunchKernelGGL(k_check_sets<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream, s->d_hashes, s->total, s->d_off, s->n, bad.p);
         RK_HIP(ctx, hipGetLastError());
     }
     uint32_t b = 0;

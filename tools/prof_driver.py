@@ -79,7 +79,58 @@ def dist_rq(n_ref=100000, n_query=1000, steps=3):
               % (dt * 1e3, n_query, n_ref, n_query * n_ref, n_query * n_ref / dt, len(hits)))
 
 
+def dist_rq_dev(n_ref=100000, n_query=1000, steps=5, n_related=0):
+    """configs[4] shape, kernel only (rk_dist_rows_dev with explicit queries), HIP-event time per launch"""
+    ctx = capi.Context(0)
+    rn, rh, roff = synth.clade_sketches(n_ref, 76, 24, seed=31)
+    qn, qh, qoff = synth.clade_sketches(n_query, 45776, 24, seed=32)
+    index = ctx.index_build(ctx.sketches_from_host(rh, roff), 24)
+    qs = ctx.sketches_from_host(qh, qoff)
+    hits = torch.empty((1 << 20) * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    counters = torch.zeros(steps + 1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        def launch(i):
+            ctx.dist_rows_dev(index, 0, 0, 20, 0.05, hits.data_ptr(), 1 << 20, counters.data_ptr() + 8 * i,
+                              stream=stream.cuda_stream, queries=qs)
+        launch(steps)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for i in range(steps):
+            launch(i)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+    print("dist_rq kernel %.3f ms/launch (events), %d x %d, hits %d" % (ev0.elapsed_time(ev1) / steps, n_query, n_ref,
+                                                                         int(counters[0].item())))
+
+
+def index(n_genomes=10000, reps=5):
+    """rk_index_build wall time, first call (cold pool) and steady state"""
+    ctx = capi.Context(0)
+    names, hashes, off = synth.clade_sketches(n_genomes, 1220, 28)
+    sk = ctx.sketches_from_host(hashes, off)
+    for r in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        idx = ctx.index_build(sk, 28)
+        dt = time.time() - t0
+        print("index build %d: %.3f ms (H=%d U=%d)" % (r, dt * 1e3, idx.total, idx.distinct))
+        del idx
+    for r in range(3):
+        t0 = time.time()
+        sk2 = ctx.sketches_from_host(hashes, off)
+        t1 = time.time()
+        idx = ctx.index_build(sk2, 28)
+        t2 = time.time()
+        h, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05)
+        t3 = time.time()
+        print("host-inclusive %d: upload %.3f + build %.3f + dist_rows %.3f = %.3f ms (%d hits)" % (
+            r, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t0) * 1e3, len(h)))
+        del idx, sk2
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
     args = [int(x) for x in sys.argv[2:]]
-    {"sketch": sketch, "dist": dist, "dist_rq": dist_rq}[which](*args)
+    {"sketch": sketch, "dist": dist, "dist_rq": dist_rq, "dist_rq_dev": dist_rq_dev, "index": index}[which](*args)
