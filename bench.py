@@ -8,19 +8,24 @@ alldist from precomputed .sketch/.dict").
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path (intersection counting through the inverted index +
-Jaccard->Mash epilogue + hit compaction, ONE kernel launch per rank) over this rank's
-query rows.  Multi-GPU: query rows are interleaved over the ranks (row r -> rank r mod N),
-the reference index is built on rank 0 and sent to every peer with ONE RCCL broadcast
-(outside the timed region); there is no data-path collective and no reduction.  Scaling
-is weak: the dataset has round(10000*sqrt(N)) genomes so that the number of pairs per GPU
-stays that of the 1-GPU workload (--scaling strong keeps 10,000 genomes instead).
+Jaccard->Mash epilogue + hit compaction, ONE kernel launch per rank) over this rank's query rows.
+Multi-GPU: blocks of 16 consecutive query rows are dealt round-robin to the ranks (block-cyclic),
+the reference index is built on rank 0 and sent to every peer with ONE RCCL broadcast (outside the
+timed region); there is no data-path collective and no reduction.  Scaling is STRONG by default --
+the metric is "10k bacteria at 1/2/4/8 GPUs", so the dataset stays 10,000 genomes at every N
+(--scaling weak grows it to round(10000*sqrt(N)) genomes instead, constant pairs per GPU).
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
-distance kernel and, at N=1, `cpu_baseline` (the reference's own dist.cpp when
-oracle/_ref/ref_driver was built, else the oracle port) timed on the host cores.
+Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the headline fields:
+  roofline      distance kernel: contract fraction (SURVEY 8d bytes / HIP-event kernel time / 8 TB/s) AND hbm_frac
+                (counter-measured HBM bytes of profiles/pmc_traffic.json / kernel time / 8 TB/s)
+  cpu_baseline  the reference's own dist.cpp (oracle/_ref/ref_driver) timed on the host cores, N=1 only
+  config3       BASELINE configs[3]: alldist over 50,000 sketches, strong scaling (where 8 GPUs have work)
+  dist_rq       BASELINE configs[4] shape: 100,000 reference sketches x 1,000 3-Gb-genome queries (24-bit hashes),
+                one fused kernel; queries shard contiguously over the ranks; reference index_dist beside it at N=1
+  sketch        sketch k-mers/s (N=1): pass rate, the scan kernel's own roofline block, CPU port beside it
+  setup         index build (cold / steady), PCIe-inclusive API path, `rabbit_kssd alldist` wall vs the reference's
 """
 import argparse
-import ctypes
 import json
 import math
 import os
@@ -29,6 +34,7 @@ import subprocess
 import sys
 import tempfile
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -40,6 +46,8 @@ HASH_BITS = 28          # L3K10: 4*(half_k - drlevel)
 HASHES_PER_GENOME = 1220
 KMER = 20
 MAX_DIST = 0.05
+TOOL = os.path.join(ROOT, "rabbitkssd_amd", "rabbit_kssd")
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
 
 
 def parse_args():
@@ -48,14 +56,17 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--genomes", type=int, default=10000)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the N>1 plumbing with all ranks on ONE GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-sketch", action="store_true")
+    ap.add_argument("--no-config3", action="store_true")
+    ap.add_argument("--no-dist-rq", action="store_true")
     ap.add_argument("--sketch-genomes", type=int, default=128)
     ap.add_argument("--sketch-length", type=int, default=5_000_000)
+    ap.add_argument("--config3-genomes", type=int, default=50000)
     return ap.parse_args()
 
 
@@ -66,54 +77,213 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(names, hashes, off, n_pairs):
-    """The reference CPU alldist on the same sketches, on this box's host cores."""
-    from oracle import oracle as ok
-    cores = host_cores()
-    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    n = len(off) - 1
-    t0 = time.time()
-    postings, counts = ok.index_build32(hashes, off, HASH_BITS)
-    t_build = time.time() - t0
-    if os.path.exists(ref):
-        with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
-            sk = os.path.join(tmp, "bench.sketch")
-            ok.save_sketches32(sk, 10, 6, 3, names, hashes, off)
-            ok.write_index32(sk + ".dict", sk + ".index", postings, counts, HASH_BITS)
-            del counts
-            t0 = time.time()
-            p = subprocess.run([ref, "alldist", tmp, sk, "bench.out", str(MAX_DIST), "0", str(cores)],
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-            wall = time.time() - t0
-            err = p.stderr.decode(errors="replace")
-            m_load = re.search(r"time of read index and offset sketch file is: ([0-9.eE+-]+)", err)
-            m_dist = re.search(r"time of multiple threads distance computing and save the subFile is: ([0-9.eE+-]+)", err)
-            if p.returncode == 0 and m_dist:
-                t_dist = float(m_dist.group(1))
-                lines = sum(1 for _ in open(os.path.join(tmp, "bench.out"))) - 1
-                return {"value": n_pairs / t_dist, "unit": "genome-pairs/s", "cores": cores,
-                        "kind": "reference",
-                        "sample": "full workload: %d sketches, %d pairs, -D %g, -t %d; reference "
-                                  "index_tridist (src/dist.cpp) distance-loop phase %.3f s; index load+"
-                                  "prefix-sum phase %.3f s; process wall %.3f s; %d hits"
-                                  % (n, n_pairs, MAX_DIST, cores, t_dist,
-                                     float(m_load.group(1)) if m_load else float("nan"), wall, lines),
-                        "wall_pairs_per_s": n_pairs / wall}
-    # port: the C restatement (same dense index, per-thread counter row, OpenMP dynamic rows)
-    sizes = np.diff(off).astype(np.uint32)
-    t0 = time.time()
-    hits, _ = ok.index_dist32(counts, HASH_BITS, postings, sizes, hashes, off, 1, 0, KMER, MAX_DIST,
-                              threads=cores)
-    t = time.time() - t0
-    return {"value": n_pairs / t, "unit": "genome-pairs/s", "cores": cores, "kind": "port",
-            "sample": "full workload: %d sketches, %d pairs, -D %g, %d threads; oracle port incl. "
-                      "2^28 prefix sum %.3f s (index build %.3f s not counted); %d hits"
-                      % (n, n_pairs, MAX_DIST, cores, t, t_build, len(hits))}
+class Env:
+    """process-wide handles: rank layout, torch, the library context"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from rabbitkssd_amd import capi
+        self.torch, self.dist, self.capi, self.args = torch, dist, capi, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            if self.rank == 0:
+                print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, self.world),
+                      file=sys.stderr)
+            sys.exit(2)
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU: the engine has no CPU fallback")
+        if args.same_device:
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(args.backend, rank=self.rank, world_size=self.world)
+        self.ctx = capi.Context(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        # a stream of our own: torch.cuda.Event measures the stream it is recorded on
+        self.stream = torch.cuda.Stream(device=self.dev)
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.int64, device=self.dev)
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+    def share_index(self, index):
+        """rank 0's index to every rank: ONE broadcast of one blob; returns (index, blob bytes, seconds)"""
+        from rabbitkssd_amd import shard
+        if self.world == 1:
+            return index, index.blob_bytes, 0.0
+        torch = self.torch
+        blob, nbytes = None, 0
+        if self.rank == 0:
+            nbytes = index.blob_bytes
+            blob = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            index.pack_dev(blob.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        self.dist.barrier()
+        t0 = time.time()
+        blob = shard.broadcast_blob(blob, 0, self.dev, self.dist)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        if self.rank != 0:
+            index = self.ctx.index_unpack_dev(blob.data_ptr(), blob.numel(), torch.cuda.current_stream().cuda_stream)
+        return index, blob.numel(), dt
+
+    def share_sketches(self, hashes, off):
+        """rank 0's host sketches to every rank (queries of the dist path are scattered by the host)"""
+        if self.world == 1:
+            return hashes, off
+        box = [hashes, off] if self.rank == 0 else [None, None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0], box[1]
 
 
-def sketch_leg(ctx, capi, torch, n_genomes, length, steps=3):
-    """secondary metric: sketch k-mers/s, sequence bytes resident in HBM."""
-    from rabbitkssd_amd import synth
+def timed_steps(env, launch, steps, warmup):
+    """W untimed + K timed launches on env.stream, barrier + synchronize on both sides; returns
+    (wall seconds max over ranks, mean kernel ms by HIP events on the launch stream)"""
+    torch = env.torch
+    with torch.cuda.stream(env.stream):
+        for i in range(warmup):
+            launch(i)
+        env.fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(env.stream)
+        for i in range(steps):
+            launch(warmup + i)
+        ev1.record(env.stream)
+        env.fence()
+        elapsed = time.perf_counter() - t0
+    return env.max_over_ranks(elapsed), ev0.elapsed_time(ev1) / steps
+
+
+def alldist_block(env, n_genomes, steps, warmup, keep=None):
+    """alldist over n_genomes synthetic sketches, this rank's block-cyclic row shard; rank 0 returns the report"""
+    from rabbitkssd_amd import capi, shard, synth
+    torch, ctx, rank, world = env.torch, env.ctx, env.rank, env.world
+    n_pairs = n_genomes * (n_genomes - 1) // 2
+    t_cold = t_steady = 0.0
+    index = None
+    names = hashes = off = None
+    if rank == 0:
+        names, hashes, off = synth.clade_sketches(n_genomes, HASHES_PER_GENOME, HASH_BITS, kmer_size=KMER)
+        sk = ctx.sketches_from_host(hashes, off)
+        t0 = time.time()
+        index = ctx.index_build(sk, HASH_BITS)      # first call: the context's pool is cold (hipMalloc)
+        t_cold = time.time() - t0
+        del index
+        t0 = time.time()
+        index = ctx.index_build(sk, HASH_BITS)      # steady state: no allocation, one read-back
+        t_steady = time.time() - t0
+    index, nbytes, t_bcast = env.share_index(index)
+    H, T = index.total, index.sum_sq
+    hits_cap = 1 << 20
+    hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=env.dev)
+    counters = torch.zeros(steps + warmup + 1, dtype=torch.int64, device=env.dev)
+
+    def launch(i):
+        ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i,
+                          row_first=rank, row_step=world, stream=env.stream.cuda_stream, row_block=shard.ROW_BLOCK)
+
+    elapsed, kernel_ms = timed_steps(env, launch, steps, warmup)
+    tot_hits = env.sum_over_ranks(int(counters[warmup].item()))
+    kernel = ctx.dist_kernel_name(index, None, 1, 0, KMER, MAX_DIST, row_first=rank, row_step=world, row_block=shard.ROW_BLOCK)
+    if keep is not None and rank == 0:
+        keep.update(names=names, hashes=hashes, off=off, index=index, sk=sk)
+    if rank != 0:
+        return None
+    # algorithmic bytes of one launch on this rank (SURVEY.md 8d): 12 B per query hash (hash + two index offsets)
+    # + 4 B per posting streamed (T = sum c_h^2) + 4 B per count cell produced; rank 0 holds ~1/world of each term
+    b_alg = (12.0 * H + 4.0 * T) / world + 4.0 * shard.rank_pairs(n_genomes, 0, world)
+    achieved = b_alg / (kernel_ms * 1e-3) / 1e9
+    return {
+        "value": n_pairs * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "genomes": n_genomes, "pairs": n_pairs,
+        "hashes": int(H), "postings_streamed_T": int(T), "hits": int(tot_hits), "steps": steps, "warmup": warmup,
+        "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg, "achieved": achieved,
+        "index_build_cold_ms": t_cold * 1e3, "index_build_ms": t_steady * 1e3, "index_blob_bytes": int(nbytes),
+        "rccl_broadcast_ms": t_bcast * 1e3,
+    }
+
+
+def dist_rq_block(env, n_ref=100000, n_query=1000, steps=20, warmup=3, keep=None):
+    """BASELINE configs[4] shape on one node: references 100,000 x 76 hashes, queries 1,000 x 45,776 hashes, 24-bit
+    hashes (K10 S7 L4), -D 0.05.  Queries shard contiguously over the ranks; the index is broadcast once."""
+    from rabbitkssd_amd import capi, synth
+    torch, ctx, rank, world = env.torch, env.ctx, env.rank, env.world
+    bits, kmer = 24, 20
+    index = None
+    qh = qoff = rh = roff = None
+    if rank == 0:
+        _, rh, roff = synth.clade_sketches(n_ref, 76, bits, seed=31)
+        _, qh, qoff = synth.clade_sketches(n_query, 45776, bits, seed=32)
+        index = ctx.index_build(ctx.sketches_from_host(rh, roff), bits)
+    index, _, t_bcast = env.share_index(index)
+    qh, qoff = env.share_sketches(qh, qoff)
+    qs = ctx.sketches_from_host(qh, qoff)
+    hits_cap = 1 << 20
+    hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=env.dev)
+    counters = torch.zeros(steps + warmup + 1, dtype=torch.int64, device=env.dev)
+    per_rank = (n_query + world - 1) // world  # contiguous query blocks (SURVEY 8e)
+
+    def launch(i):
+        ctx.dist_rows_dev(index, 0, 0, kmer, MAX_DIST, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i,
+                          row_first=rank, row_step=world, row_block=per_rank, stream=env.stream.cuda_stream, queries=qs)
+
+    elapsed, kernel_ms = timed_steps(env, launch, steps, warmup)
+    tot_hits = env.sum_over_ranks(int(counters[warmup].item()))
+    if rank != 0:
+        return None
+    if keep is not None:
+        keep.update(rh=rh, roff=roff, qh=qh, qoff=qoff)
+    # postings streamed: every query hash that is indexed walks its list once
+    uh, cnt = np.unique(rh, return_counts=True)
+    pos = np.searchsorted(uh, qh)
+    pos[pos >= len(uh)] = 0
+    T_all = int(cnt[pos][uh[pos] == qh].sum())
+    my_q = min(per_rank, n_query)
+    b_alg = (12.0 * len(qh) + 4.0 * T_all) * my_q / n_query + 4.0 * my_q * n_ref
+    achieved = b_alg / (kernel_ms * 1e-3) / 1e9
+    n_pairs = n_query * n_ref
+    return {
+        "workload": "dist: %d reference sketches x 76 hashes vs %d queries x 45,776 hashes, 24-bit hashes (K10 S7 L4), "
+                    "-D %g; one fused kernel per rank, queries in %d contiguous block(s)" % (n_ref, n_query, MAX_DIST, world),
+        "value": n_pairs * steps / elapsed, "unit": "genome-pairs/s", "ms_per_step": elapsed / steps * 1e3,
+        "pairs": n_pairs, "query_hashes": int(len(qh)), "postings_streamed_T": T_all, "hits": int(tot_hits),
+        "steps": steps, "warmup": warmup, "rccl_broadcast_ms": t_bcast * 1e3,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": ctx.dist_kernel_name(index, qs, 0, 0, kmer, MAX_DIST), "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": b_alg,
+                     "note": "SURVEY 8d bytes (12 B/query hash + 4 B/posting + 4 B/count cell); the 4 B x %d count cells "
+                             "never leave LDS, so this contract fraction can exceed what HBM moves" % (my_q * n_ref)},
+    }
+
+
+def sketch_block(env, n_genomes, length, steps=5):
+    """secondary metric: sketch k-mers/s, sequence bytes resident in HBM"""
+    from rabbitkssd_amd import capi, synth
+    torch, ctx = env.torch, env.ctx
     params = capi.params_init(10, 6, 3)
     table = synth.shuf_table(10, 6, 3)  # the product's own `rabbit_kssd shuffle`
     flt = ctx.filter(params, table)
@@ -127,177 +297,289 @@ def sketch_leg(ctx, capi, torch, n_genomes, length, steps=3):
         view[i, :length] = lut[torch.randint(0, 4, (length,), generator=g, device="cuda")]
     gbeg = np.arange(n_genomes, dtype=np.uint64) * stride
     gend = gbeg + np.uint64(length)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = env.stream.cuda_stream
     torch.cuda.synchronize()
+    ctx.set_timing(True)
     sk = ctx.sketch_packed_dev(flt, packed.data_ptr(), packed.numel(), gbeg, gend, stream)  # warm-up
     windows = sk.windows
+    kms = []
     t0 = time.time()
     for _ in range(steps):
         sk = ctx.sketch_packed_dev(flt, packed.data_ptr(), packed.numel(), gbeg, gend, stream)
+        kms.append(ctx.last_ms(0))
     torch.cuda.synchronize()
     dt = (time.time() - t0) / steps
-    return {"kmers_per_s": windows / dt, "genomes": n_genomes, "genome_length": length,
-            "kmers": int(windows), "hashes": int(sk.total), "ms_per_pass": dt * 1e3,
-            "note": "scan kernel + device sort/unique dedup, synthetic uniform ACGT resident in HBM; "
-                    "1.001 B/k-mer -> %.1f GB/s" % (windows * 1.001 / dt / 1e9)}
+    ctx.set_timing(False)
+    kernel_ms = sum(kms) / len(kms)
+    b_alg = windows * 1.001  # 1 B per k-mer window + 4 B per emitted hash
+    achieved = b_alg / (kernel_ms * 1e-3) / 1e9
+    out = {"kmers_per_s": windows / dt, "genomes": n_genomes, "genome_length": length, "kmers": int(windows),
+           "hashes": int(sk.total), "ms_per_pass": dt * 1e3,
+           "pass": "scan kernel + per-genome LDS dedup + CSR placement, one upload and one read-back per batch; synthetic "
+                   "uniform ACGT resident in HBM; 1.001 B/k-mer -> %.1f GB/s for the whole pass" % (b_alg / dt / 1e9),
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rk_sketch_kernel<20, 8, true>",
+                        "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg}}
+    pmc = load_pmc("rk_sketch_kernel<20, 8, true>", "pmc_traffic_sketch.json")
+    if pmc:
+        out["roofline"]["traffic"] = pmc
+        out["roofline"]["hbm_frac"] = pmc / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if not env.args.no_cpu_baseline:
+        out["cpu_baseline"] = sketch_cpu_baseline(packed, stride, length, n_genomes, table)
+    return out
+
+
+def sketch_cpu_baseline(packed, stride, length, n_genomes, table):
+    """the oracle's restatement of src/sketch.cpp:487-530 under the reference's own parallelism: OpenMP
+    `schedule(dynamic)` over genomes (:455-457), selected .shuf entries in a cache-resident membership structure
+    (the role of `shuffled_map`, :338-345); a bounded sample of the same synthetic genomes, already in memory"""
+    from oracle import oracle as ok
+    cores = host_cores()
+    sample = min(n_genomes, max(2 * cores, 16))
+    param = ok.init_param(10, 6, 3)
+    seq = packed.view(n_genomes, stride)[:sample, :length].contiguous().cpu().numpy().reshape(-1)
+    goff = np.arange(sample + 1, dtype=np.uint64) * np.uint64(length)
+    threads = min(cores, sample)
+    ok.sketch_genomes_mt(param, table, seq[:200000], np.array([0, 200000], dtype=np.uint64), 1)  # load the library
+    t0 = time.time()
+    sizes = ok.sketch_genomes_mt(param, table, seq, goff, threads)
+    dt = time.time() - t0
+    kmers = sample * (length - 19)
+    return {"value": kmers / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
+            "sample": "%d of the %d synthetic 5 Mb genomes (in memory: no file parsing), OpenMP dynamic over genomes on %d "
+                      "threads, %.3f s incl. building the selection bitmap; oracle/kssd_oracle.c restatement of the "
+                      "reference loop, %d hashes" % (sample, n_genomes, threads, dt, int(sizes.sum()))}
+
+
+def load_pmc(kernel, fname="pmc_traffic.json"):
+    """counter-measured HBM bytes per launch from profiles/, only if recorded for exactly this kernel variant"""
+    path = os.path.join(ROOT, "profiles", fname)
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    if d.get("kernel") != kernel:
+        print("bench.py: %s was recorded for %r, the launched kernel is %r: traffic not reported (re-run "
+              "tools/measure_round.sh)" % (fname, d.get("kernel"), kernel), file=sys.stderr)
+        return None
+    return d.get("hbm_bytes_per_launch")
+
+
+def alldist_cpu_and_cli(keep, n_pairs):
+    """the reference's index_tridist on the same sketches on this box's host cores, and -- on the very same files --
+    the product's `rabbit_kssd alldist` command line (wall clock incl. process + HIP start-up)"""
+    from oracle import oracle as ok
+    from rabbitkssd_amd import synth
+    cores = host_cores()
+    names, hashes, off = keep["names"], keep["hashes"], keep["off"]
+    n = len(off) - 1
+    res, cli = None, None
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
+        sk = os.path.join(tmp, "bench.sketch")
+        synth.write_sketch_file(sk, 10, 6, 3, names, hashes, off)
+        if os.path.exists(REF):
+            t0 = time.time()
+            postings, counts = ok.index_build32(hashes, off, HASH_BITS)
+            ok.write_index32(sk + ".dict", sk + ".index", postings, counts, HASH_BITS)
+            del counts, postings
+            t_files = time.time() - t0
+            t0 = time.time()
+            p = subprocess.run([REF, "alldist", tmp, sk, "ref.out", str(MAX_DIST), "0", str(cores)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            wall = time.time() - t0
+            err = p.stderr.decode(errors="replace")
+            m_load = re.search(r"time of read index and offset sketch file is: ([0-9.eE+-]+)", err)
+            m_dist = re.search(r"time of multiple threads distance computing and save the subFile is: ([0-9.eE+-]+)", err)
+            if p.returncode == 0 and m_dist:
+                t_dist = float(m_dist.group(1))
+                lines = sum(1 for _ in open(os.path.join(tmp, "ref.out"))) - 1
+                res = {"value": n_pairs / t_dist, "unit": "genome-pairs/s", "cores": cores, "kind": "reference",
+                       "sample": "full workload: %d sketches, %d pairs, -D %g, -t %d; reference index_tridist (src/dist.cpp) "
+                                 "distance-loop phase %.3f s; index load + prefix-sum phase %.3f s; process wall %.3f s; %d "
+                                 "hits (.dict/.index written beforehand by the oracle in %.1f s: the reference's own "
+                                 "transSketches needs 79 s)" % (n, n_pairs, MAX_DIST, cores, t_dist,
+                                                                float(m_load.group(1)) if m_load else float("nan"), wall,
+                                                                lines, t_files),
+                       "wall_s": wall, "wall_pairs_per_s": n_pairs / wall, "hits": lines}
+        # the product's command line on the same .sketch (the .dict/.index pair exists, so nothing is rewritten)
+        if os.path.exists(TOOL):
+            walls = []
+            for _ in range(3):
+                t0 = time.time()
+                p = subprocess.run([TOOL, "alldist", "-i", sk, "-D", str(MAX_DIST), "-o", "gpu.out", "-t", str(min(cores, 16))],
+                                   cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                walls.append(time.time() - t0)
+                if p.returncode != 0:
+                    walls = []
+                    break
+            if walls:
+                lines = sum(1 for _ in open(os.path.join(tmp, "gpu.out"))) - 1
+                cli = {"cli_wall_ms": min(walls) * 1e3, "cli_wall_runs_ms": [w * 1e3 for w in walls], "cli_hits": lines,
+                       "cli_note": "`rabbit_kssd alldist -i bench.sketch -D %g` end to end (process start, HIP init, read .sketch, "
+                                   "index build, distances, text output), best of 3" % MAX_DIST}
+                if res:
+                    cli["cli_vs_reference_wall"] = res["wall_s"] / min(walls)
+                    cli["cli_same_hits_as_reference"] = lines == res["hits"]
+    if res is None:
+        # port: the C restatement (same dense index, per-thread counter row, OpenMP dynamic rows)
+        t0 = time.time()
+        postings, counts = ok.index_build32(hashes, off, HASH_BITS)
+        t_build = time.time() - t0
+        sizes = np.diff(off).astype(np.uint32)
+        t0 = time.time()
+        hits, _ = ok.index_dist32(counts, HASH_BITS, postings, sizes, hashes, off, 1, 0, KMER, MAX_DIST, threads=cores)
+        t = time.time() - t0
+        res = {"value": n_pairs / t, "unit": "genome-pairs/s", "cores": cores, "kind": "port",
+               "sample": "full workload: %d sketches, %d pairs, -D %g, %d threads; oracle port incl. 2^28 prefix sum %.3f s "
+                         "(index build %.3f s not counted); %d hits" % (n, n_pairs, MAX_DIST, cores, t, t_build, len(hits))}
+    return res, cli
+
+
+def dist_rq_cpu_baseline(keep, n_pairs):
+    """the reference's index_dist (src/dist.cpp:429-776) on a bounded sample of the same queries"""
+    from oracle import oracle as ok
+    from rabbitkssd_amd import synth
+    if not os.path.exists(REF):
+        return None
+    cores = host_cores()
+    rh, roff, qh, qoff = keep["rh"], keep["roff"], keep["qh"], keep["qoff"]
+    n_ref, n_query = len(roff) - 1, len(qoff) - 1
+    sample = n_query if cores >= 32 else min(n_query, 100)
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
+        rs, qs = os.path.join(tmp, "ref.sketch"), os.path.join(tmp, "qry.sketch")
+        synth.write_sketch_file(rs, 10, 7, 4, ["r%d" % i for i in range(n_ref)], rh, roff)
+        synth.write_sketch_file(qs, 10, 7, 4, ["q%d" % i for i in range(sample)], qh[:int(qoff[sample])], qoff[:sample + 1])
+        postings, counts = ok.index_build32(rh, roff, 24)
+        ok.write_index32(rs + ".dict", rs + ".index", postings, counts, 24)
+        t0 = time.time()
+        p = subprocess.run([REF, "dist", tmp, rs, qs, "rq.out", str(MAX_DIST), "1", "0", "0", str(cores)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall = time.time() - t0
+        m = re.search(r"time of multiple threads distance computing and save the subFile is: ([0-9.eE+-]+)",
+                      p.stderr.decode(errors="replace"))
+        if p.returncode != 0 or not m:
+            return None
+        t_dist = float(m.group(1))
+        return {"value": sample * n_ref / t_dist, "unit": "genome-pairs/s", "cores": cores, "kind": "reference",
+                "sample": "%d of the %d queries against all %d references, -D %g, -t %d: reference index_dist (src/dist.cpp) "
+                          "distance-loop phase %.3f s, process wall %.3f s" % (sample, n_query, n_ref, MAX_DIST, cores, t_dist, wall),
+                "wall_pairs_per_s": sample * n_ref / wall}
 
 
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-    from rabbitkssd_amd import capi, shard, synth
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
-                  file=sys.stderr)
-        sys.exit(2)
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the engine has no CPU fallback")
-    if args.same_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-    ctx = capi.Context(local_rank)
-    dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    env = Env(args)
+    from rabbitkssd_amd import shard
+    rank, world, ctx = env.rank, env.world, env.ctx
 
     n_genomes = args.genomes if args.scaling == "strong" else shard.weak_scaling_genomes(args.genomes, world)
-    n_pairs = n_genomes * (n_genomes - 1) // 2
+    keep = {}
+    head = alldist_block(env, n_genomes, args.steps, args.warmup, keep)
 
-    # ---- setup (untimed): rank 0 generates the sketches and builds the index on its GPU; the
-    # index travels to the peers as one blob in one RCCL broadcast
-    names = hashes = off = None
+    t_host_inclusive, n_host_hits = 0.0, 0
     if rank == 0:
-        names, hashes, off = synth.clade_sketches(n_genomes, HASHES_PER_GENOME, HASH_BITS, kmer_size=KMER)
-        sk = ctx.sketches_from_host(hashes, off)
-        t0 = time.time()
-        index = ctx.index_build(sk, HASH_BITS)
-        torch.cuda.synchronize()
-        t_index_build = time.time() - t0
-        nbytes = index.blob_bytes
-        # PCIe-inclusive reference point (never `value`): host sketches -> upload -> index build ->
-        # distance kernel -> hits back on the host
-        t0 = time.time()
-        sk2 = ctx.sketches_from_host(hashes, off)
-        idx2 = ctx.index_build(sk2, HASH_BITS)
-        host_hits, _ = ctx.dist_rows(idx2, None, 1, 0, KMER, MAX_DIST)
-        t_host_inclusive = time.time() - t0
-        del sk2, idx2
-    t_bcast = 0.0
-    if world > 1:
-        blob = None
-        if rank == 0:
-            blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            index.pack_dev(blob.data_ptr(), nbytes, stream)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.time()
-        blob = shard.broadcast_blob(blob, 0, dev, dist)   # ONE RCCL broadcast of the whole index
-        torch.cuda.synchronize()
-        t_bcast = time.time() - t0
-        nbytes = blob.numel()
-        if rank != 0:
-            index = ctx.index_unpack_dev(blob.data_ptr(), nbytes, stream)
-        del blob
-    H, T = index.total, index.sum_sq
+        # PCIe-inclusive reference point (never `value`): host sketches -> upload -> index build -> distance kernel ->
+        # hits back on the host, steady state (second pass)
+        for _ in range(2):
+            t0 = time.time()
+            sk2 = ctx.sketches_from_host(keep["hashes"], keep["off"])
+            idx2 = ctx.index_build(sk2, HASH_BITS)
+            host_hits, _ = ctx.dist_rows(idx2, None, 1, 0, KMER, MAX_DIST)
+            t_host_inclusive = time.time() - t0
+            n_host_hits = len(host_hits)
+            del sk2, idx2
+    keep.pop("index", None)
+    keep.pop("sk", None)
 
-    hits_cap = 1 << 20
-    hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    counters = torch.zeros(args.steps + args.warmup + 1, dtype=torch.int64, device=dev)
+    config3 = None
+    if not args.no_config3:
+        config3 = alldist_block(env, args.config3_genomes, max(10, args.steps // 10), 3)
+    rq_keep = {}
+    rq = None
+    if not args.no_dist_rq:
+        rq = dist_rq_block(env, keep=rq_keep)
 
-    def step(i):
-        ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap,
-                          counters.data_ptr() + 8 * i, row_first=rank, row_step=world, stream=stream,
-                          row_block=shard.ROW_BLOCK)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    ev1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    n_hits_rank = int(counters[args.warmup].item())
-    tot_hits = torch.tensor([n_hits_rank], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot_hits)
     if rank != 0:
         if world > 1:
-            dist.destroy_process_group()
+            env.dist.destroy_process_group()
         return
 
-    # ---- rank 0: report
-    # algorithmic bytes of one launch on this rank: 12 B per query hash (hash +
-    # two index offsets) + 4 B per posting streamed (T = sum c_h^2) + 4 B per count cell
-    # produced.  Rank 0 holds 1/world of the rows (interleaved -> ~1/world of each term).
-    b_alg = (12.0 * H + 4.0 * T) / world + 4.0 * shard.rank_pairs(n_genomes, 0, world)
-    achieved = b_alg / (kernel_ms * 1e-3) / 1e9
+    n_pairs = head["pairs"]
     out = {
         "metric": "genome-pairs/sec alldist (10k bacteria, L3K10)",
-        "value": n_pairs * args.steps / elapsed,
+        "value": head["value"],
         "unit": "genome-pairs/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u32 counts / f64 distance",
         "data": "synthetic",
-        "config": {"workload": "alldist over %d synthetic bacterial sketches (sketch-level clade generator, "
-                               "seed 20261003, L3K10: 28-bit hashes, ~%d per genome, clades of 10), -D %g, "
-                               "distance kernel only from an HBM-resident index" % (n_genomes, HASHES_PER_GENOME, MAX_DIST),
-                   "genomes": n_genomes, "pairs": n_pairs, "hashes": int(H), "postings_streamed_T": int(T),
-                   "hits": int(tot_hits.item()), "max_dist": MAX_DIST,
+        "config": {"workload": "alldist over %d synthetic bacterial sketches (sketch-level clade generator, seed 20261003, "
+                               "L3K10: 28-bit hashes, ~%d per genome, clades of 10), -D %g, distance kernel only from an "
+                               "HBM-resident index" % (n_genomes, HASHES_PER_GENOME, MAX_DIST),
+                   "genomes": n_genomes, "pairs": n_pairs, "hashes": head["hashes"],
+                   "postings_streamed_T": head["postings_streamed_T"], "hits": head["hits"], "max_dist": MAX_DIST,
                    "sharding": "query rows in blocks of 16 dealt round-robin to %d rank(s); index broadcast once (RCCL on GPUs)" % world},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "rk_dist_kernel", "kernel_ms": kernel_ms,
-                     "algorithmic_bytes_per_launch": b_alg},
-        "setup": {"index_build_ms": t_index_build * 1e3, "index_blob_bytes": int(nbytes),
-                  "rccl_broadcast_ms": t_bcast * 1e3,
+        "roofline": {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": head["achieved"] / HBM_PEAK_GBS, "traffic": None, "hbm_frac": None,
+                     "kernel": head["kernel"], "kernel_ms": head["kernel_ms"],
+                     "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
+                     "limiter": "same-address LDS atomics, L1 tag look-ups and wave latency (DESIGN.md 4.3): `frac` is the "
+                                "contract fraction on SURVEY 8d's byte model, which bills count cells that never leave LDS; "
+                                "`hbm_frac` is what the HBM counters saw"},
+        "setup": {"index_build_ms": head["index_build_ms"], "index_build_cold_ms": head["index_build_cold_ms"],
+                  "index_blob_bytes": head["index_blob_bytes"], "rccl_broadcast_ms": head["rccl_broadcast_ms"],
                   "host_inclusive_ms": t_host_inclusive * 1e3,
-                  "host_inclusive_note": "host sketches -> H2D -> rk_index_build -> rk_dist_rows -> %d hits on the "
-                                         "host (PCIe-inclusive, whole dataset, one pass; not `value`)" % len(host_hits)},
+                  "host_inclusive_note": "host sketches -> H2D -> rk_index_build -> rk_dist_rows -> %d hits on the host "
+                                         "(PCIe-inclusive, whole dataset, one pass, steady state; not `value`)" % n_host_hits},
     }
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and world == 1:
-        try:
-            out["roofline"]["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+    if world == 1:
+        traffic = load_pmc(head["kernel"])
+        if traffic:
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["hbm_frac"] = traffic / (head["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if config3:
+        out["config3"] = {
+            "workload": "alldist over %d synthetic bacterial sketches (BASELINE configs[3]), -D %g, strong scaling: the same "
+                        "dataset at every N" % (config3["genomes"], MAX_DIST),
+            "value": config3["value"], "unit": "genome-pairs/s", "ms_per_step": config3["ms_per_step"], "scaling": "strong",
+            "pairs": config3["pairs"], "hits": config3["hits"], "steps": config3["steps"], "warmup": config3["warmup"],
+            "index_build_ms": config3["index_build_ms"], "index_blob_bytes": config3["index_blob_bytes"],
+            "rccl_broadcast_ms": config3["rccl_broadcast_ms"],
+            "roofline": {"bound": "hbm", "achieved": config3["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": config3["achieved"] / HBM_PEAK_GBS, "traffic": None, "kernel": config3["kernel"],
+                         "kernel_ms": config3["kernel_ms"],
+                         "algorithmic_bytes_per_launch": config3["algorithmic_bytes_per_launch"]}}
+    if rq:
+        if world == 1:
+            pmc = load_pmc(rq["roofline"]["kernel"], "pmc_traffic_rq.json")
+            if pmc:
+                rq["roofline"]["traffic"] = pmc
+                rq["roofline"]["hbm_frac"] = pmc / (rq["roofline"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if not args.no_cpu_baseline:
+                cb = dist_rq_cpu_baseline(rq_keep, rq["pairs"])
+                if cb:
+                    rq["cpu_baseline"] = cb
+        out["dist_rq"] = rq
     if world == 1 and not args.no_sketch:
-        out["sketch"] = sketch_leg(ctx, capi, torch, args.sketch_genomes, args.sketch_length)
+        out["sketch"] = sketch_block(env, args.sketch_genomes, args.sketch_length)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(names, hashes, off, n_pairs)
+        cb, cli = alldist_cpu_and_cli(keep, n_pairs)
+        out["cpu_baseline"] = cb
+        if cb.get("wall_pairs_per_s"):
+            cb["gpu_kernel_vs_cpu_distance_loop"] = out["value"] / cb["value"]
+            cb["gpu_api_vs_cpu_wall"] = (n_pairs / t_host_inclusive) / cb["wall_pairs_per_s"]
+        if cli:
+            out["setup"].update(cli)
     print(json.dumps(out), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        env.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -82,6 +82,12 @@ void rk_ctx_destroy(rk_ctx *ctx);
  * again (steady-state calls allocate nothing: hipMalloc/hipFree cost 50-300 us each and hipFree synchronises the
  * device); rk_ctx_trim returns the cached blocks to the driver. */
 void rk_ctx_trim(rk_ctx *ctx);
+/* Measurement: with timing on, a pass brackets its dominant kernel with HIP events on the stream it is launched on;
+ * rk_ctx_last_ms(ctx, RK_MS_SKETCH_KERNEL) then returns that kernel's duration in milliseconds for the last
+ * rk_sketch_* call.  (The distance entry points launch one kernel per call: bracket rk_dist_rows_dev yourself.) */
+#define RK_MS_SKETCH_KERNEL 0
+void rk_ctx_set_timing(rk_ctx *ctx, int on);
+double rk_ctx_last_ms(const rk_ctx *ctx, int which);
 const char *rk_last_error(const rk_ctx *ctx);
 const char *rk_version(void);
 void rk_free_host(void *p);
@@ -239,6 +245,11 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
 int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
                      const rk_dist_opts *opts, rk_hit *hits_dev, uint64_t hits_cap,
                      uint64_t *n_hits_dev, void *stream);
+
+/* Name (as a profiler prints it, e.g. "rk_dist_kernel<true, 2, 512>") of the kernel rk_dist_rows(_dev) launches for
+ * these arguments: lets a harness check that a stored counter profile belongs to the variant it is timing. */
+int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries, const rk_dist_opts *opts,
+                        char *buf, size_t cap);
 
 /* -N: keeps, per query row, the max_neighbor nearest hits with the reference's heap
  * order (emitted largest distance first).  hits must be sorted by (row, col); the

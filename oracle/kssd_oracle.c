@@ -300,6 +300,11 @@ static uint64_t scan_records(const ok_param_t *p, const int32_t *shuffled_dim, c
     return scan_records_q(p, shuffled_dim, seq, NULL, 0, rec_off, n_rec, emit, n_windows, err);
 }
 
+/* membership bits of the selected .shuf entries: the role of the reference's `shuffled_map` (src/sketch.cpp:338-345,
+ * a 4096-entry hash map that stays in cache), so that the timed CPU port does not pay a DRAM access into the 64 MiB
+ * table for every window.  Results are unchanged: a set bit still goes through the table. */
+static const uint64_t *g_sel_bits = NULL;
+
 /* qual != NULL adds the FASTQ gate `quality[i] >= leastQual` of src/sketch.cpp:785 */
 static uint64_t scan_records_q(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq,
                                const uint8_t *qual, int least_qual, const uint64_t *rec_off,
@@ -325,6 +330,7 @@ static uint64_t scan_records_q(const ok_param_t *p, const int32_t *shuffled_dim,
                 uint64_t uni = tuple < rvs_tuple ? tuple : rvs_tuple; /* :508 */
                 int dim_id = (int)((uni & domask) >> (out * 2));      /* :509 */
                 if (!shuffled_dim) continue;
+                if (g_sel_bits && !((g_sel_bits[(uint32_t)dim_id >> 6] >> (dim_id & 63)) & 1ULL)) continue;
                 int32_t v = shuffled_dim[dim_id];
                 if (!(v < p->dim_end && v >= p->dim_start)) continue; /* :341,:516 */
                 uint64_t pfilter = (uint64_t)(v - p->dim_start);     /* :519-521 */
@@ -359,6 +365,33 @@ int64_t ok_sketch_records(const ok_param_t *p, const int32_t *shuffled_dim, cons
     if (!h) h = (uint64_t *)calloc(1, 8);
     *hashes_out = h;
     return (int64_t)u;
+}
+
+/* The reference's small-file loop (`#pragma omp parallel for ... schedule(dynamic)` over files, src/sketch.cpp:455-457)
+ * over genomes already in memory: genome g = seq[goff[g] .. goff[g+1]), one record each.  sizes_out[g] = sketch size.
+ * Used as the timed CPU baseline of the sketch leg (bench.py). */
+int ok_sketch_genomes_mt(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq, const uint64_t *goff,
+                         uint64_t n_genomes, int threads, uint64_t *sizes_out)
+{
+    const uint64_t n_dim = 1ULL << (4 * p->half_subk);
+    uint64_t *bits = (uint64_t *)calloc((n_dim + 63) / 64, 8);
+    if (!bits) return -3;
+    for (uint64_t t = 0; t < n_dim; t++)
+        if (shuffled_dim[t] < p->dim_end && shuffled_dim[t] >= p->dim_start) bits[t >> 6] |= 1ULL << (t & 63);
+    g_sel_bits = bits;
+    int failed = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic)
+    for (uint64_t g = 0; g < n_genomes; g++) {
+        uint64_t *h = NULL;
+        const uint64_t off[2] = {goff[g], goff[g + 1]};
+        int64_t n = ok_sketch_records(p, shuffled_dim, seq, off, 1, &h);
+        if (n < 0) failed = 1;
+        sizes_out[g] = n < 0 ? 0 : (uint64_t)n;
+        free(h);
+    }
+    g_sel_bits = NULL;
+    free(bits);
+    return failed ? -3 : 0;
 }
 
 /* FASTQ variant, src/sketch.cpp:781-845: quality gate + per-hash occurrence count; a hash is

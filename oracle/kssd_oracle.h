@@ -83,6 +83,8 @@ int ok_parse_fastq_mem(const uint8_t *buf, uint64_t n, uint8_t **seq, uint8_t **
                        uint64_t **rec_off, uint64_t *n_rec);
 /* f1: src/sketch.cpp:781-845 (sketchFastqFile): base valid iff ACGT and quality >= least_qual;
  * hash kept iff it occurred >= least_num times.  Output sorted. */
+int ok_sketch_genomes_mt(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq, const uint64_t *goff,
+                         uint64_t n_genomes, int threads, uint64_t *sizes_out);
 int64_t ok_sketch_records_fastq(const ok_param_t *p, const int32_t *shuffled_dim, const uint8_t *seq,
                                 const uint8_t *qual, int least_qual, int least_num,
                                 const uint64_t *rec_off, uint64_t n_rec, uint64_t **hashes_out);

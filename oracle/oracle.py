@@ -173,6 +173,20 @@ def sketch_records(param, shuffled_dim, seq, rec_off):
     return h
 
 
+def sketch_genomes_mt(param, shuffled_dim, seq, goff, threads):
+    """sketch sizes of the genomes seq[goff[g]:goff[g+1]] (one record each), `threads` OpenMP threads over genomes
+    like the reference's small-file loop (src/sketch.cpp:455-457): the timed CPU baseline of bench.py's sketch leg"""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    goff = np.ascontiguousarray(goff, dtype=np.uint64)
+    tab = np.ascontiguousarray(shuffled_dim, dtype=np.int32)
+    sizes = np.zeros(len(goff) - 1, dtype=np.uint64)
+    rc = lib().ok_sketch_genomes_mt(C.byref(param), _p(tab, C.c_int32), _p(seq, C.c_uint8), _p(goff, C.c_uint64),
+                                    C.c_uint64(len(goff) - 1), int(threads), _p(sizes, C.c_uint64))
+    if rc:
+        raise MemoryError("ok_sketch_genomes_mt failed")
+    return sizes
+
+
 def count_windows(param, seq, rec_off):
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
     rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)

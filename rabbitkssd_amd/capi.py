@@ -16,7 +16,7 @@ HIT_DTYPE = np.dtype([("row", "<u4"), ("col", "<u4"), ("common", "<i4"), ("size0
                       ("size1", "<i4"), ("pad", "<i4"), ("jorc", "<f8"), ("dist", "<f8")])
 
 EXPORTS = [
-    "rk_device_count", "rk_ctx_create", "rk_ctx_destroy", "rk_ctx_trim", "rk_last_error", "rk_version",
+    "rk_device_count", "rk_ctx_create", "rk_ctx_destroy", "rk_ctx_trim", "rk_ctx_set_timing", "rk_ctx_last_ms", "rk_dist_kernel_name", "rk_last_error", "rk_version",
     "rk_free_host", "rk_pinned_alloc", "rk_pinned_free", "rk_dev_alloc", "rk_dev_free", "rk_stream_create",
     "rk_stream_destroy", "rk_stream_sync", "rk_upload_async", "rk_params_init", "rk_hash_bits", "rk_filter_create", "rk_filter_free",
     "rk_sketch_batch", "rk_sketch_batch_ex", "rk_sketch_packed_dev", "rk_sketch_packed_dev_ex", "rk_pack_layout", "rk_pack_genomes",
@@ -67,6 +67,9 @@ def lib():
         L.rk_free_host.argtypes = [C.c_void_p]
         L.rk_ctx_destroy.argtypes = [C.c_void_p]
         L.rk_ctx_trim.argtypes = [C.c_void_p]
+        L.rk_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.rk_ctx_last_ms.argtypes = [C.c_void_p, C.c_int]
+        L.rk_ctx_last_ms.restype = C.c_double
         for f in ("rk_filter_free", "rk_sketches_free", "rk_index_free"):
             getattr(L, f).argtypes = [C.c_void_p]
         for f in ("rk_sketches_total", "rk_sketches_windows", "rk_index_total", "rk_index_distinct",
@@ -116,6 +119,21 @@ class Context:
                 o.close()
             lib().rk_ctx_destroy(self._h)
             self._h = C.c_void_p()
+
+    def set_timing(self, on=True):
+        lib().rk_ctx_set_timing(self._h, 1 if on else 0)
+
+    def last_ms(self, which=0):
+        """duration of the dominant kernel of the last pass (0: sketch kernel), HIP events on its stream"""
+        return float(lib().rk_ctx_last_ms(self._h, int(which)))
+
+    def dist_kernel_name(self, index, queries, triangle, metric, kmer_size, max_dist, row_first=0, row_step=1, row_block=0):
+        opts = DistOpts(int(triangle), int(metric), int(kmer_size), int(row_block), float(max_dist),
+                        int(row_first), int(row_step))
+        buf = C.create_string_buffer(128)
+        self.check(lib().rk_dist_kernel_name(self._h, index._h, queries._h if queries is not None else None, C.byref(opts),
+                                             buf, C.c_size_t(128)))
+        return buf.value.decode()
 
     def trim(self):
         """returns the device memory cached by the context's allocator to the driver"""

@@ -168,6 +168,16 @@ int rk_ctx_create(int device, rk_ctx **out)
     return RK_OK;
 }
 
+void rk_ctx_set_timing(rk_ctx *ctx, int on)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (on && !ctx->ev[0] && (hipEventCreate(&ctx->ev[0]) != hipSuccess || hipEventCreate(&ctx->ev[1]) != hipSuccess)) return;
+    ctx->timing = on != 0;
+}
+
+double rk_ctx_last_ms(const rk_ctx *ctx, int which) { return ctx && which >= 0 && which < 4 ? ctx->last_ms[which] : 0.0; }
+
 void rk_ctx_trim(rk_ctx *ctx)
 {
     if (!ctx) return;
@@ -193,6 +203,8 @@ void rk_ctx_destroy(rk_ctx *ctx)
     // blocks still handed out belong to objects the caller has not freed: they are released with the context
     for (auto &b : ctx->live) (void)hipFree(b.first);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (hipEvent_t e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 

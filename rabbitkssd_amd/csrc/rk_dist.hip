@@ -742,6 +742,18 @@ extern "C" int rk_debug_dist_prof(unsigned long long *out16, int reset)
 
 extern "C" {
 
+int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries, const rk_dist_opts *opts, char *buf,
+                        size_t cap)
+{
+    if (!ctx || !idx || !opts || !buf || !cap) return RK_ERR_ARG;
+    if (queries) return rk_distq_kernel_name(ctx, idx, queries, buf, cap);
+    Plan p;
+    int rc = make_plan(ctx, idx, idx->n_ref, idx->max_src_size, opts, true, &p);
+    if (rc) return rc;
+    snprintf(buf, cap, "rk_dist_kernel<%s, %d, %u>", p.u16 ? "true" : "false", p.mode, p.threads);
+    return RK_OK;
+}
+
 int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
                      const rk_dist_opts *opts, rk_hit *hits_dev, uint64_t hits_cap,
                      uint64_t *n_hits_dev, void *stream)

@@ -400,6 +400,23 @@ distq_kernel_t pick_kernel(int cbits, int look)
 
 }  // namespace
 
+static int counter_bits(const rk_index *idx, const rk_sketches *qs)
+{
+    // an intersection count never exceeds the smaller sketch when both sides are sets; a query with repeated
+    // hashes still cannot exceed its own length as long as the references are sets
+    uint64_t bound = ~0ULL;
+    if (idx->ref_sets) bound = qs->is_set ? std::min<uint64_t>(qs->max_size, idx->max_ref_size) : qs->max_size;
+    return bound < 256 ? 8 : (bound < 65536 ? 16 : 32);
+}
+
+int rk_distq_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, char *buf, size_t cap)
+{
+    const int look = idx->wide ? kLookDir64 : (idx->hash_bits <= kRankMaxBits ? kLookRank : kLookDir32);
+    snprintf(buf, cap, "rk_distq_kernel<%d, %d>", counter_bits(idx, qs), look);
+    (void)ctx;
+    return RK_OK;
+}
+
 int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, const rk_dist_opts *o, rk_hit *hits_dev,
                     uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev, hipStream_t stream)
 {
@@ -408,11 +425,7 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     if (qs->wide != idx->wide) return rk_fail(ctx, RK_ERR_ARG, "query sketches and index use different hash widths");
     if (!qs->n || !idx->n_ref) return RK_OK;
     PlanQ p;
-    // an intersection count never exceeds the smaller sketch when both sides are sets; a query with repeated
-    // hashes still cannot exceed its own length as long as the references are sets
-    uint64_t bound = ~0ULL;
-    if (idx->ref_sets) bound = qs->is_set ? std::min<uint64_t>(qs->max_size, idx->max_ref_size) : qs->max_size;
-    p.cbits = bound < 256 ? 8 : (bound < 65536 ? 16 : 32);
+    p.cbits = counter_bits(idx, qs);
     int rc = ensure_rankbm(ctx, const_cast<rk_index *>(idx), stream);  // lazily built, cached in the index
     if (rc) return rc;
     p.look = idx->wide ? kLookDir64 : (idx->d_rankbm ? kLookRank : kLookDir32);

@@ -32,6 +32,10 @@ struct rk_ctx {
     std::unordered_map<void *, size_t> live;  // every block handed out or cached -> its size
     size_t pool_bytes = 0;
     std::map<std::tuple<const void *, int, size_t>, int> occupancy;  // hipOccupancy... costs 10-70 us per query
+    // optional HIP-event timing of the dominant kernel of a pass (rk_ctx_set_timing): [0] sketch kernel
+    bool timing = false;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    double last_ms[4] = {0, 0, 0, 0};
     // developer switches (environment), read once at context creation
     uint32_t sw_dist_threads = 0, sw_dist_rows = 0, sw_dist_pair = 1, sw_dist_pair_minwg = 3, sw_dist_persist = 1;
     uint32_t sw_dist_cand_cap = 0, sw_dist_stage_hits = 0, sw_dist_xcd_rows = 0;
@@ -144,6 +148,8 @@ int rk_index_ensure_dir(rk_ctx *ctx, rk_index *idx, hipStream_t stream);
 int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries, const rk_dist_opts *opts,
                     rk_hit *hits_dev, uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev,
                     hipStream_t stream);
+// the kernel variant rk_distq_launch would pick, as a profiler prints it
+int rk_distq_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries, char *buf, size_t cap);
 // true when every posting is reportable regardless of its count (the threshold admits distance 1.0)
 inline bool rk_dense_mode(const rk_dist_opts *o) { return o->triangle ? (1.0 < o->max_dist) : (1.0 <= o->max_dist); }
 // sets s->is_set / s->max_size from the device arrays (one small kernel + a 4-byte read-back)

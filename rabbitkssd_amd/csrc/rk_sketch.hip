@@ -928,7 +928,9 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             // persistent: one workgroup per CU (the 156 KiB LDS image admits only one), each
             // striding over the chunks, so the filter image is staged once per CU
             const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu);
+            if (ctx->timing) RK_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kSketchThreads), 0, stream, a);
+            if (ctx->timing) RK_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
             RK_HIP(ctx, hipGetLastError());
         }
         if (n_genomes) {
@@ -989,6 +991,10 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             }
         if (!overflow) break;
         if (attempt == 1) return rk_fail(ctx, RK_ERR_CAPACITY, "candidate overflow persisted");
+    }
+    if (ctx->timing && n_chunks) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_ms[RK_MS_SKETCH_KERNEL] = ms;
     }
     s->windows = tail.windows;
     s->total = s->h_off[n_genomes];

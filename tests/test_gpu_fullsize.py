@@ -170,3 +170,155 @@ def test_config0_fasta_to_alldist_64x5mb(ctx):
                               threads=CORES)
     assert len(want) == 6 * 45 + 6      # six complete clades + the 4-strain remainder
     check_hits(mine, want)
+
+
+# ------------------------------------------------------------------ configs[1]: 1,000 x 5 Mb FASTA -> sketch -> alldist
+def _make_clade(args):
+    """worker: writes the 10 strains of one clade as FASTA files; returns [(path, oracle hash set or None)]"""
+    clade, out_dir, length, oracle_strains = args
+    anc = np.random.default_rng(1000 + clade).integers(0, 4, size=length, dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    param = table = None
+    res = []
+    for s in range(10):
+        codes = anc
+        if s:
+            rng = np.random.default_rng(5000 + 10 * clade + s)
+            mut = rng.random(length) < 0.002 * s
+            shift = rng.integers(1, 4, size=length, dtype=np.uint8)
+            codes = np.where(mut, (anc + shift) & 3, anc).astype(np.uint8)
+        bases = acgt[codes]
+        path = os.path.join(out_dir, "c%03d_s%d.fna" % (clade, s))
+        with open(path, "wb") as f:
+            f.write(synth.fasta_text("c%d_s%d" % (clade, s), bases))
+        want = None
+        if s in oracle_strains:
+            if param is None:
+                param, table = ok.init_param(10, 6, 3), ok.shuffle_table(10, 6, 3)
+            want = ok.sketch_records(param, table, bases, np.array([0, length], dtype=np.uint64))
+        res.append((path, want))
+    return res
+
+
+def test_config1_cli_1000x5mb_sketch_then_alldist(tmp_path):
+    """configs[1] at full size through the host tool: 1,000 synthetic 5 Mb genomes (100 clades of 10 strains, 5 GB of
+    FASTA written by a process pool) -> `rabbit_kssd sketch` -> `rabbit_kssd alldist -D 0.05`.  Every 20th genome's
+    hash set equals the oracle's, all sizes are those of a 5 Mb genome at L3K10, exactly 45 hits per clade, and the
+    `common` of sampled hits is the set intersection of the two sketches."""
+    import multiprocessing as mp
+    import shutil
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rabbitkssd_amd", "rabbit_kssd")
+    n_clades, length = 100, 5_000_000
+    free = shutil.disk_usage(str(tmp_path)).free
+    batch_clades = n_clades if free > 14 * (1 << 30) else 20   # all 5 GB at once if the disk allows, else 1 GB batches
+    assert free > 3 * (1 << 30), "needs 3 GB of scratch space"
+    shuf = tmp_path / "L3K10.shuf"
+    subprocess.run([tool, "shuffle", "-k", "10", "-s", "6", "-l", "3", "-o", str(shuf)], check=True, capture_output=True)
+    wants, parts = {}, []
+    with mp.get_context("fork").Pool(min(16, CORES)) as pool:
+        for b0 in range(0, n_clades, batch_clades):
+            d = tmp_path / ("b%d" % b0)
+            d.mkdir()
+            # genome index g = 10 * clade + strain; every 20th genome = strain 0 of the even clades
+            jobs = [(c, str(d), length, {0} if c % 2 == 0 else set()) for c in range(b0, min(n_clades, b0 + batch_clades))]
+            files = []
+            for res in pool.map(_make_clade, jobs):
+                for path, want in res:
+                    files.append(path)
+                    if want is not None:
+                        wants[path] = want
+            lst = tmp_path / ("b%d.list" % b0)
+            lst.write_text("".join(f + "\n" for f in files))
+            out = tmp_path / ("b%d.sketch" % b0)
+            p = subprocess.run([tool, "sketch", "-q", "-i", str(lst), "-L", str(shuf), "-o", str(out), "-t", str(min(16, CORES))],
+                               capture_output=True)
+            assert p.returncode == 0, p.stderr.decode()[-2000:]
+            parts.append(str(out))
+            shutil.rmtree(d)
+    merged = parts[0]
+    if len(parts) > 1:
+        (tmp_path / "parts.list").write_text("".join(p + "\n" for p in parts))
+        merged = str(tmp_path / "all.sketch")
+        p = subprocess.run([tool, "merge", "-i", str(tmp_path / "parts.list"), "-o", merged], capture_output=True)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+    info, names, h, off = ok.read_sketches32(merged)
+    assert (info.half_k, info.half_subk, info.drlevel, info.genomeNumber) == (10, 6, 3, 10 * n_clades)
+    sizes = np.diff(off).astype(np.int64)
+    # 5,000,000 / 4096 = 1,221 expected hashes, sd ~35: the extremes of 1,000 genomes lie ~3.5 sd out
+    assert 1050 < sizes.min() and sizes.max() < 1400 and 1200 < sizes.mean() < 1245, (sizes.min(), sizes.max(), sizes.mean())
+    assert len(wants) == 10 * n_clades // 20
+    for g, name in enumerate(names):
+        if name in wants:
+            assert g % 20 == 0
+            assert np.array_equal(h[int(off[g]):int(off[g + 1])].astype(np.uint64), wants[name]), name
+    p = subprocess.run([tool, "alldist", "-i", merged, "-D", "0.05", "-o", "c1.out"], cwd=str(tmp_path), capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = (tmp_path / "c1.out").read_text().split("\n")
+    assert lines[0] == " genome0\tgenome1\tcommon|size0|size1\tjaccard\tmashD"
+    body = [x for x in lines[1:] if x]
+    assert len(body) == 45 * n_clades
+    index_of = {n: i for i, n in enumerate(names)}
+    rng = np.random.default_rng(1)
+    for t in rng.integers(0, len(body), size=300):
+        a, b, triple, jac, dist = body[t].split("\t")
+        j, i = index_of[a], index_of[b]            # alldist prints (sketch[j], sketch[i]) with j > i, sizes (size_i, size_j)
+        assert j > i and i // 10 == j // 10
+        common, s0, s1 = (int(x) for x in triple.split("|"))
+        si, sj = h[int(off[i]):int(off[i + 1])], h[int(off[j]):int(off[j + 1])]
+        assert (s0, s1) == (len(si), len(sj))
+        assert common == len(np.intersect1d(si, sj, assume_unique=True))
+        jj, dd = ok.distance(common, s0, s1, 0, 20)
+        assert jac == "%f" % jj and dist == "%f" % dd
+
+
+# ------------------------------------------------------------------ configs[4]: all 1,000 queries x 100,000 references
+def test_config4_ref_vs_query_all_1000_queries(ctx):
+    """configs[4] with every query: 1,000 queries of ~45,776 hashes (3 Gb genomes at L4K10) against 100,000 reference
+    sketches of 76 hashes, 24-bit hashes.  50 sampled queries get reference sketches planted into them and are compared
+    hit for hit with the oracle (containment -D 0.05 and jaccard -D 0.5); the other 950 share only chance hashes with any
+    reference, so the whole result must be exactly the oracle's result on the sample."""
+    rn, rh, roff = synth.clade_sketches(100000, 76, 24, seed=31)
+    qn, qh, qoff = synth.clade_sketches(1000, 45776, 24, seed=32)
+    rng = np.random.default_rng(4)
+    sample = np.sort(rng.choice(1000, size=50, replace=False))
+    parts = [qh[int(qoff[q]):int(qoff[q + 1])] for q in range(1000)]
+    for q in sample:
+        refs = rng.choice(100000, size=5, replace=False)
+        planted = [rh[int(roff[r]):int(roff[r + 1])] for r in refs]
+        parts[q] = np.unique(np.concatenate([parts[q]] + planted))
+    qoff = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    qh = np.concatenate(parts)
+    idx = ctx.index_build(ctx.sketches_from_host(rh, roff), 24)
+    qs = ctx.sketches_from_host(qh, qoff)
+    assert ctx.dist_kernel_name(idx, qs, 0, 1, 20, 0.05) == "rk_distq_kernel<8, 0>"   # one 100 KB tile of 8-bit counters
+    postings, counts = ok.index_build32(rh, roff, 24)
+    sizes = np.diff(roff).astype(np.uint32)
+    s_off = np.concatenate([[0], np.cumsum([len(parts[q]) for q in sample])]).astype(np.uint64)
+    s_h = np.concatenate([parts[q] for q in sample])
+    for metric, D in ((1, 0.05), (0, 0.5)):
+        want, _ = ok.index_dist32(counts, 24, postings, sizes, s_h, s_off, 0, metric, 20, D, threads=CORES)
+        want = want.copy()
+        want["row"] = sample[want["row"]]        # sample-local query numbers -> global
+        mine, _ = ctx.dist_rows(idx, qs, 0, metric, 20, D)
+        if metric == 1:
+            assert len(want) >= 50 * 5
+            check_hits(mine, want)               # nothing outside the sample may be reported
+        else:
+            # jaccard of a 76-hash reference inside a 45,776-hash query is at most 0.0017: distance 0.28 > 0.05 but < 0.5
+            sel = mine[np.isin(mine["row"], sample)]
+            check_hits(sel, want)
+            rest = mine[~np.isin(mine["row"], sample)]
+            for t in rng.integers(0, max(1, len(rest)), size=min(200, len(rest))):
+                q, r = int(rest["row"][t]), int(rest["col"][t])
+                a = rh[int(roff[r]):int(roff[r + 1])]
+                assert rest["common"][t] == len(np.intersect1d(parts[q], a, assume_unique=True))
+                assert (rest["size0"][t], rest["size1"][t]) == (len(a), len(parts[q]))
+    # dense counter rows of three whole queries (one planted, two not) against brute-force set intersections
+    three = [int(sample[0]), 1, 998]
+    t_off = np.concatenate([[0], np.cumsum([len(parts[q]) for q in three])]).astype(np.uint64)
+    t_qs = ctx.sketches_from_host(np.concatenate([parts[q] for q in three]), t_off)
+    _, dense = ctx.dist_rows(idx, t_qs, 0, 0, 20, 0.05, want_dense=True)
+    _, wdense = ok.index_dist32(counts, 24, postings, sizes, np.concatenate([parts[q] for q in three]), t_off, 0, 0, 20, 0.05,
+                                want_dense=True)
+    assert np.array_equal(dense, wdense)
