@@ -212,6 +212,10 @@ uint64_t rk_index_blob_bytes(const rk_index *idx);
 int rk_index_pack_dev(const rk_index *idx, void *blob_dev, uint64_t blob_cap, void *stream);
 int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, void *stream,
                         rk_index **out);
+/* The same inside ONE process that drives several GPUs (one context and one host thread per GPU): replicates the
+ * index of src's context onto each of the n_dst contexts, all peers copying at the same time over their own xGMI link
+ * (hipMemcpyPeerAsync; contexts on the source's device get a device-to-device copy).  out[i] belongs to dst[i]. */
+int rk_index_broadcast(const rk_index *src, rk_ctx *const *dst, uint32_t n_dst, rk_index **out);
 void rk_index_free(rk_index *idx);
 
 /* ---- distances ------------------------------------------------------------------- */

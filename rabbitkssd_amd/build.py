@@ -52,8 +52,9 @@ def build(force=False, verbose=False):
     host_src = os.path.join(HERE, "host", "rabbit_kssd.cpp")
     host_deps = [host_src, os.path.join(HERE, "host", "formats.hpp"), os.path.join(ROOT, "include", "rabbitkssd.h"), LIB]
     if force or _newer(TOOL, host_deps):
-        run([HIPCC, "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), host_src, "-o", TOOL,
-             "-L" + HERE, "-lrabbitkssd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN"])
+        # plain g++: the host side sees only the C ABI (no HIP headers, no device pass)
+        run([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), host_src, "-o", TOOL,
+             "-L" + HERE, "-lrabbitkssd", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib"])
     return LIB
 
 

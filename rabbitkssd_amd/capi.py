@@ -24,7 +24,7 @@ EXPORTS = [
     "rk_sketches_download", "rk_sketches_hashes_dev", "rk_sketches_off_dev", "rk_sketches_free",
     "rk_index_build", "rk_index_import", "rk_index_export", "rk_index_import64", "rk_index_export64", "rk_index_total",
     "rk_index_distinct", "rk_index_genomes", "rk_index_hash_bits", "rk_index_sum_sq",
-    "rk_index_free", "rk_index_blob_bytes", "rk_index_pack_dev", "rk_index_unpack_dev", "rk_dist_rows", "rk_dist_rows_dev", "rk_topn_rows", "rk_format_hit",
+    "rk_index_free", "rk_index_blob_bytes", "rk_index_pack_dev", "rk_index_unpack_dev", "rk_index_broadcast", "rk_dist_rows", "rk_dist_rows_dev", "rk_topn_rows", "rk_format_hit",
 ]
 
 
@@ -218,6 +218,14 @@ class Context:
         self.check(lib().rk_sketches_from_dev(self._h, C.c_void_p(hashes_dev_ptr), C.c_void_p(off_dev_ptr),
                                               C.c_uint32(n_genomes), C.byref(h)))
         return Sketches(self, h)
+
+    def index_broadcast_from(self, index, n=1):
+        """replicates `index` (of another context) onto this context n times is not meaningful; this helper copies it
+        once onto this context (rk_index_broadcast with one destination)"""
+        ctxs = (C.c_void_p * 1)(self._h)
+        outs = (C.c_void_p * 1)()
+        index.ctx.check(lib().rk_index_broadcast(index._h, ctxs, C.c_uint32(1), outs))
+        return Index(self, C.c_void_p(outs[0]))
 
     def index_unpack_dev(self, blob_dev_ptr, blob_bytes, stream=0):
         h = C.c_void_p()

@@ -719,6 +719,65 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
 
 }  // extern "C"
 
+// ---- one-to-all replication inside one process (the host tool's --gpus N) -----------------------------------
+extern "C" int rk_index_broadcast(const rk_index *src, rk_ctx *const *dst, uint32_t n_dst, rk_index **out)
+{
+    if (!src || (n_dst && (!dst || !out))) return RK_ERR_ARG;
+    rk_ctx *sctx = src->ctx;
+    for (uint32_t i = 0; i < n_dst; i++) out[i] = nullptr;
+    if (!n_dst) return RK_OK;
+    const uint64_t bytes = rk_index_blob_bytes(src);
+    RK_HIP(sctx, hipSetDevice(sctx->device));
+    DevBuf<char> blob(sctx);
+    if (blob.alloc(bytes) != hipSuccess) return rk_fail(sctx, RK_ERR_NOMEM, "cannot allocate the %llu-byte index blob", (unsigned long long)bytes);
+    int rc = rk_index_pack_dev(src, blob.p, bytes, sctx->stream);  // synchronises the source stream
+    if (rc) return rc;
+    // every peer pulls the blob over its own xGMI link at the same time (the links are point to point, so a
+    // one-to-all of direct copies moves the blob once per link, like a pipelined ring, without a communicator)
+    std::vector<char *> peer(n_dst, nullptr);
+    for (uint32_t i = 0; i < n_dst; i++) {
+        rk_ctx *d = dst[i];
+        if (!d) return RK_ERR_ARG;
+        RK_HIP(d, hipSetDevice(d->device));
+        peer[i] = static_cast<char *>(rk_pool_alloc(d, bytes));
+        if (!peer[i]) {
+            for (uint32_t j = 0; j < i; j++) rk_pool_free(dst[j], peer[j]);
+            return rk_fail(d, RK_ERR_NOMEM, "cannot allocate the %llu-byte index blob on device %d", (unsigned long long)bytes, d->device);
+        }
+        hipError_t e;
+        if (d->device == sctx->device) {
+            e = hipMemcpyAsync(peer[i], blob.p, bytes, hipMemcpyDeviceToDevice, d->stream);
+        } else {
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, d->device, sctx->device);
+            if (can) {
+                hipError_t pe = hipDeviceEnablePeerAccess(sctx->device, 0);
+                if (pe != hipSuccess) (void)hipGetLastError();  // already enabled
+            }
+            e = hipMemcpyPeerAsync(peer[i], d->device, blob.p, sctx->device, bytes, d->stream);
+        }
+        if (e != hipSuccess) {
+            for (uint32_t j = 0; j <= i; j++) rk_pool_free(dst[j], peer[j]);
+            return rk_fail(d, RK_ERR_HIP, "index copy to device %d failed: %s", d->device, hipGetErrorString(e));
+        }
+    }
+    for (uint32_t i = 0; i < n_dst && !rc; i++) {
+        rk_ctx *d = dst[i];
+        if (hipSetDevice(d->device) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess)
+            rc = rk_fail(d, RK_ERR_HIP, "index copy to device %d did not complete", d->device);
+        else
+            rc = rk_index_unpack_dev(d, peer[i], bytes, d->stream, &out[i]);
+    }
+    for (uint32_t i = 0; i < n_dst; i++) rk_pool_free(dst[i], peer[i]);
+    if (rc)
+        for (uint32_t i = 0; i < n_dst; i++) {
+            rk_index_free(out[i]);
+            out[i] = nullptr;
+        }
+    (void)hipSetDevice(sctx->device);
+    return rc;
+}
+
 // ---- 64-bit hash layout: sparse .index = {u64 n; u64 hash[n]; u32 count[n]} ------------------
 // (src/sketch.cpp:961-963, read back at src/dist.cpp:36-82; any block order is legal)
 namespace {

@@ -22,6 +22,7 @@
 #include <cstdarg>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -52,18 +53,43 @@ static double get_sec()
     exit(1);
 }
 
+static const double g_t_start = get_sec();
+static void stamp(const char *what)
+{
+    static const bool on = getenv("RK_TIMING") != nullptr;
+    if (on) fprintf(stderr, "[timing] %8.3f ms  %s\n", (get_sec() - g_t_start) * 1e3, what);
+}
+
 struct Gpu {
     rk_ctx *ctx = nullptr;
     explicit Gpu(int device)
     {
+        stamp("before rk_ctx_create");
         int rc = rk_ctx_create(device, &ctx);
         if (rc) die("no usable GPU (rk_ctx_create(%d) = %d): this build has no CPU path", device, rc);
+        stamp("context ready");
     }
-    ~Gpu() { rk_ctx_destroy(ctx); }
+    // The process ends right after its last GPU call (main leaves through _exit): returning ~600 MB of pooled device
+    // memory block by block and tearing the HIP runtime down costs 60-100 ms that buy nothing.
+    ~Gpu() {}
     void check(int rc, const char *what) const
     {
         if (rc) die("%s failed (%d): %s", what, rc, rk_last_error(ctx));
     }
+};
+
+// HIP runtime start-up (hipInit: 150-190 ms on an MI355X box) is the largest single item of a short alldist/dist run:
+// it starts on a thread of its own while the main thread reads the .sketch files
+struct AsyncGpu {
+    std::unique_ptr<Gpu> g;
+    std::thread th;
+    explicit AsyncGpu(int device) : th([this, device] { g.reset(new Gpu(device)); }) {}
+    Gpu &get()
+    {
+        if (th.joinable()) th.join();
+        return *g;
+    }
+    ~AsyncGpu() { if (th.joinable()) th.join(); }
 };
 
 // ---- tiny option parser -----------------------------------------------------------------
@@ -447,24 +473,62 @@ static rk_index *build_index(Gpu &gpu, const SketchSet &s, const string &sketch_
     return idx;
 }
 
-// writes the distance text exactly as src/dist.cpp:233,291 / :642,725 do; above 4 GiB the
-// rows are kept as sub-files in <out>.dir with an <out>.index map (src/dist.cpp:276-336)
-static void write_hits(const string &out, const rk_hit *hits, uint64_t n, bool alldist, const vector<string> &rows,
+// ---- distance text (src/dist.cpp:233,256,263-336 / :642,690,696-770) --------------------------------------------
+// The reference's worker threads each append their rows to a sub-file `<out>.dir/<out>.<tid>` and note
+// "rowName\tsubFile" in `<out>.index.<tid>`; afterwards the sub-files are concatenated into <out> behind the header
+// line when they total at most 4 GiB, otherwise they stay and the notes become `<out>.index` (:276-336).  Here a
+// worker is a (GPU, formatter thread) pair: every GPU's hits (sorted by row) are cut at row boundaries into pieces,
+// each piece is formatted once by one thread, and the pieces are either written into <out> with concurrent pwrites
+// or kept as the sub-files.  Every row is listed exactly once in the index, hits or not, like the reference's.
+struct HitPart {              // what one GPU computed
+    const rk_hit *hits = nullptr;
+    uint64_t n = 0;
+    vector<uint32_t> rows;    // the rows it owns, ascending
+};
+
+static uint64_t max_merge_bytes()
+{
+    const char *v = getenv("RK_DIST_MAX_MERGE_BYTES");  // tests force the split on small outputs
+    return v && atoll(v) > 0 ? (uint64_t)atoll(v) : 1ULL << 32;
+}
+
+static void write_hits(const string &out, const vector<HitPart> &parts, bool alldist, const vector<string> &rows,
                        const vector<string> &cols, int threads = 1)
 {
     const double t0 = get_sec();
-    const uint64_t max_size = 1ULL << 32;
+    const uint64_t max_size = max_merge_bytes();
     auto line = [&](const rk_hit &h, char *buf, size_t cap) {
         const string &a = alldist ? cols[h.col] : rows[h.row];
         const string &b = alldist ? rows[h.row] : cols[h.col];
         if (a.size() + b.size() + 128 > cap) die("genome name too long");
         return rk_format_hit(buf, cap, a.c_str(), b.c_str(), &h);
     };
-    vector<char> buf(1 << 16);
-    // the text of every line, formatted once by all threads (the role of the reference's per-thread
-    // sub-files, src/dist.cpp:207-255): pieces of consecutive hits, concatenated in order below
-    const uint64_t n_pieces = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, threads) * 4, (n + 65535) / 65536));
-    vector<string> piece(n_pieces);
+    struct Piece {
+        const rk_hit *hits;
+        uint64_t n;
+        const uint32_t *row_begin, *row_end;  // rows listed under this piece in the index
+        string text;
+    };
+    vector<Piece> pieces;
+    const int per_part = std::max(1, std::max(1, threads) / (int)std::max<size_t>(1, parts.size()));
+    for (const HitPart &pt : parts) {
+        // cut the part into up to per_part pieces of ~equal hit counts at row boundaries
+        uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_part * 4, (pt.n + 65535) / 65536));
+        if (max_size != (1ULL << 32)) want = (uint64_t)per_part;  // sub-file layout under test: one piece per worker
+        uint64_t i0 = 0;
+        size_t r0 = 0;
+        for (uint64_t p = 0; p < want; p++) {
+            uint64_t i1 = p + 1 == want ? pt.n : std::max(i0, pt.n / want * (p + 1));
+            while (i1 < pt.n && i1 > 0 && pt.hits[i1].row == pt.hits[i1 - 1].row) i1++;  // whole rows
+            size_t r1 = pt.rows.size();
+            if (p + 1 < want && i1 < pt.n) r1 = std::lower_bound(pt.rows.begin(), pt.rows.end(), pt.hits[i1].row) - pt.rows.begin();
+            if (p + 1 == want) i1 = pt.n;
+            pieces.push_back(Piece{pt.hits + i0, i1 - i0, pt.rows.data() + r0, pt.rows.data() + r1, string()});
+            i0 = i1;
+            r0 = r1;
+        }
+    }
+    const uint64_t n_pieces = pieces.size();
     {
         std::atomic<uint64_t> next{0};
         auto work = [&]() {
@@ -472,10 +536,9 @@ static void write_hits(const string &out, const rk_hit *hits, uint64_t n, bool a
             for (;;) {
                 const uint64_t p = next.fetch_add(1);
                 if (p >= n_pieces) break;
-                const uint64_t i0 = n / n_pieces * p, i1 = p + 1 == n_pieces ? n : n / n_pieces * (p + 1);
-                string &t = piece[p];
-                t.reserve((size_t)(i1 - i0) * 72);
-                for (uint64_t i = i0; i < i1; i++) t.append(lb.data(), (size_t)line(hits[i], lb.data(), lb.size()));
+                string &t = pieces[p].text;
+                t.reserve((size_t)pieces[p].n * 72);
+                for (uint64_t i = 0; i < pieces[p].n; i++) t.append(lb.data(), (size_t)line(pieces[p].hits[i], lb.data(), lb.size()));
             }
         };
         vector<std::thread> pool;
@@ -484,8 +547,9 @@ static void write_hits(const string &out, const rk_hit *hits, uint64_t n, bool a
         for (auto &th : pool) th.join();
     }
     uint64_t total = 0;
-    for (const string &t : piece) total += t.size();
-    if (total <= max_size) {
+    for (const Piece &pc : pieces) total += pc.text.size();
+    std::atomic<int> failed{0};
+    if (total <= max_size) {  // isMerge, src/dist.cpp:286-310
         cerr << "-----save the output distance file: " << out << endl;
         const char *head = " genome0\tgenome1\tcommon|size0|size1\tjaccard\tmashD\n";
         const int fd = open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -493,16 +557,16 @@ static void write_hits(const string &out, const rk_hit *hits, uint64_t n, bool a
         bool good = pwrite(fd, head, strlen(head), 0) == (ssize_t)strlen(head);
         vector<uint64_t> at(n_pieces);
         uint64_t pos = strlen(head);
-        for (uint64_t p = 0; p < n_pieces; p++) { at[p] = pos; pos += piece[p].size(); }
+        for (uint64_t p = 0; p < n_pieces; p++) { at[p] = pos; pos += pieces[p].text.size(); }
         std::atomic<uint64_t> next{0};
-        std::atomic<int> failed{0};
         auto put = [&]() {
             for (;;) {
                 const uint64_t p = next.fetch_add(1);
                 if (p >= n_pieces) break;
+                const string &t = pieces[p].text;
                 uint64_t done = 0;
-                while (done < piece[p].size()) {
-                    const ssize_t r = pwrite(fd, piece[p].data() + done, piece[p].size() - done, (off_t)(at[p] + done));
+                while (done < t.size()) {
+                    const ssize_t r = pwrite(fd, t.data() + done, t.size() - done, (off_t)(at[p] + done));
                     if (r <= 0) { failed = 1; break; }
                     done += (uint64_t)r;
                 }
@@ -513,36 +577,36 @@ static void write_hits(const string &out, const rk_hit *hits, uint64_t n, bool a
         put();
         for (auto &th : pool) th.join();
         if (close(fd) || failed || !good) die("write error on %s", out.c_str());
-    } else {
-        piece.clear();
-        piece.shrink_to_fit();
+    } else {  // src/dist.cpp:311-335: the sub-files stay, <out>.index maps every row to its sub-file
         const string dir = out + ".dir";
         if (mkdir(dir.c_str(), 0777) && errno != EEXIST) die("cannot create %s", dir.c_str());
         cerr << "-----the output distance file is too big to merge into one single file, saving the result into directory: "
              << dir << endl;
-        FILE *fidx = fopen((out + ".index").c_str(), "w");
-        if (!fidx) die("cannot write %s.index", out.c_str());
-        fprintf(fidx, "genomeName\tdistFileName\n");
-        const uint64_t per_file = 1ULL << 30;
-        uint64_t i = 0;
-        int shard = 0;
-        while (i < n) {
-            const string name = dir + '/' + out + '.' + std::to_string(shard++);
-            FILE *fp = fopen(name.c_str(), "w");
-            if (!fp) die("cannot write %s", name.c_str());
-            uint64_t written = 0;
-            while (i < n && written < per_file) {
-                const uint32_t row = hits[i].row;
-                fprintf(fidx, "%s\t%s\n", rows[row].c_str(), name.c_str());
-                for (; i < n && hits[i].row == row; i++) {
-                    const int l = line(hits[i], buf.data(), buf.size());
-                    fwrite(buf.data(), 1, (size_t)l, fp);
-                    written += (uint64_t)l;
-                }
+        const string index_path = out + ".index";
+        cerr << "-----save the index between genomes and distance sub-files into: " << index_path << endl;
+        auto sub_name = [&](uint64_t p) { return dir + '/' + out + '.' + std::to_string(p); };  // :154 / :543
+        std::atomic<uint64_t> next{0};
+        auto put = [&]() {
+            for (;;) {
+                const uint64_t p = next.fetch_add(1);
+                if (p >= n_pieces) break;
+                FILE *fp = fopen(sub_name(p).c_str(), "w");
+                if (!fp || fwrite(pieces[p].text.data(), 1, pieces[p].text.size(), fp) != pieces[p].text.size()) failed = 1;
+                if (fp && fclose(fp)) failed = 1;
             }
-            fclose(fp);
+        };
+        vector<std::thread> pool;
+        for (int t = 1; t < std::min(8, std::max(1, threads)) && (uint64_t)t < n_pieces; t++) pool.emplace_back(put);
+        put();
+        for (auto &th : pool) th.join();
+        FILE *fidx = fopen(index_path.c_str(), "w");
+        if (!fidx) die("cannot write %s", index_path.c_str());
+        fprintf(fidx, "genomeName\tdistFileName\n");
+        for (uint64_t p = 0; p < n_pieces; p++) {
+            const string name = sub_name(p);
+            for (const uint32_t *r = pieces[p].row_begin; r != pieces[p].row_end; ++r) fprintf(fidx, "%s\t%s\n", rows[*r].c_str(), name.c_str());
         }
-        fclose(fidx);
+        if (fclose(fidx) || failed) die("write error under %s", dir.c_str());
     }
     cerr << "===================time of merge the subFiles into final files is: " << get_sec() - t0 << endl;
 }
@@ -611,6 +675,23 @@ static int cmd_sketch(const Args &a)
     return 0;
 }
 
+// ---- several GPUs in one process (rows are independent: `#pragma omp parallel for` over rows, src/dist.cpp:174,560)
+// One context and one host thread per GPU.  The index is built once on the first GPU and replicated with
+// rk_index_broadcast (every peer pulls it over its own xGMI link); alldist deals blocks of 16 rows round-robin,
+// dist hands every GPU a contiguous block of queries; per-GPU hits go to the writer as they are (no reduction).
+struct GpuSet {
+    vector<std::unique_ptr<AsyncGpu>> gpus;
+    GpuSet(int first_device, int n, bool same_device)
+    {
+        if (n < 1) die("--gpus must be at least 1");
+        for (int g = 0; g < n; g++) gpus.emplace_back(new AsyncGpu(same_device ? first_device : first_device + g));
+    }
+    size_t size() const { return gpus.size(); }
+    Gpu &operator[](size_t g) { return gpus[g]->get(); }
+};
+
+static const int kRowBlock = 16;
+
 static int cmd_alldist(const Args &a)
 {
     if (!a.has("i")) die("alldist needs -i");
@@ -619,30 +700,69 @@ static int cmd_alldist(const Args &a)
     const string out = a.str("o", "result.out");
     const int metric = a.num("M", 0);
     const int threads = a.num("t", (int)std::thread::hardware_concurrency());
-    Gpu gpu(a.num("device", 0));
+    GpuSet set(a.num("device", 0), a.num("gpus", 1), a.has("same-device"));
     const double t0 = get_sec();
     SketchSet s;
     string sketch_path;
-    load_or_sketch(gpu, a.str("i", ""), false, a, threads, s, sketch_path);
+    if (is_sketch_file(a.str("i", ""))) {  // read while the runtime starts
+        string err;
+        sketch_path = a.str("i", "");
+        if (!read_sketches(sketch_path, s, err)) die("readSketches(), %s", err.c_str());
+    }
+    Gpu &gpu = set[0];
+    if (sketch_path.empty()) load_or_sketch(gpu, a.str("i", ""), false, a, threads, s, sketch_path);
+    stamp("sketches read");
     // the .dict/.index pair is (re)written only if missing (src/subCommand.cpp:165-169); the
     // device index is always rebuilt from the sketches: faster than reading the 2^bits array
     const bool missing = !exist_file(sketch_path + ".index") || !exist_file(sketch_path + ".dict");
-    rk_index *idx = build_index(gpu, s, sketch_path, missing);
+    const size_t G = set.size();
+    vector<rk_index *> idx(G, nullptr);
+    idx[0] = build_index(gpu, s, sketch_path, missing);
+    if (G > 1) {
+        vector<rk_ctx *> peers;
+        for (size_t g = 1; g < G; g++) peers.push_back(set[g].ctx);
+        gpu.check(rk_index_broadcast(idx[0], peers.data(), (uint32_t)peers.size(), idx.data() + 1), "rk_index_broadcast");
+    }
+    stamp("index built");
     cerr << "===================time of read sketches and build the index is " << get_sec() - t0 << endl;
     const double t1 = get_sec();
-    rk_dist_opts o{};
-    o.triangle = 1;
-    o.metric = metric;
-    o.kmer_size = 2 * s.info.half_k;
-    o.max_dist = max_dist;
-    rk_hit *hits = nullptr;
-    uint64_t n = 0;
     cerr << "=====total: " << s.size() << endl;
-    gpu.check(rk_dist_rows(gpu.ctx, idx, nullptr, &o, &hits, &n, nullptr), "rk_dist_rows");
+    vector<rk_hit *> hits(G, nullptr);
+    vector<uint64_t> n_hits(G, 0);
+    auto rows_of = [&](size_t g) {
+        rk_dist_opts o{};
+        o.triangle = 1;
+        o.metric = metric;
+        o.kmer_size = 2 * s.info.half_k;
+        o.max_dist = max_dist;
+        if (G > 1) {
+            o.row_first = (uint32_t)g;
+            o.row_step = (uint32_t)G;
+            o.row_block = kRowBlock;
+        }
+        set[g].check(rk_dist_rows(set[g].ctx, idx[g], nullptr, &o, &hits[g], &n_hits[g], nullptr), "rk_dist_rows");
+    };
+    {
+        vector<std::thread> pool;
+        for (size_t g = 1; g < G; g++) pool.emplace_back(rows_of, g);
+        rows_of(0);
+        for (auto &th : pool) th.join();
+    }
+    stamp("distances on the host");
     cerr << "===================time of multiple threads distance computing and save the subFile is: " << get_sec() - t1 << endl;
-    write_hits(out, hits, n, true, s.names, s.names, threads);
-    rk_free_host(hits);
-    rk_index_free(idx);
+    vector<HitPart> parts(G);
+    for (size_t g = 0; g < G; g++) {
+        parts[g].hits = hits[g];
+        parts[g].n = n_hits[g];
+        for (uint32_t r = 0; r < (uint32_t)s.size(); r++)
+            if (G == 1 || (r / kRowBlock) % G == g) parts[g].rows.push_back(r);
+    }
+    write_hits(out, parts, true, s.names, s.names, threads);
+    stamp("text written");
+    for (size_t g = 0; g < G; g++) {
+        rk_free_host(hits[g]);
+        rk_index_free(idx[g]);
+    }
     return 0;
 }
 
@@ -657,34 +777,110 @@ static int cmd_dist(const Args &a)
     const string out = a.str("o", "result.out");
     const int metric = a.num("M", 0);
     const int threads = a.num("t", (int)std::thread::hardware_concurrency());
-    Gpu gpu(a.num("device", 0));
+    GpuSet set(a.num("device", 0), a.num("gpus", 1), a.has("same-device"));
     SketchSet ref, qry;
     string ref_path, qry_path;
-    load_or_sketch(gpu, a.str("r", ""), false, a, threads, ref, ref_path);
+    {   // .sketch inputs are read while the runtime starts
+        string err;
+        if (is_sketch_file(a.str("r", ""))) {
+            ref_path = a.str("r", "");
+            if (!read_sketches(ref_path, ref, err)) die("readSketches(), %s", err.c_str());
+        }
+        if (is_sketch_file(a.str("q", ""))) {
+            qry_path = a.str("q", "");
+            if (!read_sketches(qry_path, qry, err)) die("readSketches(), %s", err.c_str());
+        }
+    }
+    Gpu &gpu = set[0];
+    if (ref_path.empty()) load_or_sketch(gpu, a.str("r", ""), false, a, threads, ref, ref_path);
     cerr << "the ref_sketch size is: " << ref.size() << endl;
-    load_or_sketch(gpu, a.str("q", ""), true, a, threads, qry, qry_path);
+    if (qry_path.empty()) load_or_sketch(gpu, a.str("q", ""), true, a, threads, qry, qry_path);
     if (qry.info.id != ref.info.id)  // src/subCommand.cpp:297-301
         die("command_dist(), the sketch infos between reference and query files are not match\n"
             "try to use the same shuffle file to generate sketches of the reference and query datasets");
     const bool missing = !exist_file(ref_path + ".index") || !exist_file(ref_path + ".dict");
-    rk_index *idx = build_index(gpu, ref, ref_path, missing);
-    rk_sketches *qs = upload(gpu, qry);
+    const size_t G = set.size();
+    vector<rk_index *> idx(G, nullptr);
+    idx[0] = build_index(gpu, ref, ref_path, missing);
+    if (G > 1) {
+        vector<rk_ctx *> peers;
+        for (size_t g = 1; g < G; g++) peers.push_back(set[g].ctx);
+        gpu.check(rk_index_broadcast(idx[0], peers.data(), (uint32_t)peers.size(), idx.data() + 1), "rk_index_broadcast");
+    }
     const double t1 = get_sec();
-    rk_dist_opts o{};
-    o.triangle = 0;
-    o.metric = metric;
-    o.kmer_size = 2 * ref.info.half_k;
-    o.max_dist = max_dist;
-    rk_hit *hits = nullptr;
-    uint64_t n = 0;
     cerr << "=====total: " << qry.size() << endl;
-    gpu.check(rk_dist_rows(gpu.ctx, idx, qs, &o, &hits, &n, nullptr), "rk_dist_rows");
-    if (is_neighbor) rk_topn_rows(hits, &n, (uint64_t)max_neighbor);
+    // contiguous query blocks: GPU g gets queries [q0[g], q0[g+1]) as a sketch set of its own (the host scatters the
+    // queries) and reports rows relative to it
+    const uint32_t Q = (uint32_t)qry.size();
+    vector<uint32_t> q0(G + 1, Q);
+    for (size_t g = 0; g <= G; g++) q0[g] = (uint32_t)((uint64_t)Q * g / G);
+    vector<rk_hit *> hits(G, nullptr);
+    vector<uint64_t> n_hits(G, 0);
+    auto rows_of = [&](size_t g) {
+        Gpu &dev = set[g];
+        const uint32_t nq = q0[g + 1] - q0[g];
+        vector<uint64_t> off(nq + 1);
+        for (uint32_t i = 0; i <= nq; i++) off[i] = qry.off[q0[g] + i] - qry.off[q0[g]];
+        rk_sketches *qs = nullptr;
+        if (qry.wide())
+            dev.check(rk_sketches_from_host64(dev.ctx, qry.hashes64.data() + qry.off[q0[g]], off.data(), nq, &qs), "rk_sketches_from_host64");
+        else
+            dev.check(rk_sketches_from_host(dev.ctx, qry.hashes.data() + qry.off[q0[g]], off.data(), nq, &qs), "rk_sketches_from_host");
+        rk_dist_opts o{};
+        o.triangle = 0;
+        o.metric = metric;
+        o.kmer_size = 2 * ref.info.half_k;
+        o.max_dist = max_dist;
+        dev.check(rk_dist_rows(dev.ctx, idx[g], qs, &o, &hits[g], &n_hits[g], nullptr), "rk_dist_rows");
+        for (uint64_t i = 0; i < n_hits[g]; i++) hits[g][i].row += q0[g];
+        if (is_neighbor) rk_topn_rows(hits[g], &n_hits[g], (uint64_t)max_neighbor);
+        rk_sketches_free(qs);
+    };
+    {
+        vector<std::thread> pool;
+        for (size_t g = 1; g < G; g++) pool.emplace_back(rows_of, g);
+        rows_of(0);
+        for (auto &th : pool) th.join();
+    }
     cerr << "===================time of multiple threads distance computing and save the subFile is: " << get_sec() - t1 << endl;
-    write_hits(out, hits, n, false, qry.names, ref.names, threads);
-    rk_free_host(hits);
-    rk_sketches_free(qs);
-    rk_index_free(idx);
+    vector<HitPart> parts(G);
+    for (size_t g = 0; g < G; g++) {
+        parts[g].hits = hits[g];
+        parts[g].n = n_hits[g];
+        for (uint32_t r = q0[g]; r < q0[g + 1]; r++) parts[g].rows.push_back(r);
+    }
+    write_hits(out, parts, false, qry.names, ref.names, threads);
+    for (size_t g = 0; g < G; g++) {
+        rk_free_host(hits[g]);
+        rk_index_free(idx[g]);
+    }
+    return 0;
+}
+
+// test helper: the text writer alone (no GPU): `_format alldist|dist names.txt hits.bin out pieces threads`;
+// hits.bin = rk_hit records sorted by (row, col), dealt to `pieces` parts in blocks of 16 rows like --gpus does
+static int cmd_format(int argc, char **argv)
+{
+    if (argc != 8) die("_format alldist|dist names.txt hits.bin out parts threads");
+    const bool alldist = string(argv[2]) == "alldist";
+    const vector<string> names = read_list(argv[3]);
+    FILE *fp = fopen(argv[4], "rb");
+    if (!fp) die("cannot open %s", argv[4]);
+    vector<rk_hit> all;
+    rk_hit h;
+    while (fread(&h, sizeof(h), 1, fp) == 1) all.push_back(h);
+    fclose(fp);
+    const size_t G = (size_t)std::max(1, atoi(argv[6]));
+    vector<vector<rk_hit>> per(G);
+    for (const rk_hit &x : all) per[G == 1 ? 0 : (x.row / kRowBlock) % G].push_back(x);
+    vector<HitPart> parts(G);
+    for (size_t g = 0; g < G; g++) {
+        parts[g].hits = per[g].data();
+        parts[g].n = per[g].size();
+        for (uint32_t r = 0; r < (uint32_t)names.size(); r++)
+            if (G == 1 || (r / kRowBlock) % G == g) parts[g].rows.push_back(r);
+    }
+    write_hits(argv[5], parts, alldist, names, names, atoi(argv[7]));
     return 0;
 }
 
@@ -952,8 +1148,8 @@ static int usage()
             "subcommands: shuffle sketch alldist dist union sub convert merge info\n"
             "  shuffle -k K -s S -l L -o out.shuf\n"
             "  sketch  -i genomes.list -o out[.sketch] [-L file.shuf] [-t T] [-q] [--device N]\n"
-            "  alldist -i in.sketch|genomes.list -o out [-D maxDist] [-M 0|1] [-L file.shuf] [--device N]\n"
-            "  dist    -r ref.sketch|list -q qry.sketch|list -o out [-D maxDist] [-N n] [-M 0|1] [--device N]\n"
+            "  alldist -i in.sketch|genomes.list -o out [-D maxDist] [-M 0|1] [-L file.shuf] [--device N] [--gpus G]\n"
+            "  dist    -r ref.sketch|list -q qry.sketch|list -o out [-D maxDist] [-N n] [-M 0|1] [--device N] [--gpus G]\n"
             "  info    -i in.sketch -o out [-F]\n"
             "  merge   -i sketches.list -o out.sketch\n"
             "  union   -i in.sketch -o out.sketch\n"
@@ -964,6 +1160,7 @@ static int usage()
 
 int main(int argc, char **argv)
 {
+    stamp("main");
     if (argc < 2) return usage();
     const string sub = argv[1];
     const std::map<string, string> alias = {
@@ -972,8 +1169,9 @@ int main(int argc, char **argv)
         {"-n", "n"}, {"--leastNumKmer", "n"}, {"-Q", "Q"}, {"--leastQuality", "Q"}, {"-D", "D"}, {"--maxDist", "D"},
         {"-M", "M"}, {"--metric", "M"}, {"-N", "N"}, {"--neighborN_max", "N"}, {"-r", "r"}, {"--reference", "r"},
         {"-F", "F"}, {"--Fined", "F"}, {"--device", "device"}, {"--query", "q"}, {"-q", "q"},
-        {"--reverse", "reverse"}, {"--rs", "rs"}, {"--qs", "qs"}};
+        {"--reverse", "reverse"}, {"--rs", "rs"}, {"--qs", "qs"}, {"--gpus", "gpus"}, {"--same-device", "same-device"}};
     if (sub == "_parse") return cmd_parse(argc, argv);
+    if (sub == "_format") return cmd_format(argc, argv);
     if (sub == "_layout") {  // test helper: the on-disk structs of this tool, in the format of `ref_driver layout`
         printf("sketchInfo_t %zu %zu %zu %zu %zu %zu\n", sizeof(SketchInfo), offsetof(SketchInfo, id), offsetof(SketchInfo, half_k),
                offsetof(SketchInfo, half_subk), offsetof(SketchInfo, drlevel), offsetof(SketchInfo, genomeNumber));
@@ -985,9 +1183,17 @@ int main(int argc, char **argv)
         return 0;
     }
     if (sub == "shuffle") { cerr << "-----run the subcommand: shuffle" << endl; return cmd_shuffle(parse_args(argc, argv, 2, alias, {})); }
-    if (sub == "sketch") { cerr << "-----run the subcommand: sketch" << endl; return cmd_sketch(parse_args(argc, argv, 2, alias, {"q"})); }
-    if (sub == "alldist") { cerr << "-----run the subcommand: alldist" << endl; return cmd_alldist(parse_args(argc, argv, 2, alias, {})); }
-    if (sub == "dist") { cerr << "-----run the subcommand: dist" << endl; return cmd_dist(parse_args(argc, argv, 2, alias, {})); }
+    // the GPU subcommands leave through _exit once their output is on disk (see Gpu::~Gpu)
+    auto leave = [](int rc) -> int {
+        stamp("done");
+        fflush(stdout);
+        fflush(stderr);
+        _exit(rc);
+        return rc;
+    };
+    if (sub == "sketch") { cerr << "-----run the subcommand: sketch" << endl; return leave(cmd_sketch(parse_args(argc, argv, 2, alias, {"q"}))); }
+    if (sub == "alldist") { cerr << "-----run the subcommand: alldist" << endl; return leave(cmd_alldist(parse_args(argc, argv, 2, alias, {"same-device"}))); }
+    if (sub == "dist") { cerr << "-----run the subcommand: dist" << endl; return leave(cmd_dist(parse_args(argc, argv, 2, alias, {"same-device"}))); }
     if (sub == "info") { cerr << "-----run the subcommand: info" << endl; return cmd_info(parse_args(argc, argv, 2, alias, {"F"})); }
     if (sub == "merge") { cerr << "-----run the subcommand: merge" << endl; return cmd_merge(parse_args(argc, argv, 2, alias, {})); }
     if (sub == "convert") { cerr << "-----run the subcommand: convert" << endl; return cmd_convert(parse_args(argc, argv, 2, alias, {"q", "reverse"})); }

@@ -310,3 +310,106 @@ def test_cli_fastq_list_with_quality_and_count_options(tmp_path):
     mixed = tmp_path / "mixed.list"
     mixed.write_text(paths[0] + "\n" + os.path.join(GOLDEN, "sketch", "c0_s0.fa") + "\n")
     assert run(["sketch", "-i", mixed, "-L", shuf, "-o", tmp_path / "m"], check=False).returncode == 1
+
+
+# --------------------------------------------------------------------------- D6: sub-files and their index (CPU)
+def _fake_hits(n_genomes, rng):
+    """a (row, col)-sorted structured hit array with ~60 % of the pairs, some rows without any hit"""
+    from rabbitkssd_amd import capi
+    rows, cols = np.triu_indices(n_genomes, 1)
+    keep = rng.random(len(rows)) < 0.6
+    keep &= ~np.isin(rows, [3, 17, n_genomes - 2])
+    rows, cols = rows[keep], cols[keep]
+    h = np.zeros(len(rows), dtype=capi.HIT_DTYPE)
+    h["row"], h["col"] = rows, cols
+    h["common"] = rng.integers(1, 100, size=len(rows))
+    h["size0"], h["size1"] = 100 + h["row"], 100 + h["col"]
+    h["jorc"] = h["common"] / (h["size0"] + h["size1"] - h["common"])
+    h["dist"] = rng.random(len(rows))
+    return h
+
+
+@pytest.mark.parametrize("parts,threads", [(1, 1), (1, 5), (3, 6), (4, 2)])
+def test_distance_text_single_file_and_subfile_layout(tmp_path, parts, threads):
+    """the writer alone (`rabbit_kssd _format`, no GPU): below the merge limit one file with the reference's header and
+    lines (src/dist.cpp:286-310); above it -- limit injected through RK_DIST_MAX_MERGE_BYTES -- the per-worker sub-files
+    stay under <out>.dir/ and <out>.index lists every row exactly once with its sub-file (:311-335)"""
+    rng = np.random.default_rng(parts * 10 + threads)
+    n = 70
+    names = ["dir/g%02d.fna" % i for i in range(n)]
+    hits = _fake_hits(n, rng)
+    (tmp_path / "names.txt").write_text("".join(x + "\n" for x in names))
+    (tmp_path / "hits.bin").write_bytes(hits.tobytes())
+    want = sorted(ok.alldist_text(names, hits))
+    run(["_format", "alldist", "names.txt", "hits.bin", "one.out", parts, threads], cwd=tmp_path)
+    got = (tmp_path / "one.out").read_text().split("\n")
+    assert got[0] == " genome0\tgenome1\tcommon|size0|size1\tjaccard\tmashD"
+    body = [x + "\n" for x in got[1:] if x]
+    assert sorted(body) == want and not (tmp_path / "one.out.dir").exists()
+    if parts == 1:
+        assert body == ok.alldist_text(names, hits)   # one worker: rows ascending
+    env = dict(os.environ, RK_DIST_MAX_MERGE_BYTES="20000")
+    p = subprocess.run([TOOL, "_format", "alldist", "names.txt", "hits.bin", "big.out", str(parts), str(threads)], cwd=tmp_path,
+                       env=env, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    assert not (tmp_path / "big.out").exists()
+    idx = (tmp_path / "big.out.index").read_text().split("\n")
+    assert idx[0] == "genomeName\tdistFileName" and idx[-1] == ""
+    pairs = [x.split("\t") for x in idx[1:-1]]
+    assert sorted(a for a, _ in pairs) == sorted(names)          # every row once, with or without hits
+    files = []
+    for _, f in pairs:
+        if f not in files:
+            files.append(f)
+    assert all(f.startswith("big.out.dir/big.out.") for f in files)
+    assert sorted(os.listdir(tmp_path / "big.out.dir")) == sorted(os.path.basename(f) for f in
+                                                                 ["big.out.dir/big.out.%d" % t for t in range(len(os.listdir(tmp_path / "big.out.dir")))])
+    where = dict(pairs)
+    cat = []
+    for t in range(len(os.listdir(tmp_path / "big.out.dir"))):
+        f = "big.out.dir/big.out.%d" % t
+        for line in (tmp_path / f).read_text().split("\n"):
+            if line:
+                cat.append(line + "\n")
+                assert where[line.split("\t")[1]] == f            # alldist: the second name is the row genome
+    assert cat == body                                            # sub-files in order == the merged file
+
+
+@pytest.mark.gpu
+def test_cli_multi_gpu_row_shards_reproduce_the_reference_text(tmp_path):
+    """`--gpus N --same-device`: N contexts and host threads in one process (all on the one card of the GPU box), index
+    replicated with rk_index_broadcast, block-cyclic rows (alldist) / contiguous query blocks (dist); the text must be
+    the real reference's, also when the output is kept as sub-files"""
+    d = os.path.join(GOLDEN, "dist")
+    man = json.load(open(os.path.join(d, "manifest.json")))
+    for f in ("ref.sketch", "qry.sketch"):
+        (tmp_path / f).write_bytes(open(os.path.join(d, f), "rb").read())
+    for case in man["cases"]:
+        want = open(os.path.join(d, case["file"])).read().split("\n")[:-1]
+        for gpus in (2, 3):
+            if case["cmd"] == "alldist":
+                run(["alldist", "-i", "ref.sketch", "-D", case["max_dist"], "-M", case["metric"], "-o", "o.txt", "--gpus", gpus,
+                     "--same-device"], cwd=tmp_path)
+                lines = (tmp_path / "o.txt").read_text().split("\n")[:-1]
+                assert sorted(lines[1:]) == want, (case["file"], gpus)
+            else:
+                args = ["dist", "-r", "ref.sketch", "-q", "qry.sketch", "-D", case["max_dist"], "-M", case["metric"], "-o", "o.txt",
+                        "--gpus", gpus, "--same-device"]
+                if case["max_neighbor"]:
+                    args += ["-N", case["max_neighbor"]]
+                run(args, cwd=tmp_path)
+                lines = (tmp_path / "o.txt").read_text().split("\n")[:-1]
+                assert lines[1:] == want, (case["file"], gpus)     # queries in order, -N heap order per query
+    # the same through the sub-file layout (src/dist.cpp:311-335)
+    case = [c for c in man["cases"] if c["cmd"] == "alldist" and c["max_dist"] == 1.5 and c["metric"] == 0][0]
+    want = open(os.path.join(d, case["file"])).read().split("\n")[:-1]
+    env = dict(os.environ, RK_DIST_MAX_MERGE_BYTES="4096")
+    p = subprocess.run([TOOL, "alldist", "-i", "ref.sketch", "-D", "1.5", "-o", "big.txt", "--gpus", "2", "--same-device", "-t", "4"],
+                       cwd=tmp_path, env=env, capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    idx = (tmp_path / "big.txt.index").read_text().split("\n")
+    assert idx[0] == "genomeName\tdistFileName" and len(idx) - 2 == 45      # every reference genome once
+    cat = []
+    for f in sorted(set(x.split("\t")[1] for x in idx[1:-1])):
+        cat += [x for x in (tmp_path / f).read_text().split("\n") if x]
+    assert sorted(cat) == want and not (tmp_path / "big.txt").exists()

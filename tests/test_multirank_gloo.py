@@ -81,3 +81,80 @@ def test_partition_arithmetic():
     # within 3 % at 10k x 8
     p = [shard.rank_pairs(10000, r, 8) for r in range(8)]
     assert max(p) / min(p) < 1.03
+
+
+# --------------------------------------------------------------------------- the same plumbing with the HIP path (GPU)
+def _worker_gpu(rank, port, outdir):
+    """two ranks share cuda:0 (the GPU box has one card): rank 0 builds the index with the HIP kernels, packs it into
+    one blob, the blob travels in ONE broadcast, rank 1 unpacks it, both compute their block-cyclic rows with
+    rk_dist_rows and the hits are concatenated; the union must equal the oracle's unsharded result"""
+    import torch
+    import torch.distributed as dist
+    from rabbitkssd_amd import capi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        torch.cuda.set_device(0)
+        ctx = capi.Context(0)
+        names, h, off = synth.clade_sketches(700, 90, BITS, seed=23)
+        blob = None
+        if rank == 0:
+            index = ctx.index_build(ctx.sketches_from_host(h, off), BITS)
+            dev_blob = torch.empty(index.blob_bytes, dtype=torch.uint8, device="cuda")
+            index.pack_dev(dev_blob.data_ptr(), dev_blob.numel())
+            blob = dev_blob.cpu()
+        blob = shard.broadcast_blob(blob, 0, torch.device("cpu"), dist)
+        if rank != 0:
+            dev_blob = blob.cuda()
+            index = ctx.index_unpack_dev(dev_blob.data_ptr(), dev_blob.numel())
+        mine, _ = ctx.dist_rows(index, None, 1, 0, 20, 0.1, row_first=rank, row_step=WORLD, row_block=shard.ROW_BLOCK)
+        rows = shard.rank_rows(len(names), rank, WORLD)[2]
+        assert set(np.unique(mine["row"])).issubset(set(rows.tolist()))
+        merged = shard.gather_hits(mine, dist, 0)
+        if rank == 0:
+            postings, counts = ok.index_build32(h, off, BITS)
+            want, _ = ok.index_dist32(counts, BITS, postings, np.diff(off).astype(np.uint32), h, off, 1, 0, 20, 0.1)
+            assert len(want) > 1000 and len(merged) == len(want)
+            for f in ("row", "col", "common", "size0", "size1"):
+                assert np.array_equal(merged[f], want[f]), f
+            assert np.max(np.abs(merged["dist"] - want["dist"])) <= 1e-12
+            open(os.path.join(outdir, "ok"), "w").write("%d" % len(merged))
+        del index
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_row_sharding_hip_kernels_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_gpu, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    assert int(open(tmp_path / "ok").read()) > 1000
+
+
+@pytest.mark.gpu
+def test_two_contexts_in_one_process_index_broadcast(tmp_path):
+    """what `rabbit_kssd --gpus N` does: one context per GPU in one process (here both on device 0), the index
+    replicated with rk_index_broadcast, every context computing its rows; dist: contiguous query blocks"""
+    from rabbitkssd_amd import capi
+    a, b = capi.Context(0), capi.Context(0)
+    names, h, off = synth.clade_sketches(500, 60, BITS, seed=29)
+    ia = a.index_build(a.sketches_from_host(h, off), BITS)
+    ib = b.index_broadcast_from(ia)
+    assert (ib.total, ib.distinct, ib.genomes, ib.sum_sq) == (ia.total, ia.distinct, ia.genomes, ia.sum_sq)
+    full, _ = a.dist_rows(ia, None, 1, 0, 20, 0.2)
+    pa, _ = a.dist_rows(ia, None, 1, 0, 20, 0.2, row_first=0, row_step=2, row_block=16)
+    pb, _ = b.dist_rows(ib, None, 1, 0, 20, 0.2, row_first=1, row_step=2, row_block=16)
+    merged = np.concatenate([pa, pb])
+    merged = merged[np.lexsort((merged["col"], merged["row"]))]
+    assert len(full) > 500 and merged.tobytes() == full.tobytes()
+    # ref-vs-query on the copy: queries 250..499 as a block of their own
+    q_off = (off[250:] - off[250]).astype(np.uint64)
+    qs = b.sketches_from_host(h[int(off[250]):], q_off)
+    got, _ = b.dist_rows(ib, qs, 0, 1, 20, 0.3)
+    postings, counts = ok.index_build32(h, off, BITS)
+    want, _ = ok.index_dist32(counts, BITS, postings, np.diff(off).astype(np.uint32), h[int(off[250]):], q_off, 0, 1, 20, 0.3)
+    assert len(want) > 250 and got["row"].tolist() == want["row"].tolist() and got["col"].tolist() == want["col"].tolist()
+    assert np.array_equal(got["common"], want["common"])
