@@ -164,6 +164,7 @@ int rk_ctx_create(int device, rk_ctx **out)
     ctx->sw_dist_cand_cap = env_u32("RK_DIST_CAND_CAP", 0);
     ctx->sw_dist_stage_hits = env_u32("RK_DIST_STAGE_HITS", 0);
     ctx->sw_dist_xcd_rows = env_u32("RK_DIST_XCD_ROWS", 0);
+    ctx->sw_sketch_img = getenv("RK_SKETCH_IMG") ? atoi(getenv("RK_SKETCH_IMG")) != 0 : 1;
     *out = ctx;
     return RK_OK;
 }

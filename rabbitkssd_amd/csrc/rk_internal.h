@@ -39,6 +39,7 @@ struct rk_ctx {
     // developer switches (environment), read once at context creation
     uint32_t sw_dist_threads = 0, sw_dist_rows = 0, sw_dist_pair = 1, sw_dist_pair_minwg = 3, sw_dist_persist = 1;
     uint32_t sw_dist_cand_cap = 0, sw_dist_stage_hits = 0, sw_dist_xcd_rows = 0;
+    int sw_sketch_img = 1;  // RK_SKETCH_IMG=0: the 144 KiB LDS image with the exact table, one workgroup per CU
 };
 constexpr size_t kPinnedBytes = 1 << 16;
 
@@ -93,6 +94,7 @@ struct rk_filter {
     uint32_t *d_bitmap = nullptr; // 64 KiB LDS filter image (bitmap [+ exact key/value table])
     int bitmap_bits = 0;
     bool exact = false;           // image holds the exact table: survivors never leave the CU
+    int img = 0;                  // LDS image variant (rk_sketch.hip Img<>)
     uint32_t n_keys = 0;          // entries with value in [dim_start, dim_end)
 };
 
