@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the outputs of tools/measure_round.sh (merged back under gpurun_out/) into the committed
-summaries under profiles/.      python3 tools/collect_profiles.py r01"""
+summaries under profiles/.      python3 tools/collect_profiles.py r02"""
 import csv
 import glob
 import json
@@ -15,7 +15,7 @@ PROF = os.path.join(ROOT, "profiles")
 
 
 def short_name(name):
-    m = re.search(r"\b(rk_\w+(<[^>]*>)?|k_\w+)", name)
+    m = re.search(r"\b(rk_\w+(<[^>]*>)?|k_\w+(<[^>]*>)?)", name)
     if m:
         return m.group(1)
     m = re.search(r"rocprim::\w+::detail::trampoline_kernel<[^,]*?detail::(\w+)", name) or \
@@ -28,9 +28,32 @@ def short_name(name):
     return re.sub(r"\(.*", "", name).replace("void ", "")
 
 
+def variant_of(dirs, base):
+    """full kernel name (with template arguments) of `base` as the counter passes saw it"""
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                m = re.search(r"\b(%s<[^>]*>)" % base, r["Kernel_Name"])
+                if m:
+                    return m.group(1)
+    return base
+
+
+def summary(dirs):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + dirs, capture_output=True,
+                          text=True, check=True).stdout
+
+
+def values(summ):
+    vals = {}
+    for line in summ.splitlines():
+        k, c, n, v = line.split(",")
+        vals[(k, c)] = float(v)
+    return vals
+
+
 def main(tag):
-    bench = os.path.join(OUT, "bench_r1.json")
-    d = json.load(open(bench))
+    d = json.loads(open(os.path.join(OUT, "bench_r2.json")).read().strip().split("\n")[-1])
     json.dump(d, open(os.path.join(PROF, tag + "_bench.json"), "w"))
     f = glob.glob(os.path.join(OUT, "prof_final", "**", "*kernel_stats.csv"), recursive=True)[0]
     with open(os.path.join(PROF, tag + "_bench_kernel_stats.csv"), "w") as o:
@@ -39,35 +62,43 @@ def main(tag):
         for r in csv.DictReader(open(f)):
             o.write('"%s",%s,%s,%s,%s,%s,%s\n' % (short_name(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                                                   r["Percentage"], r["MinNs"], r["MaxNs"]))
-    dirs = sorted(glob.glob(os.path.join(OUT, "pmcD_*")) + glob.glob(os.path.join(OUT, "pmcSk_*")) +
-                  glob.glob(os.path.join(OUT, "pmcS_*")))
-    summ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + dirs, capture_output=True,
-                          text=True, check=True).stdout
+    groups = {"dist": sorted(glob.glob(os.path.join(OUT, "pmcD_*"))),
+              "rq": sorted(glob.glob(os.path.join(OUT, "pmcQ_*"))),
+              "sketch": sorted(glob.glob(os.path.join(OUT, "pmcSk_*")) + glob.glob(os.path.join(OUT, "pmcS_*"))),
+              "sketch_img0": sorted(glob.glob(os.path.join(OUT, "pmcS0_*")))}
     with open(os.path.join(PROF, tag + "_pmc_summary.csv"), "w") as o:
         o.write("# rocprofv3 --pmc <group> --kernel-include-regex <kernel> --kernel-trace -- python3 tools/prof_driver.py "
-                "{dist 10000 4 | sketch 128 5000000}; one group per pass (tools/pmc_pass.sh, groups in "
-                "tools/pmc_groups_*.txt); mean over launches (tools/pmc_summary.py)\nKernel,Counter,Launches,MeanValue\n")
-        o.write(summ)
-    vals = {}
-    for line in summ.splitlines():
-        k, c, n, v = line.split(",")
-        vals[(k, c)] = float(v)
-    fetch, write = vals[("rk_dist_kernel", "FETCH_SIZE")], vals[("rk_dist_kernel", "WRITE_SIZE")]
-    miss = vals.get(("rk_dist_kernel", "TCC_MISS_sum"), 0.0)
-    sk = vals.get(("rk_sketch_kernel", "FETCH_SIZE"), 0.0)
-    json.dump({
-        "kernel": "rk_dist_kernel", "workload": "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X",
-        "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "hbm_bytes_per_launch": int(round((fetch + write) * 1024)),
-        "correction": "none applied to FETCH_SIZE: this kernel's reads are 8 B/lane gathers and slice loads that leave L2 as "
-                      "64-B requests (TCC_MISS_sum %.2f M x 64 B = %.1f MB vs FETCH_SIZE x 1024 = %.1f MB). The gfx950 x2 "
-                      "correction of MI355X_MICROARCH.md applies to wide 16 B/lane streams only; checked on rk_sketch_kernel in "
-                      "the same session: FETCH_SIZE %.0f KB x 2 x 1024 = %.1f MB for 640.0 MB of sequence bytes read once."
-                      % (miss / 1e6, miss * 64 / 1e6, fetch * 1024 / 1e6, sk, sk * 2 * 1024 / 1e6),
-        "passes": "FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes (FETCH_SIZE takes 3 of the 4 TCC slots), see "
-                  "profiles/%s_pmc_summary.csv" % tag}, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
-    print("value %.4g %s, %.4f ms/step, roofline frac %.3f, traffic %d B" % (
-        d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], int(round((fetch + write) * 1024))))
+                "{dist 10000 4 | dist_rq_dev 100000 1000 3 | sketch 128 5000000}; one group per pass (tools/pmc_pass.sh, "
+                "groups in tools/pmc_groups_*.txt); mean over launches (tools/pmc_summary.py).  Section sketch_img0 = the "
+                "144 KiB LDS image (RK_SKETCH_IMG=0, one workgroup per CU) for comparison with the default 64 KiB image\n"
+                "Section,Kernel,Counter,Launches,MeanValue\n")
+        for sec, dirs in groups.items():
+            for line in summary(dirs).splitlines():
+                o.write(sec + "," + line + "\n")
+    # counter-measured HBM bytes per launch, keyed by the exact kernel variant (bench.py refuses a mismatch)
+    def traffic(dirs, base, fname, workload, wide_stream):
+        v = values(summary(dirs))
+        fetch, write = v.get((base, "FETCH_SIZE")), v.get((base, "WRITE_SIZE"))
+        if fetch is None or write is None:
+            print("no FETCH_SIZE/WRITE_SIZE for", base)
+            return None
+        miss = v.get((base, "TCC_MISS_sum"), 0.0)
+        # gfx950: FETCH_SIZE reports half the bytes of a wide coalesced 16 B/lane stream (MI355X_MICROARCH.md, HBM);
+        # gathers of 4-8 B/lane leave L2 as 64-B requests and need no correction (checked against TCC_MISS x 64 B)
+        factor = 2.0 if wide_stream else 1.0
+        hbm = int(round((fetch * factor + write) * 1024))
+        json.dump({"kernel": variant_of(dirs, base), "workload": workload, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+                   "fetch_correction": factor, "TCC_MISS_sum": miss, "TCC_MISS_x64B": miss * 64,
+                   "hbm_bytes_per_launch": hbm,
+                   "passes": "FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, see profiles/%s_pmc_summary.csv" % tag},
+                  open(os.path.join(PROF, fname), "w"), indent=1)
+        return hbm
+    t_d = traffic(groups["dist"], "rk_dist_kernel", "pmc_traffic.json", "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X", False)
+    t_q = traffic(groups["rq"], "rk_distq_kernel", "pmc_traffic_rq.json", "dist 100,000 refs x 1,000 queries (tools/prof_driver.py dist_rq_dev), MI355X", False)
+    t_s = traffic(groups["sketch"], "rk_sketch_kernel", "pmc_traffic_sketch.json", "sketch 128 x 5 Mb (tools/prof_driver.py sketch 128 5000000), MI355X", True)
+    print("value %.4g %s, %.4f ms/step, contract frac %.3f; traffic dist %s rq %s sketch %s B/launch" % (
+        d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], t_d, t_q, t_s))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
