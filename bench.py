@@ -27,14 +27,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the he
 """
 import argparse
 import json
-import math
 import os
 import re
 import subprocess
 import sys
 import tempfile
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -311,6 +309,8 @@ def sketch_block(env, n_genomes, length, steps=5):
     dt = (time.time() - t0) / steps
     ctx.set_timing(False)
     kernel_ms = sum(kms) / len(kms)
+    # L3K10 variant of the scan kernel: the default 64 KiB LDS image, or the 144 KiB one behind RK_SKETCH_IMG=0
+    sk_kernel = "rk_sketch_kernel<20, 8, true, 0>" if os.environ.get("RK_SKETCH_IMG") == "0" else "rk_sketch_kernel<20, 8, false, 1>"
     b_alg = windows * 1.001  # 1 B per k-mer window + 4 B per emitted hash
     achieved = b_alg / (kernel_ms * 1e-3) / 1e9
     out = {"kmers_per_s": windows / dt, "genomes": n_genomes, "genome_length": length, "kmers": int(windows),
@@ -318,9 +318,11 @@ def sketch_block(env, n_genomes, length, steps=5):
            "pass": "scan kernel + per-genome LDS dedup + CSR placement, one upload and one read-back per batch; synthetic "
                    "uniform ACGT resident in HBM; 1.001 B/k-mer -> %.1f GB/s for the whole pass" % (b_alg / dt / 1e9),
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rk_sketch_kernel<20, 8, true>",
-                        "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg}}
-    pmc = load_pmc("rk_sketch_kernel<20, 8, true>", "pmc_traffic_sketch.json")
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": sk_kernel,
+                        "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg,
+                        "limiter": "VALU issue (integer): 76 % of the SIMD cycles issue vector instructions at 8 waves per SIMD "
+                                   "(profiles/r02_pmc_summary.csv, DESIGN.md 4.1)"}}
+    pmc = load_pmc(sk_kernel, "pmc_traffic_sketch.json")
     if pmc:
         out["roofline"]["traffic"] = pmc
         out["roofline"]["hbm_frac"] = pmc / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -4,9 +4,9 @@
 Inputs are synthetic (rabbitkssd_amd.synth, fixed seeds).  Expected outputs come from
   * the REAL reference objects (oracle/_ref/ref_driver = /root/reference/src/{dist,common,
     shuffle}.cpp compiled unmodified): params.txt, shuf.json, dist/*.ref.txt
-  * the C restatement (oracle/) for what the real reference cannot produce here because
-    sketch.cpp is unbuildable (RabbitFX submodule absent): sketch/expected.json.  Those
-    are marked "pinned": false.
+  * the C restatement (oracle/) for sketch/expected.json (marked "pinned": false: this script does not run
+    the reference's sketch code).  The same input files are part of tests/golden/sketch_ref, whose expected sets
+    come from the reference's own sketchFastaFile (tests/golden/make_sketch_golden.py) and are identical.
 The script refuses to write a dist fixture when the restatement and the real reference
 disagree, so a committed fixture is always one both agree on.
 """

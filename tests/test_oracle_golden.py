@@ -2,7 +2,8 @@
 
 params.txt, shuf.json and dist/*.ref.txt were produced by the REAL reference objects
 (/root/reference/src/{common,shuffle,dist}.cpp via oracle/_ref/ref_driver); see
-tests/golden/make_golden.py.  sketch/expected.json is unpinned (sketch.cpp unbuildable)."""
+tests/golden/make_golden.py.  sketch/expected.json comes from the restatement; the reference-produced sketch fixtures are
+tests/golden/sketch_ref (tests/test_sketch_ref_golden.py)."""
 import hashlib
 import json
 import os
@@ -141,7 +142,8 @@ def test_record_reader_restatement_matches_the_real_kseq():
 
 
 def test_sketch_fixture_hash_sets():
-    """unpinned fixture: C restatement == expected.json (itself cross-checked by numpy)."""
+    """C restatement == expected.json (cross-checked by numpy; the same files, produced by the reference itself, are in
+    tests/golden/sketch_ref)."""
     d = os.path.join(GOLDEN, "sketch")
     exp = json.load(open(os.path.join(d, "expected.json")))
     param = ok.init_param(exp["half_k"], exp["half_subk"], exp["drlevel"])
