@@ -75,8 +75,11 @@ __global__ void k_scatter_heads(const K *keys, const uint32_t *gidx, uint64_t n,
     }
 }
 
-// class of a source element's "later genomes" slice
+// class of a source element's "later genomes" slice, carried by the slice itself so that no separate (byte-granular,
+// randomly scattered) class array is needed: (x, y) with x < y = open, x == y = empty, stored reversed (y, x) = covered
 enum : uint8_t { kEmpty = 0, kOpen = 1, kCovered = 2 };
+__device__ inline uint8_t slice_class(uint2 r) { return r.x == r.y ? kEmpty : (r.x < r.y ? kOpen : kCovered); }
+__device__ inline uint2 slice_range(uint2 r) { return r.x <= r.y ? r : make_uint2(r.y, r.x); }
 
 // postings[k] = genome of the k-th sorted element; selfrange of its source element = (k+1, end of the group): the
 // sort is stable and source elements are genome-major, so the rest of the group holds the later genomes.
@@ -87,7 +90,7 @@ enum : uint8_t { kEmpty = 0, kOpen = 1, kCovered = 2 };
 template <bool CHECK_DUPS>
 __global__ void k_postings_selfrange(const uint32_t *sorted_e, const uint32_t *gidx, const uint32_t *upos,
                                      const uint32_t *gid, uint64_t n, uint32_t *postings, uint2 *self_raw,
-                                     uint8_t *cls, BuildResult *res)
+                                     BuildResult *res)
 {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -96,17 +99,16 @@ __global__ void k_postings_selfrange(const uint32_t *sorted_e, const uint32_t *g
     postings[k] = me;
     const uint32_t g = gidx[k] - 1;
     const uint32_t end = upos[g + 1];
-    self_raw[e] = make_uint2((uint32_t)k + 1, end);
     const bool has_prev = k > upos[g];
     uint32_t prev = 0xFFFFFFFFu;
     if (has_prev && (CHECK_DUPS || (me & 1u))) prev = gid[sorted_e[k - 1]];
     if (CHECK_DUPS && has_prev && prev == me) res->dups = 1;
-    const bool nonempty = (uint32_t)k + 1 < end;
-    cls[e] = !nonempty ? kEmpty : (((me & 1u) && has_prev && prev == me - 1) ? kCovered : kOpen);
+    const bool covered = (me & 1u) && has_prev && prev == me - 1 && (uint32_t)k + 1 < end;
+    self_raw[e] = covered ? make_uint2(end, (uint32_t)k + 1) : make_uint2((uint32_t)k + 1, end);
 }
 
 // one wave per genome: number of open / covered slices of its row
-__global__ void k_row_counts(const uint64_t *off, uint32_t n_genomes, const uint8_t *cls, uint32_t *n_open, uint32_t *n_cov)
+__global__ void k_row_counts(const uint64_t *off, uint32_t n_genomes, const uint2 *self_raw, uint32_t *n_open, uint32_t *n_cov)
 {
     const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= n_genomes) return;
@@ -114,7 +116,7 @@ __global__ void k_row_counts(const uint64_t *off, uint32_t n_genomes, const uint
     const uint64_t e1 = off[g + 1];
     uint32_t no = 0, nc = 0;
     for (uint64_t e = off[g] + lane; e < e1; e += 64) {
-        const uint8_t c = cls[e];
+        const uint8_t c = slice_class(self_raw[e]);
         no += c == kOpen;
         nc += c == kCovered;
     }
@@ -182,7 +184,7 @@ __global__ void k_row_scan(const uint32_t *n_open, const uint32_t *n_cov, uint32
 
 // one wave per genome: open slices to the front of the row, covered ones behind them, empty ones dropped; the order
 // inside each class is the source order (ballot ranks)
-__global__ void k_row_place(const uint64_t *off, uint32_t n_genomes, const uint8_t *cls, const uint2 *self_raw,
+__global__ void k_row_place(const uint64_t *off, uint32_t n_genomes, const uint2 *self_raw,
                             const uint64_t *self_off, const uint64_t *self_split, uint2 *out)
 {
     const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -193,8 +195,9 @@ __global__ void k_row_place(const uint64_t *off, uint32_t n_genomes, const uint8
     const uint64_t e0 = off[g], e1 = off[g + 1];
     for (uint64_t base = e0; base < e1; base += 64) {
         const uint64_t e = base + lane;
-        const uint8_t c = e < e1 ? cls[e] : (uint8_t)kEmpty;
-        const uint2 r = c != kEmpty ? self_raw[e] : make_uint2(0, 0);
+        const uint2 raw = e < e1 ? self_raw[e] : make_uint2(0, 0);
+        const uint8_t c = slice_class(raw);
+        const uint2 r = slice_range(raw);
         const unsigned long long mo = __ballot(c == kOpen), mc = __ballot(c == kCovered);
         if (c == kOpen) out[at_open + __popcll(mo & lt)] = r;
         if (c == kCovered) out[at_cov + __popcll(mc & lt)] = r;
@@ -409,14 +412,12 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     if (H) {
         DevBuf<uint32_t> iota(ctx), keys_sorted(ctx), sorted_e(ctx), flags(ctx), gid(ctx), n_open(ctx), n_cov(ctx);
         DevBuf<uint64_t> keys_sorted64(ctx);
-        DevBuf<uint8_t> cls(ctx);
         DevBuf<uint2> self_raw(ctx);
         DevBuf<char> tmp(ctx);
         RK_HIP(ctx, iota.alloc(H));
         RK_HIP(ctx, sorted_e.alloc(H));
         RK_HIP(ctx, flags.alloc(H));
         RK_HIP(ctx, gid.alloc(H));
-        RK_HIP(ctx, cls.alloc(H));
         RK_HIP(ctx, self_raw.alloc(H));
         RK_HIP(ctx, n_open.alloc((size_t)N + 1));
         RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
@@ -454,14 +455,14 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
                                idx->d_uhash, idx->d_upos, res.p);
         if (s->is_set)
             hipLaunchKernelGGL(k_postings_selfrange<false>, dim3(blocks_for(H)), dim3(kThreads), 0, st, sorted_e.p, gidx,
-                               idx->d_upos, gid.p, H, idx->d_postings, self_raw.p, cls.p, res.p);
+                               idx->d_upos, gid.p, H, idx->d_postings, self_raw.p, res.p);
         else
             hipLaunchKernelGGL(k_postings_selfrange<true>, dim3(blocks_for(H)), dim3(kThreads), 0, st, sorted_e.p, gidx,
-                               idx->d_upos, gid.p, H, idx->d_postings, self_raw.p, cls.p, res.p);
+                               idx->d_upos, gid.p, H, idx->d_postings, self_raw.p, res.p);
         // drop the empty slices (26 % of the elements at 10,000 genomes), covered slices last in their row
-        hipLaunchKernelGGL(k_row_counts, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_off, N, cls.p, n_open.p, n_cov.p);
+        hipLaunchKernelGGL(k_row_counts, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_off, N, self_raw.p, n_open.p, n_cov.p);
         hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, res.p);
-        hipLaunchKernelGGL(k_row_place, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_off, N, cls.p, self_raw.p,
+        hipLaunchKernelGGL(k_row_place, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_off, N, self_raw.p,
                            idx->d_self_off, idx->d_self_split, idx->d_selfrange);
         RK_HIP(ctx, hipGetLastError());
         RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));  // the one synchronisation of the build

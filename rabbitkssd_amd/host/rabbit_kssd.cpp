@@ -1083,7 +1083,14 @@ static int cmd_sub(const Args &a)
             out.off.push_back(out.hashes64.size());
         }
     } else {
-        vector<uint64_t> dict(((size_t)1 << 32) / 64, 0);  // one bit per hash value, MSB first (:575-583)
+        // one bit per hash value, MSB first (:575-583); sized by the sketches' hash space (2^28 values = 32 MiB of bits
+        // at L3K10), not by the 2^32 of the type
+        const int bits = std::min(32, std::max(1, 4 * (qry.info.half_k - qry.info.drlevel)));
+        uint32_t top = 0;
+        for (uint32_t h : ref.hashes) top = std::max(top, h);
+        for (uint32_t h : qry.hashes) top = std::max(top, h);
+        const uint64_t space = std::max<uint64_t>((uint64_t)1 << bits, (uint64_t)top + 1);  // a foreign file may exceed its declared space
+        vector<uint64_t> dict((size_t)((space + 63) / 64), 0);
         for (uint32_t h : ref.hashes) dict[h / 64] |= 0x8000000000000000ULL >> (h % 64);
         for (size_t i = 0; i < qry.size(); i++) {
             for (uint64_t e = qry.off[i]; e < qry.off[i + 1]; e++) {

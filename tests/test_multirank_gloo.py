@@ -1,7 +1,7 @@
-"""world_size-2 test of the N>1 path on CPU (gloo): interleaved row sharding, one broadcast of
-the reference index, concatenation of per-rank hits.  The per-rank compute is done by the
-oracle here (no GPU in this tier); on the GPU box bench.py drives the same plumbing over
-RCCL with the HIP kernels."""
+"""world_size-2 tests of the N>1 path (gloo): block-cyclic row sharding, one broadcast of the reference index,
+concatenation of per-rank hits.  CPU tier: the per-rank compute is the oracle's (partition arithmetic and the
+broadcast helper).  GPU tier (-m gpu): the same two ranks compute with the HIP kernels on the box's one card, and two
+library contexts in one process exchange the index through rk_index_broadcast (what `rabbit_kssd --gpus N` does)."""
 import os
 import socket
 
