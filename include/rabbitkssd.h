@@ -82,6 +82,9 @@ void rk_ctx_destroy(rk_ctx *ctx);
  * again (steady-state calls allocate nothing: hipMalloc/hipFree cost 50-300 us each and hipFree synchronises the
  * device); rk_ctx_trim returns the cached blocks to the driver. */
 void rk_ctx_trim(rk_ctx *ctx);
+/* out[0] bytes obtained from the driver, out[1] of which idle in the cache, out[2] hipMalloc calls, out[3] hipFree
+ * calls made by the context's allocator so far (a steady-state call sequence leaves out[2] and out[3] unchanged). */
+void rk_ctx_pool_stats(rk_ctx *ctx, uint64_t out[4]);
 /* Measurement: with timing on, a pass brackets its dominant kernel with HIP events on the stream it is launched on;
  * rk_ctx_last_ms(ctx, RK_MS_SKETCH_KERNEL) then returns that kernel's duration in milliseconds for the last
  * rk_sketch_* call.  (The distance entry points launch one kernel per call: bracket rk_dist_rows_dev yourself.) */

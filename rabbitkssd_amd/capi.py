@@ -16,7 +16,7 @@ HIT_DTYPE = np.dtype([("row", "<u4"), ("col", "<u4"), ("common", "<i4"), ("size0
                       ("size1", "<i4"), ("pad", "<i4"), ("jorc", "<f8"), ("dist", "<f8")])
 
 EXPORTS = [
-    "rk_device_count", "rk_ctx_create", "rk_ctx_destroy", "rk_ctx_trim", "rk_ctx_set_timing", "rk_ctx_last_ms", "rk_dist_kernel_name", "rk_last_error", "rk_version",
+    "rk_device_count", "rk_ctx_create", "rk_ctx_destroy", "rk_ctx_trim", "rk_ctx_pool_stats", "rk_ctx_set_timing", "rk_ctx_last_ms", "rk_dist_kernel_name", "rk_last_error", "rk_version",
     "rk_free_host", "rk_pinned_alloc", "rk_pinned_free", "rk_dev_alloc", "rk_dev_free", "rk_stream_create",
     "rk_stream_destroy", "rk_stream_sync", "rk_upload_async", "rk_params_init", "rk_hash_bits", "rk_filter_create", "rk_filter_free",
     "rk_sketch_batch", "rk_sketch_batch_ex", "rk_sketch_packed_dev", "rk_sketch_packed_dev_ex", "rk_pack_layout", "rk_pack_genomes",
@@ -67,6 +67,7 @@ def lib():
         L.rk_free_host.argtypes = [C.c_void_p]
         L.rk_ctx_destroy.argtypes = [C.c_void_p]
         L.rk_ctx_trim.argtypes = [C.c_void_p]
+        L.rk_ctx_pool_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.rk_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.rk_ctx_last_ms.argtypes = [C.c_void_p, C.c_int]
         L.rk_ctx_last_ms.restype = C.c_double
@@ -134,6 +135,12 @@ class Context:
         self.check(lib().rk_dist_kernel_name(self._h, index._h, queries._h if queries is not None else None, C.byref(opts),
                                              buf, C.c_size_t(128)))
         return buf.value.decode()
+
+    def pool_stats(self):
+        """(bytes from the driver, idle bytes in the cache, hipMalloc calls, hipFree calls) of the context's allocator"""
+        out = (C.c_uint64 * 4)()
+        lib().rk_ctx_pool_stats(self._h, out)
+        return tuple(int(x) for x in out)
 
     def trim(self):
         """returns the device memory cached by the context's allocator to the driver"""

@@ -33,6 +33,7 @@ void *rk_pool_alloc(rk_ctx *ctx, size_t bytes)
         // best fit, but never hand a block far bigger than the request (it would be missing when its own size is asked for)
         if (it != ctx->free_blocks.end() && (it->first <= 2 * want || it->first <= (1u << 16))) {
             void *p = it->second;
+            ctx->cached_bytes -= it->first;
             ctx->free_blocks.erase(it);
             return p;
         }
@@ -49,6 +50,7 @@ void *rk_pool_alloc(rk_ctx *ctx, size_t bytes)
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->live[p] = want;
     ctx->pool_bytes += want;
+    ctx->driver_allocs++;
     return p;
 }
 
@@ -61,6 +63,14 @@ void rk_pool_free(rk_ctx *ctx, void *p)
         (void)hipFree(p);
         return;
     }
+    if (ctx->cached_bytes + it->second > ctx->cache_limit) {  // the cache is full: back to the driver
+        ctx->pool_bytes -= it->second;
+        ctx->live.erase(it);
+        ctx->driver_frees++;
+        (void)hipFree(p);
+        return;
+    }
+    ctx->cached_bytes += it->second;
     ctx->free_blocks.emplace(it->second, p);
 }
 
@@ -156,6 +166,7 @@ int rk_ctx_create(int device, rk_ctx **out)
         rk_ctx_destroy(ctx);
         return RK_ERR_HIP;
     }
+    ctx->cache_limit = (size_t)env_u32("RK_POOL_LIMIT_MB", 32768) << 20;
     ctx->sw_dist_threads = env_u32("RK_DIST_THREADS", 0);
     ctx->sw_dist_rows = env_u32("RK_DIST_ROWS", 0);
     ctx->sw_dist_pair = env_u32("RK_DIST_PAIR", 1);
@@ -177,6 +188,16 @@ void rk_ctx_set_timing(rk_ctx *ctx, int on)
     ctx->timing = on != 0;
 }
 
+void rk_ctx_pool_stats(rk_ctx *ctx, uint64_t out[4])
+{
+    if (!ctx || !out) return;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    out[0] = ctx->pool_bytes;
+    out[1] = ctx->cached_bytes;
+    out[2] = ctx->driver_allocs;
+    out[3] = ctx->driver_frees;
+}
+
 double rk_ctx_last_ms(const rk_ctx *ctx, int which) { return ctx && which >= 0 && which < 4 ? ctx->last_ms[which] : 0.0; }
 
 void rk_ctx_trim(rk_ctx *ctx)
@@ -187,9 +208,11 @@ void rk_ctx_trim(rk_ctx *ctx)
     for (auto &b : ctx->free_blocks) {
         ctx->live.erase(b.second);
         ctx->pool_bytes -= b.first;
+        ctx->driver_frees++;
         (void)hipFree(b.second);
     }
     ctx->free_blocks.clear();
+    ctx->cached_bytes = 0;
 }
 
 void rk_ctx_destroy(rk_ctx *ctx)

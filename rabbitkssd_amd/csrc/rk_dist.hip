@@ -56,6 +56,7 @@ struct DistArgs {
     int triangle, metric, kmer_size, dense_mode;
     double max_dist;
     double min_jorc;            // conservative lower bound on jaccard/containment of a reportable pair
+    uint32_t min_ref_size;      // smallest non-empty reference sketch (lower bound of a containment denominator)
     rk_hit *hits;
     unsigned long long cap;
     unsigned long long *n_hits;
@@ -286,6 +287,14 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         };
         const uint32_t jbeg_a = a.triangle ? max(col0, row_a + 1) : col0;
         const uint32_t cells_end = has_b ? row_b_cell + ncol : ncol;   // cells in use
+        // row-level reject while scanning: a reportable cell needs common >= min_jorc * denominator, and the
+        // denominator is at least the row's sketch size (jaccard) / min(row, smallest non-empty sketch) (containment):
+        // the 1-2 chance hashes shared with unrelated genomes never enter the cell list
+        auto floor_common = [&](int qsize) -> uint32_t {
+            const uint32_t lb = a.metric ? min((uint32_t)qsize, a.min_ref_size) : (uint32_t)qsize;
+            return max(1u, (uint32_t)floor(a.min_jorc * (double)lb));
+        };
+        const uint32_t minc_a = floor_common(qsize_a), minc_b = has_b ? floor_common(qsize_b) : 1u;
 
         if (!a.dense_mode) {
             // Sparse mode: the threshold excludes distance 1.0 (== common 0), so only cells
@@ -300,20 +309,22 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                 const uint4 v = c4[q];
                 if ((v.x | v.y | v.z | v.w) == 0) continue;
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                const uint32_t cq = q * 4 * kPerWord;
+                const uint32_t minc = PAIR && cq >= row_b_cell ? minc_b : minc_a;  // a quad lies in one row
                 uint32_t n = 0;
 #pragma unroll
                 for (int wi = 0; wi < 4; wi++) {
-                    if (U16) n += ((w[wi] & 0xFFFFu) != 0) + ((w[wi] >> 16) != 0);
-                    else n += w[wi] != 0;
+                    if (U16) n += ((w[wi] & 0xFFFFu) >= minc) + ((w[wi] >> 16) >= minc);
+                    else n += w[wi] >= minc;
                 }
+                if (!n) continue;
                 uint32_t at = atomicAdd(&s_total, n);
-                const uint32_t cq = q * 4 * kPerWord;
 #pragma unroll
                 for (int wi = 0; wi < 4; wi++) {
 #pragma unroll
                     for (uint32_t h = 0; h < kPerWord; h++) {
                         const uint32_t common = U16 ? (w[wi] >> (16 * h)) & 0xFFFFu : w[wi];
-                        if (common) {
+                        if (common >= minc) {
                             if (at < kCandCap) cand[at] = make_uint2(cq + wi * kPerWord + h, common);
                             at++;
                         }
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                 // more sharing columns than the list holds: walk the rows, one cell per lane
                 for (uint32_t c = (jbeg_a - col0) + tid; c < cells_end; c += kDistThreads) {
                     const uint32_t common = cell(c);
-                    if (common) eval_cell(c, common);
+                    if (common >= (PAIR && c >= row_b_cell ? minc_b : minc_a)) eval_cell(c, common);
                 }
                 __syncthreads();  // the rows are zeroed next
             }
@@ -671,6 +682,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     // distance < D  <=>  jaccard > t/(2-t), t = exp(-k D)   (containment: c > t); 1e-6 relative slack
     // keeps the reject conservative, the exact formula still decides.  Disabled in dense mode.
     a.min_jorc = 0.0;
+    a.min_ref_size = (uint32_t)std::min<uint64_t>(idx->min_ref_size, 0xFFFFFFFFu);
     if (!p.dense_mode && o->max_dist > 0.0) {
         const double t = exp(-(double)o->kmer_size * o->max_dist);
         a.min_jorc = (a.metric ? t : t / (2.0 - t)) * (1.0 - 1e-6);

@@ -56,6 +56,7 @@ struct DistQArgs {
     uint32_t cand_cap, stage_hits;
     int32_t triangle, metric, kmer_size, dense_mode;
     double max_dist, min_jorc;
+    uint32_t min_ref_size;       // smallest non-empty reference sketch
     rk_hit *hits;
     unsigned long long cap;
     unsigned long long *n_hits;
@@ -204,14 +205,17 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
                     pos[i] = lo[i];
                 }
             }
+            // posting ranges of the present hashes only (masked lanes issue no request); all of a batch are requested
+            // before the first is queued
+            PostingPair r[kLookups];
+#pragma unroll
+            for (uint32_t i = 0; i < kLookups; i++)
+                if (present[i]) r[i] = *reinterpret_cast<const PostingPair *>(a.upos + pos[i]);
 #pragma unroll
             for (uint32_t i = 0; i < kLookups; i++) {
                 const unsigned long long m = __ballot(present[i]);
                 if (m) {  // uniform
-                    if (present[i]) {
-                        const PostingPair r = *reinterpret_cast<const PostingPair *>(a.upos + pos[i]);
-                        queue[qn + __popcll(m & lt_mask)] = make_uint2(r.x, r.y);
-                    }
+                    if (present[i]) queue[qn + __popcll(m & lt_mask)] = make_uint2(r[i].x, r[i].y);
                     qn += __popcll(m);
                     if (qn >= 64) walk();
                 }
@@ -227,6 +231,13 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
         }
         const int qsize = (int)(qe - qb);
         const uint32_t jbeg = a.triangle ? max(col0, row + 1) : col0;  // :207 / :600
+        // Row-level reject, applied while the row is scanned: a reportable cell needs common >= min_jorc * denominator
+        // (the exact-safe pre-filter below) and the denominator is at least the query's size (jaccard: |q| + |r| - common
+        // with |r| >= common) or min(|q|, smallest non-empty reference) (containment).  A 45,776-hash query shares 1-2
+        // chance hashes with ~15,000 of 100,000 unrelated references: they never enter the cell list, and their
+        // reference sizes are never fetched.
+        const uint32_t lb = a.metric ? min((uint32_t)qsize, a.min_ref_size) : (uint32_t)qsize;
+        const uint32_t min_common = max(1u, (uint32_t)floor(a.min_jorc * (double)lb));
         auto evaluate = [&](uint32_t j, int common, rk_hit &hrec) -> bool {
             const int rs = (int)a.ref_sizes[j];
             const int size0 = a.triangle ? qsize : rs;  // :215-216 / :607-608
@@ -268,7 +279,8 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
 #pragma unroll
                 for (int wi = 0; wi < 4; wi++)
 #pragma unroll
-                    for (uint32_t s = 0; s < kPerWord; s++) n += ((w[wi] >> (s * CBITS % 32)) & kCellMask) != 0;
+                    for (uint32_t s = 0; s < kPerWord; s++) n += ((w[wi] >> (s * CBITS % 32)) & kCellMask) >= min_common;
+                if (!n) continue;
                 uint32_t at = atomicAdd(&s_total, n);
                 const uint32_t cq = q * 4 * kPerWord;
 #pragma unroll
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
 #pragma unroll
                     for (uint32_t s = 0; s < kPerWord; s++) {
                         const uint32_t common = (w[wi] >> (s * CBITS % 32)) & kCellMask;
-                        if (common) {
+                        if (common >= min_common) {
                             if (at < a.cand_cap) cand[at] = make_uint2(cq + wi * kPerWord + s, common);
                             at++;
                         }
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
                 for (uint32_t c = (jbeg - col0) + tid; c < ncol; c += nthreads) {
                     const uint32_t common = cell(c);
                     rk_hit hrec;
-                    if (common && evaluate(col0 + c, (int)common, hrec)) stage_hit(hrec);
+                    if (common >= min_common && evaluate(col0 + c, (int)common, hrec)) stage_hit(hrec);
                 }
             }
         } else {
@@ -492,6 +504,7 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     a.dense_mode = rk_dense_mode(o) ? 1 : 0;
     a.max_dist = o->max_dist;
     a.min_jorc = 0.0;
+    a.min_ref_size = (uint32_t)std::min<uint64_t>(idx->min_ref_size, 0xFFFFFFFFu);
     if (!a.dense_mode && o->max_dist > 0.0) {
         // distance < D  <=>  jaccard > t/(2-t), t = exp(-k D)  (containment: c > t); 1e-6 relative slack keeps the
         // reject conservative, the exact formula still decides

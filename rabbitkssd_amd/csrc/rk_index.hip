@@ -390,6 +390,10 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     idx->hash_bits = hash_bits;
     idx->wide = s->wide;
     idx->max_src_size = idx->max_ref_size = s->max_size;
+    for (uint32_t g = 0; g < s->n; g++) {
+        const uint64_t sz = s->h_off[g + 1] - s->h_off[g];
+        if (sz && (!idx->min_ref_size || sz < idx->min_ref_size)) idx->min_ref_size = sz;
+    }
     struct Guard { rk_index *p; ~Guard() { if (p) rk_index_free(p); } } guard{idx};
 
     // distinct hashes: at most H, at most the hash space
@@ -498,7 +502,10 @@ int rk_index_import(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const
     idx->n_ref = n_ref;
     idx->H = total;
     idx->hash_bits = hash_bits;
-    for (uint32_t g = 0; g < n_ref; g++) idx->max_ref_size = std::max<uint64_t>(idx->max_ref_size, ref_sizes[g]);
+    for (uint32_t g = 0; g < n_ref; g++) {
+        idx->max_ref_size = std::max<uint64_t>(idx->max_ref_size, ref_sizes[g]);
+        if (ref_sizes[g] && (!idx->min_ref_size || ref_sizes[g] < idx->min_ref_size)) idx->min_ref_size = ref_sizes[g];
+    }
     struct Guard { rk_index *p; ~Guard() { if (p) rk_index_free(p); } } guard{idx};
 
     RK_TRY(pool_array(ctx, &idx->d_sizes, (size_t)n_ref + 1));
@@ -578,12 +585,12 @@ int rk_index_export(const rk_index *idx, uint32_t *postings, uint32_t *counts)
 namespace {
 struct BlobHeader {
     uint64_t magic, bytes;
-    uint64_t H, U, max_src_size, max_ref_size, n_self;
+    uint64_t H, U, max_src_size, max_ref_size, min_ref_size, n_self;
     uint32_t n_ref, has_self, ref_sets;
     int32_t hash_bits, wide;
     uint64_t off_postings, off_uhash, off_upos, off_sizes, off_self, off_selfoff, off_src, off_split;
 };
-constexpr uint64_t kBlobMagic = 0x33584449444b5352ULL;  // "RSKDIDX3"
+constexpr uint64_t kBlobMagic = 0x34584449444b5352ULL;  // "RSKDIDX4"
 inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ULL; }
 
 // the layout this library produces for an index of these dimensions (derived arrays -- prefix directory, rank
@@ -614,6 +621,7 @@ void blob_header(const rk_index *idx, BlobHeader *h)
     h->U = idx->U;
     h->max_src_size = idx->max_src_size;
     h->max_ref_size = idx->max_ref_size;
+    h->min_ref_size = idx->min_ref_size;
     h->n_self = idx->n_self;
     h->n_ref = idx->n_ref;
     h->has_self = idx->d_selfrange ? 1 : 0;
@@ -686,6 +694,7 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
     idx->U = h.U;
     idx->max_src_size = h.max_src_size;
     idx->max_ref_size = h.max_ref_size;
+    idx->min_ref_size = h.min_ref_size;
     idx->n_self = h.n_self;
     idx->ref_sets = h.ref_sets != 0;
     idx->hash_bits = h.hash_bits;
@@ -852,7 +861,10 @@ int rk_index_import64(rk_ctx *ctx, const uint32_t *postings, uint64_t total, con
     idx->H = total;
     idx->U = n_hash;
     idx->hash_bits = hash_bits;
-    for (uint32_t g = 0; g < n_ref; g++) idx->max_ref_size = std::max<uint64_t>(idx->max_ref_size, ref_sizes[g]);
+    for (uint32_t g = 0; g < n_ref; g++) {
+        idx->max_ref_size = std::max<uint64_t>(idx->max_ref_size, ref_sizes[g]);
+        if (ref_sizes[g] && (!idx->min_ref_size || ref_sizes[g] < idx->min_ref_size)) idx->min_ref_size = ref_sizes[g];
+    }
     hipStream_t st = ctx->stream;
     RK_TRY(pool_array(ctx, &idx->d_sizes, (size_t)n_ref + 1));
     RK_TRY(pool_array(ctx, &idx->d_postings, total + 4));

@@ -30,7 +30,10 @@ struct rk_ctx {
     std::mutex mu;
     std::multimap<size_t, void *> free_blocks;
     std::unordered_map<void *, size_t> live;  // every block handed out or cached -> its size
-    size_t pool_bytes = 0;
+    size_t pool_bytes = 0;           // everything obtained from the driver
+    size_t cached_bytes = 0;         // of which idle in free_blocks
+    uint64_t driver_allocs = 0, driver_frees = 0;  // hipMalloc / hipFree calls made by the pool
+    size_t cache_limit = 0;          // idle bytes above this go straight back to the driver (RK_POOL_LIMIT_MB, default 32 GiB)
     std::map<std::tuple<const void *, int, size_t>, int> occupancy;  // hipOccupancy... costs 10-70 us per query
     // optional HIP-event timing of the dominant kernel of a pass (rk_ctx_set_timing): [0] sketch kernel
     bool timing = false;
@@ -123,6 +126,7 @@ struct rk_index {
     bool sum_sq_known = false;
     uint64_t max_src_size = 0;       // largest source sketch (built index only)
     uint64_t max_ref_size = 0;       // largest reference sketch (every index)
+    uint64_t min_ref_size = 0;       // smallest NON-EMPTY reference sketch (0: all empty): lower bound of a containment denominator
     bool ref_sets = false;           // no genome appears twice in a posting list (the sketches are sets): an
                                      // intersection count is then bounded by the smaller sketch
     uint2 *d_rankbm = nullptr;       // lazily built by the query path (rk_distq.hip): per 32 consecutive hash values

@@ -402,3 +402,33 @@ def test_fastq_quality_gate_and_occurrence_count(ctx, least_qual, least_num):
         assert sum(len(w) for w in wants) > 100
     if least_qual == 127:
         assert sk.total == 0
+
+
+def test_steady_state_calls_do_not_touch_the_driver_allocator():
+    """the context's pool: after a warm-up pass, upload -> index build -> self join -> ref-vs-query -> frees repeat
+    without a single hipMalloc / hipFree (rk_ctx_pool_stats), and rk_ctx_trim gives the cache back"""
+    c = capi.Context(0)
+    names, h, off = synth.clade_sketches(3000, 300, 26, seed=3)
+    q_off = (off[:101] - off[0]).astype(np.uint64)
+
+    def one_pass():
+        sk = c.sketches_from_host(h, off)
+        idx = c.index_build(sk, 26)
+        a, _ = c.dist_rows(idx, None, 1, 0, 20, 0.05)
+        qs = c.sketches_from_host(h[:int(off[100])], q_off)
+        b, _ = c.dist_rows(idx, qs, 0, 0, 20, 0.05)
+        for o in (qs, idx, sk):
+            o.close()
+        return len(a), len(b)
+
+    first = one_pass()
+    one_pass()
+    before = c.pool_stats()
+    for _ in range(3):
+        assert one_pass() == first
+    after = c.pool_stats()
+    assert after[2] == before[2] and after[3] == before[3], (before, after)
+    assert after[1] == after[0] > 0          # everything is back in the cache
+    c.trim()
+    assert c.pool_stats()[:2] == (0, 0)
+    c.close()
