@@ -466,81 +466,104 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         const uint32_t nb = (uint32_t)((e1 - e0 + kDistThreads - 1) / kDistThreads);
         for (uint32_t b = 0; b < nb; b++) {
             const uint64_t at = e0 + (uint64_t)b * kDistThreads;
-            const uint2 rg = pre;
+            const uint2 raw = pre;
             const bool held_in_b = PAIR && at + tid >= cur.eb;   // the slice this lane holds is the partner's
             if (b + 1 < nb) pre = load_slice(at + kDistThreads + tid, e1);
             else pre = load_slice(nxt.e0 + tid, nxt.e1);
             PROF_MARK(0);
 
-            Gathered g;
-            gather(rg, g);
-            // Lists longer than 8 (2.5 % of the slices at 10,000 genomes, 1.6 per wave and
-            // batch): postings 8..23 of up to four of them are requested right away, one list
-            // per 16-lane row, so their latency overlaps the quad gathers instead of adding a
-            // dependent round trip each; whatever is longer still is streamed by the whole wave.
-            unsigned long long longs = __ballot(rg.y - rg.x > (uint32_t)kGroup);
-            uint32_t lx[4] = {0, 0, 0, 0}, ly[4] = {0, 0, 0, 0};  // uniform
-            int lown[4] = {0, 0, 0, 0};                           // uniform: lane holding the slice
-            uint32_t qx = 0, qy = 0;                              // this lane's 16-lane row
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                if (longs) {  // uniform
+            // Compact slices (rk_index.hip compact_slice: bit 31 | first genome, bitmask of the ids first .. first+31) carry
+            // their posting list in the record: no posting load, no address arithmetic.  Every lane scatters its own
+            // list; the wave loops as often as its longest list has bits (a handful of neighbouring strains).  The lists
+            // of one row name the same few relatives, so every lane starts at a different bit (mask rotated by lane & 7):
+            // an LDS atomic instruction then spreads over ~8 columns instead of queueing 64 lanes on one counter.
+            const bool cpt = (raw.x >> 31) != 0;
+            const uint2 rg = cpt ? make_uint2(0, 0) : raw;      // posting ranges for the gather path below
+            if (__ballot(cpt)) {  // uniform
+                const uint32_t first = raw.x & 0x7FFFFFFFu;
+                // pair mode: a first-row slice is shared with the partner iff its first genome IS the partner, who then
+                // gets every later genome of the list
+                const bool c_shared = PAIR && cpt && !held_in_b && first == row_b;
+                const uint32_t rot = lane & 7u;
+                uint32_t m = cpt ? __builtin_amdgcn_alignbit(raw.y, raw.y, rot) : 0u;  // rotate right by rot
+                while (__ballot(m != 0)) {
+                    const bool v = m != 0;
+                    const uint32_t k = v ? ((uint32_t)__ffs((int)m) - 1u + rot) & 31u : 0u;
+                    bump(first + k, v, held_in_b, c_shared && k != 0);
+                    m &= m - 1u;
+                }
+            }
+            if (__ballot(rg.y > rg.x)) {  // uniform: some lane holds a posting range
+                Gathered g;
+                gather(rg, g);
+                // Lists longer than 8 (2.5 % of the slices at 10,000 genomes, 1.6 per wave and
+                // batch): postings 8..23 of up to four of them are requested right away, one list
+                // per 16-lane row, so their latency overlaps the quad gathers instead of adding a
+                // dependent round trip each; whatever is longer still is streamed by the whole wave.
+                unsigned long long longs = __ballot(rg.y - rg.x > (uint32_t)kGroup);
+                uint32_t lx[4] = {0, 0, 0, 0}, ly[4] = {0, 0, 0, 0};  // uniform
+                int lown[4] = {0, 0, 0, 0};                           // uniform: lane holding the slice
+                uint32_t qx = 0, qy = 0;                              // this lane's 16-lane row
+    #pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (longs) {  // uniform
+                        const int L = __ffsll((long long)longs) - 1;
+                        longs &= longs - 1;
+                        lown[t] = L;
+                        lx[t] = __builtin_amdgcn_readlane(rg.x, L) + kGroup;
+                        ly[t] = __builtin_amdgcn_readlane(rg.y, L);
+                        if ((lane >> 4) == (uint32_t)t) { qx = lx[t]; qy = ly[t]; }
+                    }
+                }
+                const uint32_t kq = qx + (lane & 15);
+                const bool lokq = kq < qy;
+                const uint32_t lidq = a.postings[lokq ? kq : 0];
+                PROF_MARK(7);
+                PROF_FENCE();
+                PROF_MARK(8);
+                // pair mode: a first-row slice is shared with the partner iff its first posting IS
+                // the partner; the partner then gets every later posting of the list
+                bool held_shared = false;  // for the slice this lane holds
+                auto walk = [&](int j, bool in_b) {
+                    bool shared = false;
+                    if (PAIR) {
+                        const uint32_t first = quad_bcast<0>(g.ok0[j] ? g.id[j].x : 0xFFFFFFFEu);  // never a row
+                        shared = !in_b && first == row_b;
+                        if (sub == (uint32_t)j) held_shared = shared;
+                    }
+                    bump(g.id[j].x, g.ok0[j], in_b, shared && sub != 0);  // the first posting is the partner itself
+                    bump(g.id[j].y, g.ok1[j], in_b, shared);
+                };
+                const uint32_t hb = held_in_b ? 1u : 0u;
+                walk(0, PAIR && quad_bcast<0>(hb) != 0);
+                walk(1, PAIR && quad_bcast<1>(hb) != 0);
+                walk(2, PAIR && quad_bcast<2>(hb) != 0);
+                walk(3, PAIR && quad_bcast<3>(hb) != 0);
+                PROF_FENCE();
+                PROF_MARK(9);
+                unsigned long long shared_mask = 0, in_b_mask = 0;
+                if (PAIR) {
+                    shared_mask = __ballot(held_shared);
+                    in_b_mask = __ballot(held_in_b);
+                }
+                bool q_shared = false, q_in_b = false;
+    #pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if ((lane >> 4) == (uint32_t)t) {
+                        q_shared = (shared_mask >> lown[t]) & 1;
+                        q_in_b = (in_b_mask >> lown[t]) & 1;
+                    }
+                bump(lidq, lokq, q_in_b, q_shared);
+    #pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (lx[t] + 16 < ly[t])  // uniform
+                        stream_list(lx[t] + 16, ly[t], (in_b_mask >> lown[t]) & 1, (shared_mask >> lown[t]) & 1);
+                while (longs) {
                     const int L = __ffsll((long long)longs) - 1;
                     longs &= longs - 1;
-                    lown[t] = L;
-                    lx[t] = __builtin_amdgcn_readlane(rg.x, L) + kGroup;
-                    ly[t] = __builtin_amdgcn_readlane(rg.y, L);
-                    if ((lane >> 4) == (uint32_t)t) { qx = lx[t]; qy = ly[t]; }
+                    stream_list(__builtin_amdgcn_readlane(rg.x, L) + kGroup, __builtin_amdgcn_readlane(rg.y, L),
+                                (in_b_mask >> L) & 1, (shared_mask >> L) & 1);
                 }
-            }
-            const uint32_t kq = qx + (lane & 15);
-            const bool lokq = kq < qy;
-            const uint32_t lidq = a.postings[lokq ? kq : 0];
-            PROF_MARK(7);
-            PROF_FENCE();
-            PROF_MARK(8);
-            // pair mode: a first-row slice is shared with the partner iff its first posting IS
-            // the partner; the partner then gets every later posting of the list
-            bool held_shared = false;  // for the slice this lane holds
-            auto walk = [&](int j, bool in_b) {
-                bool shared = false;
-                if (PAIR) {
-                    const uint32_t first = quad_bcast<0>(g.ok0[j] ? g.id[j].x : 0xFFFFFFFEu);  // never a row
-                    shared = !in_b && first == row_b;
-                    if (sub == (uint32_t)j) held_shared = shared;
-                }
-                bump(g.id[j].x, g.ok0[j], in_b, shared && sub != 0);  // the first posting is the partner itself
-                bump(g.id[j].y, g.ok1[j], in_b, shared);
-            };
-            const uint32_t hb = held_in_b ? 1u : 0u;
-            walk(0, PAIR && quad_bcast<0>(hb) != 0);
-            walk(1, PAIR && quad_bcast<1>(hb) != 0);
-            walk(2, PAIR && quad_bcast<2>(hb) != 0);
-            walk(3, PAIR && quad_bcast<3>(hb) != 0);
-            PROF_FENCE();
-            PROF_MARK(9);
-            unsigned long long shared_mask = 0, in_b_mask = 0;
-            if (PAIR) {
-                shared_mask = __ballot(held_shared);
-                in_b_mask = __ballot(held_in_b);
-            }
-            bool q_shared = false, q_in_b = false;
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-                if ((lane >> 4) == (uint32_t)t) {
-                    q_shared = (shared_mask >> lown[t]) & 1;
-                    q_in_b = (in_b_mask >> lown[t]) & 1;
-                }
-            bump(lidq, lokq, q_in_b, q_shared);
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-                if (lx[t] + 16 < ly[t])  // uniform
-                    stream_list(lx[t] + 16, ly[t], (in_b_mask >> lown[t]) & 1, (shared_mask >> lown[t]) & 1);
-            while (longs) {
-                const int L = __ffsll((long long)longs) - 1;
-                longs &= longs - 1;
-                stream_list(__builtin_amdgcn_readlane(rg.x, L) + kGroup, __builtin_amdgcn_readlane(rg.y, L),
-                            (in_b_mask >> L) & 1, (shared_mask >> L) & 1);
             }
             PROF_FENCE();
             PROF_MARK(10);

@@ -7,8 +7,10 @@
 //   upos      u32[U+1]  posting offsets of each distinct hash
 //   sizes     u32[N]    sketch sizes
 //   selfrange uint2[n_self]  for every source element (genome g, hash h) with later sharers: the slice of h's posting
-//                       list holding genomes > g (the all-vs-all triangle needs no lookup); rows back to back,
-//                       inside a row the slices "covered" by the pair partner last (self_split)
+//                       list holding genomes > g (the all-vs-all triangle needs no lookup), either as the posting range
+//                       (x, y) or, when the genomes lie within 32 ids, COMPACT as (bit 31 | first genome, bitmask of
+//                       the ids first .. first+31); rows back to back, inside a row the slices "covered" by the
+//                       pair partner last (self_split)
 // Derived on demand and cached: dir (prefix directory into uhash, for 64-bit / > 2^30 hash spaces), the rank bitmap
 // of the query path (rk_distq.hip), sum of squared list lengths.  The dense 2^bits count array of the .index file
 // is only materialised by rk_index_export / consumed by rk_index_import.
@@ -182,10 +184,23 @@ __global__ void k_row_scan(const uint32_t *n_open, const uint32_t *n_cov, uint32
     }
 }
 
+// A slice whose genomes all lie within 32 ids -- the normal case in a collection ordered by similarity, where a hash is
+// shared by a handful of neighbouring strains -- is stored COMPACT: (bit 31 | first genome, bitmask of the genomes
+// first+0 .. first+31; bit 0 is always set).  The distance kernel then needs no posting load for it at all: the
+// 8-byte slice record IS the posting list.  Other slices stay posting ranges (x, y), x < 2^31.
+__device__ inline uint2 compact_slice(uint2 r, const uint32_t *postings)
+{
+    const uint32_t first = postings[r.x], last = postings[r.y - 1];
+    if (r.y > 0x7FFFFFFFu || (first >> 31) || last - first > 31u) return r;
+    uint32_t mask = 1;
+    for (uint32_t k = r.x + 1; k < r.y; k++) mask |= 1u << (postings[k] - first);
+    return make_uint2(0x80000000u | first, mask);
+}
+
 // one wave per genome: open slices to the front of the row, covered ones behind them, empty ones dropped; the order
 // inside each class is the source order (ballot ranks)
 __global__ void k_row_place(const uint64_t *off, uint32_t n_genomes, const uint2 *self_raw,
-                            const uint64_t *self_off, const uint64_t *self_split, uint2 *out)
+                            const uint64_t *self_off, const uint64_t *self_split, const uint32_t *postings, uint2 *out)
 {
     const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= n_genomes) return;
@@ -197,7 +212,8 @@ __global__ void k_row_place(const uint64_t *off, uint32_t n_genomes, const uint2
         const uint64_t e = base + lane;
         const uint2 raw = e < e1 ? self_raw[e] : make_uint2(0, 0);
         const uint8_t c = slice_class(raw);
-        const uint2 r = slice_range(raw);
+        uint2 r = slice_range(raw);
+        if (c != kEmpty) r = compact_slice(r, postings);
         const unsigned long long mo = __ballot(c == kOpen), mc = __ballot(c == kCovered);
         if (c == kOpen) out[at_open + __popcll(mo & lt)] = r;
         if (c == kCovered) out[at_cov + __popcll(mc & lt)] = r;
@@ -467,7 +483,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         hipLaunchKernelGGL(k_row_counts, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_off, N, self_raw.p, n_open.p, n_cov.p);
         hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, res.p);
         hipLaunchKernelGGL(k_row_place, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_off, N, self_raw.p,
-                           idx->d_self_off, idx->d_self_split, idx->d_selfrange);
+                           idx->d_self_off, idx->d_self_split, idx->d_postings, idx->d_selfrange);
         RK_HIP(ctx, hipGetLastError());
         RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));  // the one synchronisation of the build
     } else {
@@ -590,7 +606,7 @@ struct BlobHeader {
     int32_t hash_bits, wide;
     uint64_t off_postings, off_uhash, off_upos, off_sizes, off_self, off_selfoff, off_src, off_split;
 };
-constexpr uint64_t kBlobMagic = 0x34584449444b5352ULL;  // "RSKDIDX4"
+constexpr uint64_t kBlobMagic = 0x35584449444b5352ULL;  // "RSKDIDX5"
 inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ULL; }
 
 // the layout this library produces for an index of these dimensions (derived arrays -- prefix directory, rank
