@@ -452,6 +452,15 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                 if (PAIR && also_b) bump_cell(row_b_cell + c);
             }
         };
+        // adds n (a wave-level count, <= 64) to column `id` of the unit's first row or of its partner
+        auto bump_n = [&](uint32_t id, uint32_t n, bool to_b) {
+            const uint32_t c = id - col0;
+            if (n && (!FILTER || (c < ncol && id >= lo_id))) {
+                const uint32_t cellc = (PAIR && to_b ? row_b_cell : 0) + c;
+                if (U16) atomicAdd(&cnt[cellc >> 1], (cellc & 1) ? n << 16 : n);
+                else atomicAdd(&cnt[cellc], n);
+            }
+        };
         auto stream_list = [&](uint32_t sx, uint32_t sy, bool in_b, bool also_b) {  // whole wave, 2 x 64 postings in flight
             for (uint32_t k = sx + lane; k < sy; k += 128) {
                 const bool ok1 = k + 64 < sy;
@@ -484,13 +493,37 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                 // pair mode: a first-row slice is shared with the partner iff its first genome IS the partner, who then
                 // gets every later genome of the list
                 const bool c_shared = PAIR && cpt && !held_in_b && first == row_b;
-                const uint32_t rot = lane & 7u;
-                uint32_t m = cpt ? __builtin_amdgcn_alignbit(raw.y, raw.y, rot) : 0u;  // rotate right by rot
-                while (__ballot(m != 0)) {
-                    const bool v = m != 0;
-                    const uint32_t k = v ? ((uint32_t)__ffs((int)m) - 1u + rot) & 31u : 0u;
-                    bump(first + k, v, held_in_b, c_shared && k != 0);
-                    m &= m - 1u;
+                // The lists of one row name the same few relatives: scattered lane by lane, the 64 lanes of an LDS atomic
+                // queue on a handful of counters (48 % of the kernel's time).  Instead the WAVE counts: every list is shifted
+                // onto the 32 columns behind the unit's first row, one ballot per occupied column counts the lanes that
+                // name it, lane p receives the count of column p, and ONE conflict-free atomic per row adds them.
+                const uint32_t base = row + 1;
+                const uint32_t rel = first - base;
+                const bool fits = cpt && rel < 32u && (rel == 0 || (raw.y >> (32u - rel)) == 0);
+                const uint32_t mw = fits ? raw.y << rel : 0u;
+                const uint32_t ma = PAIR && held_in_b ? 0u : mw;
+                const uint32_t mb = PAIR ? (held_in_b ? mw : (c_shared ? mw & ~1u : 0u)) : 0u;  // bit 0 = the partner itself
+                uint32_t ca = 0, cb = 0;
+                for (uint32_t p = 0; p < 32u && __ballot(((ma | mb) >> p) != 0); p++) {
+                    const unsigned long long ba = __ballot((ma >> p) & 1u);
+                    const unsigned long long bb = PAIR ? __ballot((mb >> p) & 1u) : 0ULL;
+                    if (lane == p) {
+                        ca = (uint32_t)__popcll(ba);
+                        cb = (uint32_t)__popcll(bb);
+                    }
+                }
+                bump_n(base + lane, ca, false);
+                if (PAIR) bump_n(base + lane, cb, true);
+                // compact lists that reach beyond those 32 columns: lane by lane, starting at rotated bits
+                if (__ballot(cpt && !fits)) {
+                    const uint32_t rot = lane & 7u;
+                    uint32_t m = cpt && !fits ? __builtin_amdgcn_alignbit(raw.y, raw.y, rot) : 0u;  // rotate right by rot
+                    while (__ballot(m != 0)) {
+                        const bool v = m != 0;
+                        const uint32_t k = v ? ((uint32_t)__ffs((int)m) - 1u + rot) & 31u : 0u;
+                        bump(first + k, v, held_in_b, c_shared && k != 0);
+                        m &= m - 1u;
+                    }
                 }
             }
             if (__ballot(rg.y > rg.x)) {  // uniform: some lane holds a posting range
