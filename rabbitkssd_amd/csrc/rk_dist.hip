@@ -303,9 +303,15 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
             // per lane that found any), then evaluate the list one cell per lane: the FP64
             // divide + log run in parallel, not serialised on the lane that happened to own a
             // clade's adjacent columns.
+            // both rows of a pair are scanned from the quad that holds the first row's diagonal (nothing left of it can be
+            // non-zero in a triangle; in the other modes the scan starts at the row's first quad)
+            const uint32_t row_quads_s = (a.pair_stride / kPerWord) / 4;
             const uint32_t q_first = ((jbeg_a - col0) / kPerWord) / 4;
-            const uint32_t q_end = ((cells_end + kPerWord - 1) / kPerWord + 3) / 4;
-            for (uint32_t q = q_first + tid; q < q_end; q += kDistThreads) {
+            const uint32_t q_last = ((ncol + kPerWord - 1) / kPerWord + 3) / 4;   // one row's quads in use
+            const uint32_t span_s = q_last - min(q_first, q_last);
+            for (uint32_t i = tid; i < span_s * (has_b ? 2u : 1u); i += kDistThreads) {
+                const uint32_t which_s = has_b && i >= span_s ? 1u : 0u;
+                const uint32_t q = which_s * row_quads_s + q_first + (i - which_s * span_s);
                 const uint4 v = c4[q];
                 if ((v.x | v.y | v.z | v.w) == 0) continue;
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -434,7 +440,19 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         if (nrow != kNone) open_unit(nrow, nxt);
 
         uint4 *z4 = reinterpret_cast<uint4 *>(cnt);  // memset row (src/dist.cpp:179)
-        for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
+        if (!FILTER && row != kNone) {
+            // self join: only columns behind the row are ever incremented and only they are scanned, so only they are
+            // zeroed (a workgroup takes its rows in ascending order; what an earlier row left further left is never read)
+            const uint32_t row_quads = (a.pair_stride / kPerWord) / 4;
+            const uint32_t q0 = ((row + 1) / kPerWord) / 4;
+            const uint32_t span = row_quads - min(q0, row_quads);
+            for (uint32_t i = tid; i < span * (PAIR ? 2u : 1u); i += kDistThreads) {
+                const uint32_t which = PAIR && i >= span ? 1u : 0u;
+                z4[which * row_quads + q0 + (i - which * span)] = make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
+        }
         if (tid == 0) s_cells[parity] = 0;
         __syncthreads();
         PROF_MARK(6);
