@@ -235,15 +235,13 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
 
     // ---- epilogue of one unit (src/dist.cpp:207-255 / :600-682) --------------------------
     // row_a: the unit's (first) row; row_b: its pair partner or 0xFFFFFFFF
-    auto epilogue = [&](uint32_t row_a, uint32_t row_b, uint32_t &s_total) {
+    auto epilogue = [&](uint32_t row_a, uint32_t row_b, uint32_t &s_total, const int qsize_a, const int qsize_b) {
         const bool has_b = PAIR && row_b != 0xFFFFFFFFu;
         if (a.common_dense) {  // never in pair mode
             int32_t *dst = a.common_dense + (size_t)row_a * a.n_ref + col0;
             for (uint32_t i = tid; i < ncol; i += kDistThreads)
                 dst[i] = (int32_t)(U16 ? (cnt[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu : cnt[i]);
         }
-        const int qsize_a = (int)(a.size_off[row_a + 1] - a.size_off[row_a]);
-        const int qsize_b = has_b ? (int)(a.size_off[row_b + 1] - a.size_off[row_b]) : 0;
 
         // evaluates one (row, j) cell; returns true when it is reported
         auto evaluate = [&](uint32_t row, int qsize, uint32_t j, int common, rk_hit &hrec) -> bool {
@@ -396,14 +394,19 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     struct Unit {
         uint64_t e0, eb, e1;
         uint32_t row_b;
+        int qsize_a, qsize_b;  // sketch sizes of the unit's rows: fetched one unit ahead, the epilogue starts with them
     };
     auto open_unit = [&](uint32_t row_a, Unit &u) {
         u.e0 = a.range_off[row_a];
         u.eb = u.e1 = a.range_off[row_a + 1];
         u.row_b = 0xFFFFFFFFu;
+        const uint64_t s0 = a.size_off[row_a], s1 = a.size_off[row_a + 1];
+        u.qsize_a = (int)(s1 - s0);
+        u.qsize_b = 0;
         if (PAIR && row_a + 1 < a.n_query) {
             u.row_b = row_a + 1;
             u.e1 = a.range_split[row_a + 1];  // eb == range_off[row_b]
+            u.qsize_b = (int)(a.size_off[row_a + 2] - s1);
         }
     };
     // pipeline of unit slots: s_cur is processed, s_nxt is known (its slices get prefetched), the
@@ -422,6 +425,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     Unit cur;
     cur.e0 = cur.eb = cur.e1 = 0;
     cur.row_b = kNone;
+    cur.qsize_a = cur.qsize_b = 0;
     if (row != kNone) open_unit(row, cur);
     uint2 pre = load_slice(cur.e0 + tid, cur.e1);
     uint32_t parity = 0;
@@ -437,6 +441,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         Unit nxt;
         nxt.e0 = nxt.eb = nxt.e1 = 0;
         nxt.row_b = kNone;
+        nxt.qsize_a = nxt.qsize_b = 0;
         if (nrow != kNone) open_unit(nrow, nxt);
 
         uint4 *z4 = reinterpret_cast<uint4 *>(cnt);  // memset row (src/dist.cpp:179)
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         if (nb == 0) pre = load_slice(nxt.e0 + tid, nxt.e1);  // a unit without slices still hands over the prefetch
         __syncthreads();  // all scatters of the unit done
         PROF_MARK(1);
-        if (row != kNone) epilogue(row, row_b, s_cells[parity]);
+        if (row != kNone) epilogue(row, row_b, s_cells[parity], cur.qsize_a, cur.qsize_b);
         parity ^= 1;
         s_cur = s_nxt;
         s_nxt = s_nn;
