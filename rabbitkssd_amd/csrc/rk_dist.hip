@@ -53,6 +53,7 @@ struct DistArgs {
     int persist;                 // 1: as many workgroups as the chip holds, each walks its share of the units
     uint32_t units_per_xcd, units_per_chunk;
     uint32_t cand_cap, stage_hits;  // LDS carve-up (entries)
+    uint32_t cand_flush;            // a cell list is evaluated once it holds this many entries
     int triangle, metric, kmer_size, dense_mode;
     double max_dist;
     double min_jorc;            // conservative lower bound on jaccard/containment of a reportable pair
@@ -137,12 +138,17 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     // counter row(s) | non-zero cell list | staged hits | scalars
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *cnt = lds;
-    uint2 *cand = reinterpret_cast<uint2 *>(lds + a.cnt_words);  // (cell, common) of the current unit
-    rk_hit *stage = reinterpret_cast<rk_hit *>(cand + a.cand_cap);
+    // reportable cells: one workgroup per CU (1,024 threads) collects (row, column, common, row's sketch size) over
+    // SEVERAL units in two lists taking turns (BATCH); smaller workgroups keep one (cell, common) list per unit
+    constexpr bool BATCH = THREADS >= 1024;
+    uint4 *cand = reinterpret_cast<uint4 *>(lds + a.cnt_words);
+    uint2 *cand2 = reinterpret_cast<uint2 *>(lds + a.cnt_words);
+    rk_hit *stage = BATCH ? reinterpret_cast<rk_hit *>(cand + 2 * a.cand_cap) : reinterpret_cast<rk_hit *>(cand2 + a.cand_cap);
     uint32_t *scal = reinterpret_cast<uint32_t *>(stage + a.stage_hits);
     unsigned long long &s_base = *reinterpret_cast<unsigned long long *>(scal);
-    uint32_t *s_cells = scal + 2;   // [2] cells of the unit being scanned (alternating per unit)
+    uint32_t *s_ncand = scal + 2;   // [2] entries in the two cell lists
     uint32_t &s_cursor = scal[4];   // staged hits
+    uint32_t &s_dense = scal[5];    // dense mode: reports of the unit being evaluated
     const uint32_t kCandCap = a.cand_cap, kStageHits = a.stage_hits;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
@@ -167,7 +173,10 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     const uint32_t col0 = blockIdx.y * a.tile_cols;
     const uint32_t col1 = min(a.n_ref, col0 + a.tile_cols);
     const uint32_t ncol = col1 - col0;
-    if (tid == 0) s_cursor = 0;
+    if (tid == 0) {
+        s_cursor = 0;
+        s_ncand[0] = s_ncand[1] = 0;
+    }
 
     const uint32_t sub = lane & 3;  // lane of the quad
     const bool tri_filter = a.triangle && !a.common_dense;
@@ -233,9 +242,53 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         static_assert(kGroup == 8, "a quad covers 4 lanes x 2 postings");
     };
 
+    // evaluates one (row, j) cell; returns true when it is reported
+    auto evaluate = [&](uint32_t row, int qsize, uint32_t j, int common, rk_hit &hrec) -> bool {
+        const int rs = (int)a.ref_sizes[j];
+        const int size0 = a.triangle ? qsize : rs;  // :215-216 / :607-608
+        const int size1 = a.triangle ? rs : qsize;
+        // cheap exact-safe reject before the FP64 divide + log: the distance is monotone in
+        // jaccard/containment and min_jorc sits strictly below the value at the threshold
+        const int denom = a.metric ? min(size0, size1) : size0 + size1 - common;
+        if ((double)common < a.min_jorc * (double)denom) return false;
+        const JorcDist jd = rk_distance(common, size0, size1, a.metric, a.kmer_size);
+        hrec.row = row;
+        hrec.col = j;
+        hrec.common = common;
+        hrec.size0 = size0;
+        hrec.size1 = size1;
+        hrec.pad_ = 0;
+        hrec.jorc = jd.jorc;
+        hrec.dist = jd.dist;
+        return a.triangle ? (jd.dist < a.max_dist) : (jd.dist <= a.max_dist);  // :232 / :624
+    };
+    auto stage_hit = [&](const rk_hit &hrec) {
+        const uint32_t sl = atomicAdd(&s_cursor, 1u);
+        if (sl < kStageHits) stage[sl] = hrec;
+        else {  // staging full: rare, pay the device-scope atomic per hit
+            const unsigned long long at = atomicAdd(a.n_hits, 1ULL);
+            if (at < a.cap) a.hits[at] = hrec;
+        }
+    };
+    // Cell lists.  A row of a similarity-ordered collection yields a handful of reportable cells; evaluating them unit
+    // by unit leaves one wave with ~9 busy lanes waiting on a reference-size load and an FP64 divide + log while the
+    // rest of the workgroup idles at the next barrier (a third of the kernel at 50,000 genomes, one workgroup per CU).
+    // The scan therefore only APPENDS (row, column, common, |row|) to the current list; once a list is half full it is
+    // evaluated by the whole workgroup, one cell per lane, and the other list takes over.
+    uint32_t ccur = 0;  // uniform: the list the scans append to
+    auto eval_list = [&](uint32_t which, uint32_t n, uint32_t skip_a, uint32_t skip_b) {
+        for (uint32_t i = tid; i < n; i += kDistThreads) {
+            const uint4 e = cand[which * kCandCap + i];
+            if (e.x >= 0xFFFFFFFEu || e.x == skip_a || e.x == skip_b) continue;  // placeholder / the caller walks these rows itself
+            rk_hit hrec;
+            if (evaluate(e.x, (int)e.w, e.y, (int)e.z, hrec)) stage_hit(hrec);
+        }
+    };
+
     // ---- epilogue of one unit (src/dist.cpp:207-255 / :600-682) --------------------------
     // row_a: the unit's (first) row; row_b: its pair partner or 0xFFFFFFFF
-    auto epilogue = [&](uint32_t row_a, uint32_t row_b, uint32_t &s_total, const int qsize_a, const int qsize_b) {
+    auto epilogue = [&](uint32_t row_a, uint32_t row_b, const int qsize_a, const int qsize_b, uint32_t par) {
+        uint32_t &s_total = s_dense;
         const bool has_b = PAIR && row_b != 0xFFFFFFFFu;
         if (a.common_dense) {  // never in pair mode
             int32_t *dst = a.common_dense + (size_t)row_a * a.n_ref + col0;
@@ -243,34 +296,6 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                 dst[i] = (int32_t)(U16 ? (cnt[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu : cnt[i]);
         }
 
-        // evaluates one (row, j) cell; returns true when it is reported
-        auto evaluate = [&](uint32_t row, int qsize, uint32_t j, int common, rk_hit &hrec) -> bool {
-            const int rs = (int)a.ref_sizes[j];
-            const int size0 = a.triangle ? qsize : rs;  // :215-216 / :607-608
-            const int size1 = a.triangle ? rs : qsize;
-            // cheap exact-safe reject before the FP64 divide + log: the distance is monotone in
-            // jaccard/containment and min_jorc sits strictly below the value at the threshold
-            const int denom = a.metric ? min(size0, size1) : size0 + size1 - common;
-            if ((double)common < a.min_jorc * (double)denom) return false;
-            const JorcDist jd = rk_distance(common, size0, size1, a.metric, a.kmer_size);
-            hrec.row = row;
-            hrec.col = j;
-            hrec.common = common;
-            hrec.size0 = size0;
-            hrec.size1 = size1;
-            hrec.pad_ = 0;
-            hrec.jorc = jd.jorc;
-            hrec.dist = jd.dist;
-            return a.triangle ? (jd.dist < a.max_dist) : (jd.dist <= a.max_dist);  // :232 / :624
-        };
-        auto stage_hit = [&](const rk_hit &hrec) {
-            const uint32_t sl = atomicAdd(&s_cursor, 1u);
-            if (sl < kStageHits) stage[sl] = hrec;
-            else {  // staging full: rare, pay the device-scope atomic per hit
-                const unsigned long long at = atomicAdd(a.n_hits, 1ULL);
-                if (at < a.cap) a.hits[at] = hrec;
-            }
-        };
         auto cell = [&](uint32_t c) -> uint32_t {
             return U16 ? (cnt[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu : cnt[c];
         };
@@ -301,56 +326,122 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
             // per lane that found any), then evaluate the list one cell per lane: the FP64
             // divide + log run in parallel, not serialised on the lane that happened to own a
             // clade's adjacent columns.
-            // both rows of a pair are scanned from the quad that holds the first row's diagonal (nothing left of it can be
-            // non-zero in a triangle; in the other modes the scan starts at the row's first quad)
-            const uint32_t row_quads_s = (a.pair_stride / kPerWord) / 4;
-            const uint32_t q_first = ((jbeg_a - col0) / kPerWord) / 4;
-            const uint32_t q_last = ((ncol + kPerWord - 1) / kPerWord + 3) / 4;   // one row's quads in use
-            const uint32_t span_s = q_last - min(q_first, q_last);
-            for (uint32_t i = tid; i < span_s * (has_b ? 2u : 1u); i += kDistThreads) {
-                const uint32_t which_s = has_b && i >= span_s ? 1u : 0u;
-                const uint32_t q = which_s * row_quads_s + q_first + (i - which_s * span_s);
-                const uint4 v = c4[q];
-                if ((v.x | v.y | v.z | v.w) == 0) continue;
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                const uint32_t cq = q * 4 * kPerWord;
-                const uint32_t minc = PAIR && cq >= row_b_cell ? minc_b : minc_a;  // a quad lies in one row
-                uint32_t n = 0;
+            if constexpr (BATCH) {
+                // both rows of a pair are scanned from the quad that holds the first row's diagonal (nothing left of it can be
+                // non-zero in a triangle; in the other modes the scan starts at the row's first quad)
+                const uint32_t row_quads_s = (a.pair_stride / kPerWord) / 4;
+                const uint32_t q_first = ((jbeg_a - col0) / kPerWord) / 4;
+                const uint32_t q_last = ((ncol + kPerWord - 1) / kPerWord + 3) / 4;   // one row's quads in use
+                const uint32_t span_s = q_last - min(q_first, q_last);
+                for (uint32_t i = tid; i < span_s * (has_b ? 2u : 1u); i += kDistThreads) {
+                    const uint32_t which_s = has_b && i >= span_s ? 1u : 0u;
+                    const uint32_t q = which_s * row_quads_s + q_first + (i - which_s * span_s);
+                    const uint4 v = c4[q];
+                    if ((v.x | v.y | v.z | v.w) == 0) continue;
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                    const uint32_t cq = q * 4 * kPerWord;
+                    const uint32_t minc = PAIR && cq >= row_b_cell ? minc_b : minc_a;  // a quad lies in one row
+                    uint32_t n = 0;
 #pragma unroll
-                for (int wi = 0; wi < 4; wi++) {
-                    if (U16) n += ((w[wi] & 0xFFFFu) >= minc) + ((w[wi] >> 16) >= minc);
-                    else n += w[wi] >= minc;
-                }
-                if (!n) continue;
-                uint32_t at = atomicAdd(&s_total, n);
+                    for (int wi = 0; wi < 4; wi++) {
+                        if (U16) n += ((w[wi] & 0xFFFFu) >= minc) + ((w[wi] >> 16) >= minc);
+                        else n += w[wi] >= minc;
+                    }
+                    if (!n) continue;
+                    uint32_t at = atomicAdd(&s_ncand[ccur], n);
+                    const bool in_b = PAIR && cq >= row_b_cell;
+                    const uint32_t erow = in_b ? row_b : row_a;
+                    const uint32_t eq = (uint32_t)(in_b ? qsize_b : qsize_a);
+                    const uint32_t jq = col0 + (in_b ? cq - row_b_cell : cq);  // column of the quad's first cell
+                    const uint32_t jbeg = a.triangle ? max(col0, erow + 1) : col0;  // :207 / :600
 #pragma unroll
-                for (int wi = 0; wi < 4; wi++) {
+                    for (int wi = 0; wi < 4; wi++) {
 #pragma unroll
-                    for (uint32_t h = 0; h < kPerWord; h++) {
-                        const uint32_t common = U16 ? (w[wi] >> (16 * h)) & 0xFFFFu : w[wi];
-                        if (common >= minc) {
-                            if (at < kCandCap) cand[at] = make_uint2(cq + wi * kPerWord + h, common);
-                            at++;
+                        for (uint32_t h = 0; h < kPerWord; h++) {
+                            const uint32_t common = U16 ? (w[wi] >> (16 * h)) & 0xFFFFu : w[wi];
+                            if (common >= minc) {
+                                const uint32_t j = jq + wi * kPerWord + h;
+                                // (cells left of the diagonal / beyond the tile are never non-zero; an entry that fails
+                                // the test still occupies its slot, with a row no unit has)
+                                if (at < kCandCap)
+                                    cand[ccur * kCandCap + at] = make_uint4(j >= jbeg && j < col1 ? erow : kNone - 1, j, common, eq);
+                                at++;
+                            }
                         }
                     }
                 }
-            }
-            PROF_MARK(2);
-            __syncthreads();
-            PROF_MARK(3);
-            const uint32_t n_cells = s_total;
-            if (n_cells <= kCandCap) {
-                for (uint32_t i = tid; i < n_cells; i += kDistThreads) {
-                    const uint2 cj = cand[i];
-                    eval_cell(cj.x, cj.y);
+                PROF_MARK(2);
+                __syncthreads();
+                PROF_MARK(3);
+                const uint32_t n_cells = s_ncand[ccur];
+                if (n_cells > kCandCap) {
+                    // this unit brought more cells than the list had room for: evaluate what the list holds of EARLIER units,
+                    // walk this unit's rows directly, and start over with the other list
+                    eval_list(ccur, kCandCap, row_a, has_b ? row_b : row_a);
+                    for (uint32_t c = (jbeg_a - col0) + tid; c < cells_end; c += kDistThreads) {
+                        const uint32_t common = cell(c);
+                        if (common >= (PAIR && c >= row_b_cell ? minc_b : minc_a)) eval_cell(c, common);
+                    }
+                    if (tid == 0) s_ncand[ccur ^ 1] = 0;
+                    ccur ^= 1;
+                    __syncthreads();  // the rows are zeroed next
+                } else if (n_cells >= a.cand_flush) {
+                    eval_list(ccur, n_cells, kNone - 1, kNone - 1);
+                    if (tid == 0) s_ncand[ccur ^ 1] = 0;  // (its entries were evaluated at least one unit ago)
+                    ccur ^= 1;
                 }
             } else {
-                // more sharing columns than the list holds: walk the rows, one cell per lane
-                for (uint32_t c = (jbeg_a - col0) + tid; c < cells_end; c += kDistThreads) {
-                    const uint32_t common = cell(c);
-                    if (common >= (PAIR && c >= row_b_cell ? minc_b : minc_a)) eval_cell(c, common);
+                // both rows of a pair are scanned from the quad that holds the first row's diagonal (nothing left of it can be
+                // non-zero in a triangle; in the other modes the scan starts at the row's first quad)
+                const uint32_t row_quads_s = (a.pair_stride / kPerWord) / 4;
+                const uint32_t q_first = ((jbeg_a - col0) / kPerWord) / 4;
+                const uint32_t q_last = ((ncol + kPerWord - 1) / kPerWord + 3) / 4;   // one row's quads in use
+                const uint32_t span_s = q_last - min(q_first, q_last);
+                for (uint32_t i = tid; i < span_s * (has_b ? 2u : 1u); i += kDistThreads) {
+                    const uint32_t which_s = has_b && i >= span_s ? 1u : 0u;
+                    const uint32_t q = which_s * row_quads_s + q_first + (i - which_s * span_s);
+                    const uint4 v = c4[q];
+                    if ((v.x | v.y | v.z | v.w) == 0) continue;
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                    const uint32_t cq = q * 4 * kPerWord;
+                    const uint32_t minc = PAIR && cq >= row_b_cell ? minc_b : minc_a;  // a quad lies in one row
+                    uint32_t n = 0;
+#pragma unroll
+                    for (int wi = 0; wi < 4; wi++) {
+                        if (U16) n += ((w[wi] & 0xFFFFu) >= minc) + ((w[wi] >> 16) >= minc);
+                        else n += w[wi] >= minc;
+                    }
+                    if (!n) continue;
+                    uint32_t at = atomicAdd(&s_ncand[par], n);
+#pragma unroll
+                    for (int wi = 0; wi < 4; wi++) {
+#pragma unroll
+                        for (uint32_t h = 0; h < kPerWord; h++) {
+                            const uint32_t common = U16 ? (w[wi] >> (16 * h)) & 0xFFFFu : w[wi];
+                            if (common >= minc) {
+                                if (at < kCandCap) cand2[at] = make_uint2(cq + wi * kPerWord + h, common);
+                                at++;
+                            }
+                        }
+                    }
                 }
-                __syncthreads();  // the rows are zeroed next
+                PROF_MARK(2);
+                __syncthreads();
+                PROF_MARK(3);
+                const uint32_t n_cells = s_ncand[par];
+                if (n_cells <= kCandCap) {
+                    for (uint32_t i = tid; i < n_cells; i += kDistThreads) {
+                        const uint2 cj = cand2[i];
+                        eval_cell(cj.x, cj.y);
+                    }
+                } else {
+                    // more sharing columns than the list holds: walk the rows, one cell per lane
+                    for (uint32_t c = (jbeg_a - col0) + tid; c < cells_end; c += kDistThreads) {
+                        const uint32_t common = cell(c);
+                        if (common >= (PAIR && c >= row_b_cell ? minc_b : minc_a)) eval_cell(c, common);
+                    }
+                    __syncthreads();  // the rows are zeroed next
+                }
             }
             PROF_MARK(4);
         } else {
@@ -458,7 +549,10 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         } else {
             for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
         }
-        if (tid == 0) s_cells[parity] = 0;
+        if (tid == 0) {
+            s_dense = 0;
+            if (!BATCH) s_ncand[parity] = 0;  // per-unit cell counter, alternating so that a slow wave still reads its unit's
+        }
         __syncthreads();
         PROF_MARK(6);
 
@@ -627,7 +721,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         if (nb == 0) pre = load_slice(nxt.e0 + tid, nxt.e1);  // a unit without slices still hands over the prefetch
         __syncthreads();  // all scatters of the unit done
         PROF_MARK(1);
-        if (row != kNone) epilogue(row, row_b, s_cells[parity], cur.qsize_a, cur.qsize_b);
+        if (row != kNone) epilogue(row, row_b, cur.qsize_a, cur.qsize_b, parity);
         parity ^= 1;
         s_cur = s_nxt;
         s_nxt = s_nn;
@@ -635,6 +729,9 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         cur = nxt;
     }
 
+    // the cells still waiting in the current list
+    __syncthreads();
+    if (BATCH) eval_list(ccur, min(s_ncand[ccur], kCandCap), kNone - 1, kNone - 1);
     // flush the staged hits of this workgroup: one device-scope atomic, coalesced 8-byte stores
     __syncthreads();
     const uint32_t n_st = min(s_cursor, kStageHits);
@@ -679,8 +776,11 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     const bool small_rows = one_row + (size_t)p->cand_cap * sizeof(uint2) + kStageHitsDefault * sizeof(rk_hit) + 64 <= 24 * 1024;
     p->persist = idx->n_ref && ctx->sw_dist_persist != 2;
     p->stage_hits = ctx->sw_dist_stage_hits ? ctx->sw_dist_stage_hits : 4 * kStageHitsDefault;
+    // cell lists: (cell, common) per unit for workgroups below 1,024 threads; 1,024-thread workgroups (one per CU) keep two
+    // lists of 16-byte entries and evaluate across units (kernel: BATCH).  Tiles are sized for the bigger layout.
+    const size_t batch_extra = 2 * (size_t)p->cand_cap * sizeof(uint4) - (size_t)p->cand_cap * sizeof(uint2);
     size_t fixed = (size_t)p->cand_cap * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
-    const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - fixed;
+    const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - fixed - batch_extra;
     const uint32_t max_cols = (uint32_t)(p->u16 ? lds_cap / 2 : lds_cap / 4) & ~63u;
     uint32_t tile = idx->n_ref ? idx->n_ref : 1;
     if (tile > max_cols) {
@@ -726,6 +826,7 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     if (p->mode == kSelfPair && p->threads == 256) p->threads = 512;  // two rows' slices per unit: measured better
     const uint32_t forced = ctx->sw_dist_threads;
     if (forced == 256 || forced == 512 || forced == 1024 || forced == 768) p->threads = forced;
+    if (p->threads >= 1024) p->lds_bytes += batch_extra;
     // does a pair with distance exactly 1.0 (common == 0) pass the threshold?
     p->dense_mode = rk_dense_mode(o) ? 1 : 0;
     return RK_OK;
@@ -775,6 +876,10 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.runs_per_chunk = std::max<uint32_t>(1, (ctx->sw_dist_xcd_rows ? ctx->sw_dist_xcd_rows : kRowsPerXcdChunk) / (p.units_per_wg * unit_rows));
     a.cand_cap = p.cand_cap;
     a.stage_hits = p.stage_hits;
+    // one workgroup per CU (rows of ~100 KB): nothing else hides the latency of evaluating a unit's handful of cells, so
+    // they are collected over several units and evaluated by the whole workgroup; with several workgroups per CU the
+    // others fill the gap and every unit evaluates its own cells right away
+    a.cand_flush = p.cand_cap / 2;
     void (*kern)(DistArgs) = nullptr;
 #define RK_PICK3(U, T)                                                                          \
     (p.mode == kSelfPair ? rk_dist_kernel<U, kSelfPair, T>                                      \
