@@ -532,9 +532,11 @@ def main():
                      "frac": head["achieved"] / HBM_PEAK_GBS, "traffic": None, "hbm_frac": None,
                      "kernel": head["kernel"], "kernel_ms": head["kernel_ms"],
                      "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
-                     "limiter": "same-address LDS atomics, L1 tag look-ups and wave latency (DESIGN.md 4.3): `frac` is the "
-                                "contract fraction on SURVEY 8d's byte model, which bills count cells that never leave LDS; "
-                                "`hbm_frac` is what the HBM counters saw"},
+                     "limiter": "per-unit latency (3 barriers, slice stream, wave-level column counts) at 24 waves per CU; not HBM "
+                                "(DESIGN.md 4.3).  `frac` is the CONTRACT fraction on SURVEY 8d's byte model (12 B/query hash + 4 B/"
+                                "posting + 4 B/count cell): the kernel keeps the counts in LDS and, with compact slices, streams no "
+                                "postings at all, so the model bills bytes that never move and `frac` can exceed 1; `hbm_frac` is "
+                                "what the HBM counters saw"},
         "setup": {"index_build_ms": head["index_build_ms"], "index_build_cold_ms": head["index_build_cold_ms"],
                   "index_blob_bytes": head["index_blob_bytes"], "rccl_broadcast_ms": head["rccl_broadcast_ms"],
                   "host_inclusive_ms": t_host_inclusive * 1e3,

@@ -93,7 +93,9 @@ def main(tag):
                    "passes": "FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, see profiles/%s_pmc_summary.csv" % tag},
                   open(os.path.join(PROF, fname), "w"), indent=1)
         return hbm
-    t_d = traffic(groups["dist"], "rk_dist_kernel", "pmc_traffic.json", "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X", False)
+    # the self join now streams only its 8-byte slice records (compact slices carry their posting list): a coalesced
+    # stream, FETCH_SIZE x 2 like every wide read on gfx950 (check: ~5.4 M uncovered slices x 8 B = 43 MB)
+    t_d = traffic(groups["dist"], "rk_dist_kernel", "pmc_traffic.json", "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X", True)
     t_q = traffic(groups["rq"], "rk_distq_kernel", "pmc_traffic_rq.json", "dist 100,000 refs x 1,000 queries (tools/prof_driver.py dist_rq_dev), MI355X", False)
     t_s = traffic(groups["sketch"], "rk_sketch_kernel", "pmc_traffic_sketch.json", "sketch 128 x 5 Mb (tools/prof_driver.py sketch 128 5000000), MI355X", True)
     print("value %.4g %s, %.4f ms/step, contract frac %.3f; traffic dist %s rq %s sketch %s B/launch" % (
