@@ -66,14 +66,14 @@ constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
 //         0.05 %).  Measured 0.360 ms against 0.392 ms for IMG 0 on 128 x 5 Mb; A 2^19 + B 2^16 measured 0.365 ms.
 template <int IMG> struct Img {
     static constexpr int kBitsA = IMG ? 18 : 19, kBitsB = 18;
-    static constexpr uint32_t kStageCap = 96;  // keys staged per wave before a flush
+    static constexpr uint32_t kStageCap = 96;  // slots of a wave's window queue (drained from 64 on)
     static constexpr uint32_t kWordsA = (1u << kBitsA) / 32, kWordsB = (1u << kBitsB) / 32;
     static constexpr bool kHasExact = IMG == 0;
     static constexpr size_t kFilterLdsBytes = (kWordsA + kWordsB) * 4 + (kHasExact ? kExactSlots * 4 + kExactSlots * 2 : 0);
     static constexpr int kWavesPerEu = IMG ? 8 : 4;
 };
-// per-wave staging of emitted keys in LDS: one global atomic + one coalesced store burst
-// per flush instead of one contended device-scope atomic per emitted hash
+// per-wave queue in LDS of the windows that passed both bitmaps: resolved 64 at a time, one global atomic and one
+// store burst per round
 template <int IMG> constexpr size_t stage_lds_bytes() { return kWavesPerBlock * (Img<IMG>::kStageCap * 8 + 8); }
 static_assert(Img<0>::kFilterLdsBytes + stage_lds_bytes<0>() <= 160 * 1024, "LDS image must fit one CU");
 static_assert(2 * (Img<1>::kFilterLdsBytes + stage_lds_bytes<1>()) <= 160 * 1024, "two small images must fit one CU");
@@ -105,23 +105,24 @@ struct SketchArgs {
     unsigned long long *n_windows;
 };
 
-// low 64 bits of the 96-bit string w2:w1:w0 shifted right by sh (0 <= sh < 96)
-__device__ inline uint64_t ext96(uint32_t w2, uint32_t w1, uint32_t w0, int sh)
-{
-    const uint64_t lo = ((uint64_t)w1 << 32) | w0;
-    const uint64_t hi = ((uint64_t)w2 << 32) | w1;
-    if (sh == 0) return lo;
-    if (sh < 32) return (lo >> sh) | ((uint64_t)w2 << (64 - sh));
-    if (sh < 64) return hi >> (sh - 32);
-    return (uint64_t)(w2 >> (sh - 64));
-}
-
-// low 32 bits of the same; with a compile-time sh this is one v_alignbit_b32
+// low 32 bits of the 96-bit string w2:w1:w0 shifted right by sh (0 <= sh < 96); with a compile-time sh this is one
+// v_alignbit_b32
 __device__ inline uint32_t ext96_lo(uint32_t w2, uint32_t w1, uint32_t w0, int sh)
 {
     if (sh < 32) return __builtin_amdgcn_alignbit(w1, w0, sh);
     if (sh < 64) return __builtin_amdgcn_alignbit(w2, w1, sh - 32);
     return w2 >> (sh - 64);
+}
+
+// low 64 bits of the same for a shift only known at run time, branch-free (5 selects + 2 funnel shifts)
+__device__ inline uint64_t ext96v(uint32_t w2, uint32_t w1, uint32_t w0, uint32_t sh)
+{
+    const uint32_t q = sh >> 5;
+    const uint32_t a0 = q == 0 ? w0 : (q == 1 ? w1 : w2);
+    const uint32_t a1 = q == 0 ? w1 : (q == 1 ? w2 : 0u);
+    const uint32_t a2 = q == 0 ? w2 : 0u;
+    const uint32_t lo = __builtin_amdgcn_alignbit(a1, a0, sh & 31u), hi = __builtin_amdgcn_alignbit(a2, a1, sh & 31u);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // 16 ASCII bases -> G: 2-bit codes, base i of the lane at bits 2i (the orientation of the
@@ -161,14 +162,6 @@ __device__ inline void pack16(const uint4 w, uint32_t &G, uint32_t &V)
 
 // scan code <-> BaseMap code of every 2-bit group (swaps 2 and 3; an involution)
 __host__ __device__ inline uint32_t to_base_code(uint32_t g) { return g ^ ((g >> 1) & 0x55555555u); }
-
-// 2-bit-group reversal: base i moves from bits 2i to bits 2(15-i) (the orientation of
-// `tuple`, src/sketch.cpp:498)
-__device__ inline uint32_t rev2(uint32_t G)
-{
-    const uint32_t b = __brev(G);
-    return ((b >> 1) & 0x55555555u) | ((b & 0x55555555u) << 1);
-}
 
 // value of lane-1 (DPP wave_shr:1); lane 0 receives lane0_val
 __device__ inline uint32_t wave_shr1(uint32_t v, uint32_t lane0_val)
@@ -210,19 +203,55 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     unsigned long long windows = 0;
-    uint32_t staged = 0;  // wave-uniform: keys in this wave's staging buffer
+    uint32_t staged = 0;  // wave-uniform: windows in this wave's queue
 
-    // wave-level flush of the staged keys into the genome's candidate region (all 64 lanes call it together):
-    // one device-scope atomic on the genome's counter + one coalesced burst
-    auto flush = [&](uint32_t gid, unsigned long long *region, uint32_t region_cap) {
+    // A window that passed both bitmaps (0.2 % of all) is not resolved where it is found -- that would run the
+    // reference arithmetic below with 1-2 of 64 lanes active, several times per block --: its 2k bits go to the
+    // wave's queue in LDS, and once 64 are together every lane confirms one.
+    // W: the window in the orientation of G (oldest base in the low bits, scan code).
+    auto confirm = [&](uint64_t W, unsigned long long &key) -> bool {
+        const uint64_t Bc = W ^ ((W >> 1) & 0x5555555555555555ULL);       // BaseMap codes (to_base_code)
+        const uint64_t rvs = ~Bc & a.tupmask;                             // :499
+        uint64_t r = __brevll(Bc);                                        // forward strand: base order reversed
+        r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+        const uint64_t tuple = r >> (64 - 2 * k);                         // :498
+        const uint64_t uni = tuple < rvs ? tuple : rvs;                   // :508
+        const uint32_t dim = (uint32_t)(uni >> out2) & dim_mask;          // :509
+        int32_t v = -1;
+        if (EXACT) {
+            uint32_t slot = (dim * 0x9E3779B1u) >> (32 - kExactSlotsLog2);
+            for (;;) {
+                const uint32_t kk = keys[slot];
+                if (kk == dim) { v = (int32_t)vals[slot] + a.dim_start; break; }
+                if (kk == kEmptyKey) break;
+                slot = (slot + 1) & (kExactSlots - 1);
+            }
+        } else {
+            v = a.table[dim];
+        }
+        if (v < a.dim_start || v >= a.dim_end) return false;              // :341,:516
+        const uint64_t pf = (uint64_t)(v - a.dim_start);                  // :519-521
+        key = (((uni & a.undomask0) | ((uni & a.undomask1) << a.und1_shift)) >> a.dr_shift) | pf;  // :524
+        return true;
+    };
+    // wave-level drain of the queue (all 64 lanes call it together): 64 windows per round, one device-scope atomic
+    // on the genome's counter and one burst of stores per round
+    auto drain = [&](uint32_t gid, unsigned long long *region, uint32_t region_cap) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint32_t n = min(*(volatile uint32_t *)stage_n, kStageCap);
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            unsigned long long key = 0;
+            bool ok = false;
+            if (i0 + lane < n) ok = confirm(stage[i0 + lane], key);
+            const unsigned long long m = __ballot(ok);
+            if (m) {
+                uint32_t basep = 0;
+                if (lane == 0) basep = atomicAdd(a.gcount + gid, (uint32_t)__popcll(m));
+                basep = __shfl(basep, 0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (ok && basep < region_cap) region[basep] = key;
+            }
+        }
         if (n) {
-            uint32_t basep = 0;
-            if (lane == 0) basep = atomicAdd(a.gcount + gid, n);
-            basep = __shfl(basep, 0);
-            for (uint32_t i = lane; i < n; i += 64)
-                if (basep + i < region_cap) region[basep + i] = stage[i];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (lane == 0) *(volatile uint32_t *)stage_n = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -300,10 +329,10 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
             }
             return maybe;
         };
-        // level 2 (1.6 % of the windows): bitmap B on the high bits, then the full reference
-        // arithmetic for the ~0.05 % that pass both.  Returns the keys this lane staged.
+        // level 2 (1.6-3 % of the windows): bitmap B on the high bits; the ~0.2 % that pass both are queued.
+        // Returns the windows this lane queued.
         auto survivors = [&](const Blk &o) -> uint32_t {
-            uint32_t emitted = 0;
+            uint32_t queued = 0;
             uint32_t maybe = o.maybe;
             const uint32_t G = o.G, G1 = o.G1, G2 = o.G2;
             while (maybe) {
@@ -315,39 +344,19 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
                 const uint32_t x = __builtin_amdgcn_alignbit(wb, wa, sh & 31) & dim_mask;
                 const uint32_t ib = x >> a.hi_shift;
                 if (!((bmB[ib >> 5] >> (ib & 31)) & 1u)) continue;
-                const uint32_t B0 = to_base_code(G), B1 = to_base_code(G1), B2 = to_base_code(G2);  // BaseMap codes
-                const uint32_t F = rev2(B0), F1 = rev2(B1), F2 = rev2(B2);   // forward strand words
-                const uint64_t tuple = ext96(F2, F1, F, 2 * (15 - j)) & a.tupmask;          // :498
-                const uint64_t rvs = ext96(~B0, ~B1, ~B2, 2 * (33 + j - k)) & a.tupmask;   // :499
-                const uint64_t uni = tuple < rvs ? tuple : rvs;                            // :508
-                const uint32_t dim = (uint32_t)(uni >> out2) & dim_mask;                   // :509
-                int32_t v = -1;
-                if (EXACT) {
-                    uint32_t slot = (dim * 0x9E3779B1u) >> (32 - kExactSlotsLog2);
-                    for (;;) {
-                        const uint32_t kk = keys[slot];
-                        if (kk == dim) { v = (int32_t)vals[slot] + a.dim_start; break; }
-                        if (kk == kEmptyKey) break;
-                        slot = (slot + 1) & (kExactSlots - 1);
-                    }
-                } else {
-                    v = a.table[dim];
-                }
-                if (v >= a.dim_start && v < a.dim_end) {                        // :341,:516
-                    const uint64_t pf = (uint64_t)(v - a.dim_start);            // :519-521
-                    const uint64_t dr = (((uni & a.undomask0) | ((uni & a.undomask1) << a.und1_shift)) >>
-                                         a.dr_shift) | pf;                      // :524
-                    const unsigned long long key = dr;
-                    const uint32_t sl = atomicAdd(stage_n, 1u);
-                    emitted++;
-                    if (sl < kStageCap) stage[sl] = key;
-                    else {  // staging full inside one block (low-complexity sequence): go direct
+                const uint64_t W = ext96v(G, G1, G2, 2 * (33 + j - k)) & a.tupmask;
+                const uint32_t sl = atomicAdd(stage_n, 1u);
+                queued++;
+                if (sl < kStageCap) stage[sl] = W;
+                else {  // queue full inside one block (low-complexity sequence): resolve in place
+                    unsigned long long key;
+                    if (confirm(W, key)) {
                         const uint32_t slot = atomicAdd(a.gcount + gid, 1u);
                         if (slot < region_cap) region[slot] = key;
                     }
                 }
             }
-            return emitted;
+            return queued;
         };
 
         uint4 c0 = load_block(0), c1 = load_block(1);
@@ -366,15 +375,15 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
                 A.bad = bad_windows(VA, VA1, VA2);
                 windows += __popc(~A.bad & 0xFFFFu);
                 A.maybe = probe_a(A) & ~A.bad;
-                const uint32_t emitted = survivors(A);
+                const uint32_t queued = survivors(A);
                 for (uint32_t lvl = 1; ; lvl++) {
-                    const unsigned long long m = __ballot(emitted >= lvl);
+                    const unsigned long long m = __ballot(queued >= lvl);
                     if (!m) break;
                     staged += __popcll(m);
                 }
                 c0 = c1;
                 c1 = n0;
-                if (staged >= kStageCap / 2) { flush(gid, region, region_cap); staged = 0; }
+                if (staged >= 64) { drain(gid, region, region_cap); staged = 0; }
             }
         } else
         for (uint32_t b = 0; b < nb; b += 2) {
@@ -401,18 +410,18 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
             A.maybe = ma & ~A.bad;
             B.maybe = mb & ~B.bad;
 
-            uint32_t emitted = survivors(A);
-            emitted += survivors(B);
+            uint32_t queued = survivors(A);
+            queued += survivors(B);
             for (uint32_t lvl = 1; ; lvl++) {  // wave-uniform count of staged keys, no LDS round trip
-                const unsigned long long m = __ballot(emitted >= lvl);
+                const unsigned long long m = __ballot(queued >= lvl);
                 if (!m) break;
                 staged += __popcll(m);
             }
             c0 = n0;
             c1 = n1;
-            if (staged >= kStageCap / 2) { flush(gid, region, region_cap); staged = 0; }
+            if (staged >= 64) { drain(gid, region, region_cap); staged = 0; }
         }
-        flush(gid, region, region_cap);
+        drain(gid, region, region_cap);
         staged = 0;
     }
     for (int o = 32; o > 0; o >>= 1) windows += __shfl_down(windows, o);

@@ -29,11 +29,12 @@ def sketch(n_genomes=128, length=5_000_000, steps=3):
     gbeg = np.arange(n_genomes, dtype=np.uint64) * stride
     gend = gbeg + np.uint64(length)
     torch.cuda.synchronize()
+    ctx.set_timing(True)
     for _ in range(steps):
         t0 = time.time()
         sk = ctx.sketch_packed_dev(flt, packed.data_ptr(), packed.numel(), gbeg, gend, 0)
         torch.cuda.synchronize()
-        print("sketch pass %.3f ms, %d windows, %d hashes" % ((time.time() - t0) * 1e3, sk.windows, sk.total))
+        print("sketch pass %.3f ms (scan kernel %.4f ms), %d windows, %d hashes" % ((time.time() - t0) * 1e3, ctx.last_ms(0), sk.windows, sk.total))
 
 
 def dist(n_genomes=10000, steps=5, row_step=1, row_block=0):

@@ -1,0 +1,7 @@
+set +e
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout -k 10 600 python3 -m pytest tests -m gpu -x -q -k "sketch or golden or cli or config1" > gpurun_out/gpu_sk_tests.log 2>&1 || { tail -60 gpurun_out/gpu_sk_tests.log; exit 1; }
+tail -3 gpurun_out/gpu_sk_tests.log
+timeout -k 10 200 python3 tools/prof_driver.py sketch 128 5000000 6 > gpurun_out/sk.log 2>&1 || { tail -20 gpurun_out/sk.log; exit 1; }
+cat gpurun_out/sk.log
