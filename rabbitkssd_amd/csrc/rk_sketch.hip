@@ -315,19 +315,20 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
         // bitmaps are symmetric under reverse complement and stored pre-complemented, so x indexes
         // them directly: bitmap A on the low bits.
         auto probe_a = [&](const Blk &o) -> uint32_t {
-            uint32_t maybe = 0;
+            uint32_t acc = 0;
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 // bit x[18:0] of bitmap A: the word's byte offset (x >> 5) * 4 is cut straight out of
-                // the base string (one funnel shift + mask), the bit position is x[4:0] (v_bfe reads
-                // only the low 5 bits of its offset operand): 6 VALU per window
+                // the base string (one funnel shift + mask), the bit position is x[4:0] (a variable shift reads
+                // only the low 5 bits of its operand), and the bit enters the result from the top through a
+                // funnel shift, which needs no masking: 5 VALU per window
                 const int sh = 2 * (33 + j - k) + out2;
                 const uint32_t x = ext96_lo(o.G, o.G1, o.G2, sh);
                 const uint32_t off = ext96_lo(o.G, o.G1, o.G2, sh + 3) & off_mask;
                 const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(bmA) + off);
-                maybe |= __builtin_amdgcn_ubfe(word, x, 1) << j;
+                acc = __builtin_amdgcn_alignbit(word >> (x & 31u), acc, 1);
             }
-            return maybe;
+            return acc >> 16;  // window j at bit j
         };
         // level 2 (1.6-3 % of the windows): bitmap B on the high bits; the ~0.2 % that pass both are queued.
         // Returns the windows this lane queued.
