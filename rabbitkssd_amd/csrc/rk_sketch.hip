@@ -199,7 +199,10 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
 
     const int k = KS ? KS : a.kmer;
     const int out2 = KS ? OUT2 : a.out2;
-    const uint32_t dim_mask = (1u << a.dim_bits) - 1;
+    // 4 * half_subk inner bits; a compile-time constant in the specialised kernels (k - 2 * outer context bases)
+    const int dim_bits = KS ? 2 * KS - 2 * OUT2 : a.dim_bits;
+    const int hi_shift = KS ? (2 * KS - 2 * OUT2 > Img<IMG>::kBitsB ? 2 * KS - 2 * OUT2 - Img<IMG>::kBitsB : 0) : a.hi_shift;
+    const uint32_t dim_mask = (1u << dim_bits) - 1;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     unsigned long long windows = 0;
@@ -340,10 +343,15 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
                 const int j = __ffs((int)maybe) - 1;
                 maybe &= maybe - 1;
                 const int sh = 2 * (33 + j - k) + out2;  // 2..94
-                const uint32_t wa = sh < 32 ? G2 : (sh < 64 ? G1 : G);
-                const uint32_t wb = sh < 32 ? G1 : (sh < 64 ? G : 0u);
-                const uint32_t x = __builtin_amdgcn_alignbit(wb, wa, sh & 31) & dim_mask;
-                const uint32_t ib = x >> a.hi_shift;
+                uint32_t x;
+                if (KS && 2 * (33 - KS) + OUT2 >= 32) {  // every window's inner bases start in G1 or G: one 64-bit shift
+                    x = (uint32_t)(((((uint64_t)G) << 32) | G1) >> (sh - 32));
+                } else {
+                    const uint32_t wa = sh < 32 ? G2 : (sh < 64 ? G1 : G);
+                    const uint32_t wb = sh < 32 ? G1 : (sh < 64 ? G : 0u);
+                    x = __builtin_amdgcn_alignbit(wb, wa, sh & 31);
+                }
+                const uint32_t ib = (x & dim_mask) >> hi_shift;
                 if (!((bmB[ib >> 5] >> (ib & 31)) & 1u)) continue;
                 const uint64_t W = ext96v(G, G1, G2, 2 * (33 + j - k)) & a.tupmask;
                 const uint32_t sl = atomicAdd(stage_n, 1u);
