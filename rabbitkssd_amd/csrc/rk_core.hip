@@ -175,6 +175,9 @@ int rk_ctx_create(int device, rk_ctx **out)
     ctx->sw_dist_cand_cap = env_u32("RK_DIST_CAND_CAP", 0);
     ctx->sw_dist_stage_hits = env_u32("RK_DIST_STAGE_HITS", 0);
     ctx->sw_dist_xcd_rows = env_u32("RK_DIST_XCD_ROWS", 0);
+    ctx->sw_dist_bands = getenv("RK_DIST_BANDS") ? atoi(getenv("RK_DIST_BANDS")) != 0 : 1;
+    if (getenv("RK_DIST_BAND_MIN_ROWS")) ctx->sw_dist_band_min_rows = std::max(1, atoi(getenv("RK_DIST_BAND_MIN_ROWS")));
+    if (getenv("RK_DIST_LDS_KB")) ctx->sw_dist_lds_kb = std::max(0, atoi(getenv("RK_DIST_LDS_KB")));
     ctx->sw_sketch_img = getenv("RK_SKETCH_IMG") ? atoi(getenv("RK_SKETCH_IMG")) != 0 : 1;
     *out = ctx;
     return RK_OK;

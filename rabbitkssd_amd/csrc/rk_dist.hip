@@ -19,6 +19,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <tuple>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -49,6 +51,8 @@ struct DistArgs {
     const uint64_t *range_split; // pair mode: u64[n_query], a row's slices from here on are covered by its partner
     uint32_t n_query, n_ref;
     uint32_t row_first, row_step, row_block, units_per_block, n_units;
+    uint32_t slot_base;          // this launch covers the unit slots slot_base .. slot_base + n_units of the shard (a band of rows)
+    uint32_t col_base;           // first column of the LDS rows: a band of the self join only needs the columns behind its first row
     uint32_t tile_cols, cnt_words, pair_stride, units_per_wg, runs_per_chunk;
     int persist;                 // 1: as many workgroups as the chip holds, each walks its share of the units
     uint32_t units_per_xcd, units_per_chunk;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     const bool dynamic = a.persist != 0;
     const uint32_t slot0 = run * a.units_per_wg;
     if (!dynamic && slot0 >= a.n_units) return;
-    const uint32_t col0 = blockIdx.y * a.tile_cols;
+    const uint32_t col0 = a.col_base + blockIdx.y * a.tile_cols;
     const uint32_t col1 = min(a.n_ref, col0 + a.tile_cols);
     const uint32_t ncol = col1 - col0;
     if (tid == 0) {
@@ -190,6 +194,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     // (block-cyclic; row_block 1 = plain interleave): this rank owns blocks row_first,
     // row_first + row_step, ...
     auto unit_row = [&](uint32_t slot) -> uint32_t {
+        slot += a.slot_base;
         const uint32_t upb = a.units_per_block;
         const uint32_t t = upb == 1 ? slot : slot / upb;
         const uint32_t r = slot - t * upb;
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
             // self join: only columns behind the row are ever incremented and only they are scanned, so only they are
             // zeroed (a workgroup takes its rows in ascending order; what an earlier row left further left is never read)
             const uint32_t row_quads = (a.pair_stride / kPerWord) / 4;
-            const uint32_t q0 = ((row + 1) / kPerWord) / 4;
+            const uint32_t q0 = ((row + 1 - col0) / kPerWord) / 4;
             const uint32_t span = row_quads - min(q0, row_quads);
             for (uint32_t i = tid; i < span * (PAIR ? 2u : 1u); i += kDistThreads) {
                 const uint32_t which = PAIR && i >= span ? 1u : 0u;
@@ -752,6 +757,7 @@ struct Plan {
     uint32_t n_units, tile_cols, n_tiles, cnt_words, row_words;
     uint32_t cand_cap, stage_hits, units_per_wg, threads;
     uint32_t row_first, row_step, row_block, units_per_block;
+    uint32_t slot_base, col_base;  // a band of the self join: its first unit slot and the first column of its LDS rows
     bool persist;
     size_t lds_bytes;
     int dense_mode, mode;
@@ -759,8 +765,9 @@ struct Plan {
 };
 
 // want_self: the ranges are the index's own "later genomes" slices (self join, triangle, no dense output)
+// n_cols: columns an LDS row must hold (the whole reference range, or what lies behind a band's first row)
 int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_query_size,
-              const rk_dist_opts *o, bool want_self, Plan *p)
+              const rk_dist_opts *o, bool want_self, uint32_t n_cols, Plan *p)
 {
     if (o->kmer_size <= 0) return rk_fail(ctx, RK_ERR_ARG, "kmer_size must be positive");
     if (o->row_block < 0) return rk_fail(ctx, RK_ERR_ARG, "row_block must be >= 0");
@@ -768,11 +775,12 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // two 16-bit counters per word when no count can overflow: a count never exceeds the query sketch as long as
     // no genome sits twice in a posting list (sketches with repeated hashes fall back to 32-bit counters)
     p->u16 = idx->ref_sets && max_query_size < 65536;
+    p->slot_base = p->col_base = 0;
     p->cand_cap = ((ctx->sw_dist_cand_cap ? ctx->sw_dist_cand_cap : kCandCapDefault) + 1) & ~1u;
     // Persistent workgroups (one tile, >= 512 threads: with 256-thread workgroups one run of two rows
     // per workgroup measured better, 0.134 vs 0.145 ms) live long, so they stage more hits before the
     // one flush at their end.  Capacity decisions below assume the bigger staging area.
-    const uint64_t one_row = (uint64_t)idx->n_ref * (p->u16 ? 2 : 4);
+    const uint64_t one_row = (uint64_t)n_cols * (p->u16 ? 2 : 4);
     const bool small_rows = one_row + (size_t)p->cand_cap * sizeof(uint2) + kStageHitsDefault * sizeof(rk_hit) + 64 <= 24 * 1024;
     p->persist = idx->n_ref && ctx->sw_dist_persist != 2;
     p->stage_hits = ctx->sw_dist_stage_hits ? ctx->sw_dist_stage_hits : 4 * kStageHitsDefault;
@@ -780,22 +788,24 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // lists of 16-byte entries and evaluate across units (kernel: BATCH).  Tiles are sized for the bigger layout.
     const size_t batch_extra = 2 * (size_t)p->cand_cap * sizeof(uint4) - (size_t)p->cand_cap * sizeof(uint2);
     size_t fixed = (size_t)p->cand_cap * sizeof(uint2) + p->stage_hits * sizeof(rk_hit) + 64;
-    const size_t lds_cap = (ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds) - fixed - batch_extra;
+    size_t lds_cu = ctx->max_lds > 160 * 1024 ? 160 * 1024 : ctx->max_lds;
+    if (ctx->sw_dist_lds_kb && (size_t)ctx->sw_dist_lds_kb * 1024 < lds_cu) lds_cu = std::max<size_t>((size_t)ctx->sw_dist_lds_kb * 1024, fixed + batch_extra + 1024);
+    const size_t lds_cap = lds_cu - fixed - batch_extra;
     const uint32_t max_cols = (uint32_t)(p->u16 ? lds_cap / 2 : lds_cap / 4) & ~63u;
-    uint32_t tile = idx->n_ref ? idx->n_ref : 1;
+    uint32_t tile = n_cols ? n_cols : 1;
     if (tile > max_cols) {
-        const uint32_t nt = (idx->n_ref + max_cols - 1) / max_cols;
-        tile = ((idx->n_ref + nt - 1) / nt + 63) & ~63u;
+        const uint32_t nt = (n_cols + max_cols - 1) / max_cols;
+        tile = ((n_cols + nt - 1) / nt + 63) & ~63u;
     }
     p->tile_cols = tile;
-    p->n_tiles = idx->n_ref ? (idx->n_ref + tile - 1) / tile : 1;
+    p->n_tiles = n_cols ? (n_cols + tile - 1) / tile : 1;
     p->row_words = ((p->u16 ? (tile + 1) / 2 : tile) + 3) & ~3u;  // whole 16-byte quads
 
     // row distribution: blocks of row_block rows dealt round-robin to row_step shards
     p->row_step = o->row_step ? o->row_step : 1;
     p->row_first = o->row_first;
     p->row_block = o->row_block > 0 ? (uint32_t)o->row_block : 1;
-    if (p->row_step == 1 && p->row_first == 0) p->row_block = std::max<uint32_t>(2, (n_query + 1) & ~1u);  // all rows: one block
+    if (p->row_step == 1 && p->row_first == 0) p->row_block = kRowsPerXcdChunk;  // all rows: every block is this shard's
     p->mode = want_self && p->n_tiles == 1 ? kSelf : kFiltered;
     // pairs of neighbouring rows: blocks must hold whole pairs and two rows must fit in LDS next to
     // each other with room for at least three workgroups per CU (measured: with fewer, the lost
@@ -851,6 +861,8 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.row_block = p.row_block;
     a.units_per_block = p.units_per_block;
     a.n_units = p.n_units;
+    a.slot_base = p.slot_base;
+    a.col_base = p.col_base;
     a.tile_cols = p.tile_cols;
     a.cnt_words = p.cnt_words;
     a.pair_stride = p.row_words * (p.u16 ? 2 : 1);
@@ -913,6 +925,67 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     return RK_OK;
 }
 
+// Bands of the self join.  Row i only counts in the columns behind it, so the rows of a shard are cut into bands whose
+// LDS rows start at the band's first row: the later the band, the shorter its rows, the more workgroups share a CU --
+// and where two rows fit next to each other, neighbouring rows pair up.  (50,000 genomes: rows 0-12k need the whole
+// 100 KB row and one 1,024-thread workgroup per CU; from row ~39k on the kernel runs as it does for 10,000 genomes.)
+// A boundary lies where the kernel variant changes (threads, mode, tiles) and at a multiple of row_step * row_block rows,
+// so that a band is a contiguous range of the shard's unit slots.
+
+int plan_bands(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, std::vector<Plan> *bands)
+{
+    const uint32_t n = idx->n_ref;
+    Plan cur;
+    int rc = make_plan(ctx, idx, n, idx->max_src_size, o, true, n, &cur);
+    if (rc) return rc;
+    bands->clear();
+    const uint64_t round_rows = (uint64_t)cur.row_step * cur.row_block;  // one block of every shard
+    const uint64_t n_rounds = ((uint64_t)n + round_rows - 1) / round_rows;
+    const uint64_t min_rounds = std::max<uint64_t>(1, ((uint64_t)ctx->sw_dist_band_min_rows + round_rows - 1) / round_rows);
+    auto plan_at = [&](uint64_t round, Plan *q) -> int {
+        const uint64_t row = round * round_rows;
+        const uint32_t col_base = (uint32_t)row & ~63u;  // whole 128-byte stretches of a 16-bit row
+        int prc = make_plan(ctx, idx, n, idx->max_src_size, o, true, n - col_base, q);
+        q->col_base = col_base;
+        q->slot_base = (uint32_t)(round * q->units_per_block);
+        return prc;
+    };
+    auto differs = [&](const Plan &x, const Plan &y) { return x.threads != y.threads || x.mode != y.mode || x.n_tiles != y.n_tiles; };
+    uint64_t t0 = 0;
+    while (ctx->sw_dist_bands && !rk_dense_mode(o)) {
+        const uint64_t lo = t0 + min_rounds;
+        if (lo + min_rounds > n_rounds) break;
+        uint64_t hi = n_rounds - min_rounds;  // lo <= hi
+        Plan q;
+        if ((rc = plan_at(hi, &q))) return rc;
+        if (!differs(q, cur)) break;
+        uint64_t a = lo;  // smallest round in [lo, hi] whose plan differs (the variant only ever changes one way)
+        while (a < hi) {
+            const uint64_t mid = (a + hi) / 2;
+            if ((rc = plan_at(mid, &q))) return rc;
+            if (differs(q, cur)) hi = mid; else a = mid + 1;
+        }
+        cur.n_units = (uint32_t)((a - t0) * cur.units_per_block);
+        bands->push_back(cur);
+        if ((rc = plan_at(a, &cur))) return rc;
+        t0 = a;
+    }
+    cur.n_units = cur.n_units > cur.slot_base ? cur.n_units - cur.slot_base : 0;  // to the end of the shard
+    bands->push_back(cur);
+    return RK_OK;
+}
+
+int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, rk_hit *hits_dev, uint64_t cap,
+                unsigned long long *n_hits_dev, hipStream_t stream)
+{
+    std::vector<Plan> bands;
+    int rc = plan_bands(ctx, idx, o, &bands);
+    for (size_t b = 0; !rc && b < bands.size(); b++)
+        rc = launch_dist(ctx, idx, idx->d_selfrange, idx->d_self_off, idx->d_src_off, idx->n_ref, o, bands[b], hits_dev, cap,
+                         n_hits_dev, nullptr, stream);
+    return rc;
+}
+
 }  // namespace
 
 #ifdef RK_DIST_PROFILE
@@ -943,10 +1016,14 @@ int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *que
 {
     if (!ctx || !idx || !opts || !buf || !cap) return RK_ERR_ARG;
     if (queries) return rk_distq_kernel_name(ctx, idx, queries, buf, cap);
-    Plan p;
-    int rc = make_plan(ctx, idx, idx->n_ref, idx->max_src_size, opts, true, &p);
+    std::vector<Plan> bands;  // several bands: the variant of the first (widest rows)
+    int rc = plan_bands(ctx, idx, opts, &bands);
     if (rc) return rc;
-    snprintf(buf, cap, "rk_dist_kernel<%s, %d, %u>", p.u16 ? "true" : "false", p.mode, p.threads);
+    const Plan &p = bands[0];
+    if (bands.size() > 1)
+        snprintf(buf, cap, "rk_dist_kernel<%s, %d, %u> [%u bands]", p.u16 ? "true" : "false", p.mode, p.threads, (unsigned)bands.size());
+    else
+        snprintf(buf, cap, "rk_dist_kernel<%s, %d, %u>", p.u16 ? "true" : "false", p.mode, p.threads);
     return RK_OK;
 }
 
@@ -965,11 +1042,7 @@ int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *querie
     }
     if (!opts->triangle || !idx->d_selfrange)
         return rk_fail(ctx, RK_ERR_ARG, "queries == NULL needs triangle=1 and an index built by rk_index_build");
-    Plan p;
-    int rc = make_plan(ctx, idx, idx->n_ref, idx->max_src_size, opts, true, &p);
-    if (rc) return rc;
-    return launch_dist(ctx, idx, idx->d_selfrange, idx->d_self_off, idx->d_src_off, idx->n_ref, opts, p, hits_dev,
-                       hits_cap, (unsigned long long *)n_hits_dev, nullptr, (hipStream_t)stream);
+    return launch_self(ctx, idx, opts, hits_dev, hits_cap, (unsigned long long *)n_hits_dev, (hipStream_t)stream);
 }
 
 int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
@@ -987,12 +1060,7 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
     if (opts->triangle && n_query != idx->n_ref)
         return rk_fail(ctx, RK_ERR_ARG, "triangle mode needs the indexed sketches as queries (%u vs %u)",
                        n_query, idx->n_ref);
-    Plan p;
     int rc = RK_OK;
-    if (self) {
-        rc = make_plan(ctx, idx, n_query, idx->max_src_size, opts, true, &p);
-        if (rc) return rc;
-    }
     const bool dense_mode = rk_dense_mode(opts);
     hipStream_t stream = ctx->stream;
 
@@ -1023,8 +1091,7 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
                            (unsigned long long)cap);
         RK_HIP(ctx, hipMemsetAsync(counter.p, 0, 8, stream));
         if (self)
-            rc = launch_dist(ctx, idx, idx->d_selfrange, idx->d_self_off, idx->d_src_off, n_query, opts, p, hits.p, cap,
-                             counter.p, nullptr, stream);
+            rc = launch_self(ctx, idx, opts, hits.p, cap, counter.p, stream);
         else
             rc = rk_distq_launch(ctx, idx, queries, opts, hits.p, cap, counter.p, common_dense ? dense.p : nullptr, stream);
         if (rc) return rc;

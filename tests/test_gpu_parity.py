@@ -154,19 +154,62 @@ def test_block_cyclic_row_sharding_union_equals_full(ctx, n, block, world):
 
 
 def test_pair_kernel_equals_single_row_kernel(ctx, monkeypatch):
-    # the same self join through the pair kernel (default) and the single-row kernel (RK_DIST_PAIR=2)
+    # the same self join through the pair kernel (default) and the single-row kernel (RK_DIST_PAIR=2; the developer
+    # switches are read when a context is created)
     names, h, off = synth.clade_sketches(777, 300, 24, seed=23)
+    monkeypatch.setenv("RK_DIST_PAIR", "2")
+    ctx1 = capi.Context(0)
+    monkeypatch.delenv("RK_DIST_PAIR")
     idx = ctx.index_build(ctx.sketches_from_host(h, off), 24)
+    idx1 = ctx1.index_build(ctx1.sketches_from_host(h, off), 24)
+    assert ", 2, " in ctx.dist_kernel_name(idx, None, 1, 0, 20, 0.05) and ", 1, " in ctx1.dist_kernel_name(idx1, None, 1, 0, 20, 0.05)
     postings, counts = ok.index_build32(h, off, 24)
     sizes = np.diff(off).astype(np.uint32)
     for metric, D in ((0, 0.05), (1, 0.02), (0, 0.5)):
         want, _ = ok.index_dist32(counts, 24, postings, sizes, h, off, 1, metric, 20, D, threads=4)
         pair, _ = ctx.dist_rows(idx, None, 1, metric, 20, D)
-        monkeypatch.setenv("RK_DIST_PAIR", "2")
-        single, _ = ctx.dist_rows(idx, None, 1, metric, 20, D)
-        monkeypatch.delenv("RK_DIST_PAIR")
+        single, _ = ctx1.dist_rows(idx1, None, 1, metric, 20, D)
         assert_hits_equal(pair, want)
         assert_hits_equal(single, want)
+    del idx1
+    ctx1.close()
+
+
+@pytest.mark.parametrize("n,lds_kb,world", [(12000, 0, 1), (8000, 24, 1), (12000, 0, 3), (9000, 20, 2)])
+def test_self_join_in_bands(monkeypatch, n, lds_kb, world):
+    """Row i only counts in the columns behind it: the rows are cut into bands whose LDS rows start at the band's first
+    row (tiled -> single rows -> row pairs as the rows get shorter).  Developer switches bring the band boundaries
+    down to test sizes; the result must equal the oracle's and the one-launch path's, also per shard."""
+    names, h, off = synth.clade_sketches(n, 40, 24, seed=37)
+    monkeypatch.setenv("RK_DIST_BAND_MIN_ROWS", "256")
+    if lds_kb:
+        monkeypatch.setenv("RK_DIST_LDS_KB", str(lds_kb))
+    banded = capi.Context(0)
+    monkeypatch.setenv("RK_DIST_BANDS", "0")
+    plain = capi.Context(0)
+    for v in ("RK_DIST_BAND_MIN_ROWS", "RK_DIST_BANDS"):
+        monkeypatch.delenv(v)
+    ib = banded.index_build(banded.sketches_from_host(h, off), 24)
+    ip = plain.index_build(plain.sketches_from_host(h, off), 24)
+    name_b, name_p = banded.dist_kernel_name(ib, None, 1, 0, 20, 0.05), plain.dist_kernel_name(ip, None, 1, 0, 20, 0.05)
+    assert "bands]" in name_b and "bands]" not in name_p, (name_b, name_p)
+    postings, counts = ok.index_build32(h, off, 24)
+    sizes = np.diff(off).astype(np.uint32)
+    for metric, D in ((0, 0.05), (1, 0.2)):
+        want, _ = ok.index_dist32(counts, 24, postings, sizes, h, off, 1, metric, 20, D, threads=8)
+        assert len(want) > n
+        if world == 1:
+            assert_hits_equal(banded.dist_rows(ib, None, 1, metric, 20, D)[0], want)
+            assert_hits_equal(plain.dist_rows(ip, None, 1, metric, 20, D)[0], want)
+        else:
+            parts = [banded.dist_rows(ib, None, 1, metric, 20, D, row_first=r, row_step=world, row_block=16)[0] for r in range(world)]
+            for r, p in enumerate(parts):
+                assert np.all((p["row"] // 16) % world == r)
+            merged = np.concatenate(parts)
+            assert_hits_equal(merged[np.lexsort((merged["col"], merged["row"]))], want)
+    del ib, ip
+    banded.close()
+    plain.close()
 
 
 def test_self_join_of_big_sketches_uses_32bit_counters_in_pairs(ctx):

@@ -52,16 +52,20 @@ def values(summ):
     return vals
 
 
-def main(tag):
-    d = json.loads(open(os.path.join(OUT, "bench_r2.json")).read().strip().split("\n")[-1])
-    json.dump(d, open(os.path.join(PROF, tag + "_bench.json"), "w"))
-    f = glob.glob(os.path.join(OUT, "prof_final", "**", "*kernel_stats.csv"), recursive=True)[0]
-    with open(os.path.join(PROF, tag + "_bench_kernel_stats.csv"), "w") as o:
-        o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline "
-                "(MI355X, tools/measure_round.sh)\nName,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
-        for r in csv.DictReader(open(f)):
-            o.write('"%s",%s,%s,%s,%s,%s,%s\n' % (short_name(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
-                                                  r["Percentage"], r["MinNs"], r["MaxNs"]))
+def main(tag, traffic_only=False):
+    """traffic_only: on the GPU box, between the counter passes and bench.py, so that the bench line of a round
+    carries the counter traffic measured in the same call"""
+    d = None
+    if not traffic_only:
+        d = json.loads(open(os.path.join(OUT, "bench_r2.json")).read().strip().split("\n")[-1])
+        json.dump(d, open(os.path.join(PROF, tag + "_bench.json"), "w"))
+        f = glob.glob(os.path.join(OUT, "prof_final", "**", "*kernel_stats.csv"), recursive=True)[0]
+        with open(os.path.join(PROF, tag + "_bench_kernel_stats.csv"), "w") as o:
+            o.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline "
+                    "(MI355X, tools/measure_round.sh)\nName,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+            for r in csv.DictReader(open(f)):
+                o.write('"%s",%s,%s,%s,%s,%s,%s\n' % (short_name(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                                                      r["Percentage"], r["MinNs"], r["MaxNs"]))
     groups = {"dist": sorted(glob.glob(os.path.join(OUT, "pmcD_*"))),
               "rq": sorted(glob.glob(os.path.join(OUT, "pmcQ_*"))),
               "sketch": sorted(glob.glob(os.path.join(OUT, "pmcSk_*")) + glob.glob(os.path.join(OUT, "pmcS_*"))),
@@ -98,9 +102,12 @@ def main(tag):
     t_d = traffic(groups["dist"], "rk_dist_kernel", "pmc_traffic.json", "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X", True)
     t_q = traffic(groups["rq"], "rk_distq_kernel", "pmc_traffic_rq.json", "dist 100,000 refs x 1,000 queries (tools/prof_driver.py dist_rq_dev), MI355X", False)
     t_s = traffic(groups["sketch"], "rk_sketch_kernel", "pmc_traffic_sketch.json", "sketch 128 x 5 Mb (tools/prof_driver.py sketch 128 5000000), MI355X", True)
-    print("value %.4g %s, %.4f ms/step, contract frac %.3f; traffic dist %s rq %s sketch %s B/launch" % (
-        d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], t_d, t_q, t_s))
+    print("traffic dist %s rq %s sketch %s B/launch" % (t_d, t_q, t_s))
+    if d:
+        print("value %.4g %s, %.4f ms/step, contract frac %.3f, hbm frac %s" % (
+            d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("hbm_frac")))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
+    args = [x for x in sys.argv[1:] if not x.startswith("--")]
+    main(args[0] if args else "r02", "--traffic-only" in sys.argv)
