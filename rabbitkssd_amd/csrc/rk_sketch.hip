@@ -442,7 +442,9 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
 // (bitonic), equal neighbours collapse (FASTQ: a hash survives only with >= min_count occurrences, :828-845), and
 // the sorted distinct hashes are written back coalesced together with their number.  Replaces the ~20 launches
 // of a device-wide radix sort + unique + split that doubled the device time of a batch in round 1.
-constexpr uint32_t kDedupThreads = 256;
+// 16 waves per genome: a step of the sort is ~35 dependent instructions per wave, and one wave per SIMD issues them
+// one every few cycles (256 threads: 41 us for 128 genomes of ~1,250 candidates; 1,024: see DESIGN.md 4.1)
+constexpr uint32_t kDedupThreads = 1024;
 constexpr uint32_t kDedupMaxBytes = 64 * 1024;  // LDS sort capacity: 16,384 32-bit or 8,192 64-bit keys
 
 enum : uint32_t { kFlagOverflow = 1 };
@@ -476,6 +478,11 @@ __global__ __launch_bounds__(kDedupThreads) void k_dedup(const unsigned long lon
     // padding keys are all ones: they sort behind every real key (or tie with it), so the first n are the real ones
     for (uint32_t i = tid; i < P; i += kDedupThreads) a[i] = i < n ? (K)src[i] : (K)~(K)0;
     __syncthreads();
+    // Pair t compares elements (i, i + j).  A wave owns pairs 64w .. 64w+63 (+ multiples of the workgroup size): for
+    // j <= 64 these are exactly the elements 128w .. 128w+127, in every such step -- the wave only ever meets its own
+    // earlier writes, and LDS operations of one wave complete in order.  Only the steps that reach across 128-element
+    // blocks (j >= 128), and the step before one, end with a workgroup barrier: 10 of the 66 steps for 2,048 keys.
+    static_assert(kDedupThreads % 64 == 0, "whole waves");
     for (uint32_t k = 2; k <= P; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = tid; t < P / 2; t += kDedupThreads) {
@@ -487,8 +494,10 @@ __global__ __launch_bounds__(kDedupThreads) void k_dedup(const unsigned long lon
                     a[i + j] = x;
                 }
             }
-            __syncthreads();
+            if (j >= 128 || (j == 1 && k >= 128)) __syncthreads();
+            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+    __syncthreads();
     // run heads that are kept; every thread owns a contiguous stretch so that the output stays sorted
     const uint32_t per = (n + kDedupThreads - 1) / kDedupThreads;
     const uint32_t i0 = min(n, tid * per), i1 = min(n, i0 + per);
