@@ -320,7 +320,7 @@ def sketch_block(env, n_genomes, length, steps=5):
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": sk_kernel,
                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg,
-                        "limiter": "VALU issue (integer): 76 % of the SIMD cycles issue vector instructions at 8 waves per SIMD "
+                        "limiter": "VALU issue (integer): 192 vector instructions per wave and 1,024 bases; 73 % of the SIMD cycles issue one, at 8 waves per SIMD "
                                    "(profiles/r02_pmc_summary.csv, DESIGN.md 4.1)"}}
     pmc = load_pmc(sk_kernel, "pmc_traffic_sketch.json")
     if pmc:
