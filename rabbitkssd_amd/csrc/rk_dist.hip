@@ -181,6 +181,15 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         s_cursor = 0;
         s_ncand[0] = s_ncand[1] = 0;
     }
+    // Self join, sparse report: the rows are zeroed ONCE.  A unit only increments cells behind its diagonal, its scan
+    // covers exactly that stretch and clears every non-zero quad it meets, so the rows are clean again when the next unit
+    // scatters: no zero pass and one barrier less per unit (the scan's barrier also fences the next scatter).
+    const bool keep_clean = !FILTER && !a.dense_mode;
+    if (keep_clean) {
+        uint4 *z = reinterpret_cast<uint4 *>(cnt);
+        for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
 
     const uint32_t sub = lane & 3;  // lane of the quad
     const bool tri_filter = a.triangle && !a.common_dense;
@@ -281,10 +290,10 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     // The scan therefore only APPENDS (row, column, common, |row|) to the current list; once a list is half full it is
     // evaluated by the whole workgroup, one cell per lane, and the other list takes over.
     uint32_t ccur = 0;  // uniform: the list the scans append to
-    auto eval_list = [&](uint32_t which, uint32_t n, uint32_t skip_a, uint32_t skip_b) {
+    auto eval_list = [&](uint32_t which, uint32_t n) {
         for (uint32_t i = tid; i < n; i += kDistThreads) {
             const uint4 e = cand[which * kCandCap + i];
-            if (e.x >= 0xFFFFFFFEu || e.x == skip_a || e.x == skip_b) continue;  // placeholder / the caller walks these rows itself
+            if (e.x == kNone) continue;  // a cell outside the triangle / the tile
             rk_hit hrec;
             if (evaluate(e.x, (int)e.w, e.y, (int)e.z, hrec)) stage_hit(hrec);
         }
@@ -314,6 +323,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
             if (j >= jbeg && j < col1 && evaluate(row, in_b ? qsize_b : qsize_a, j, (int)common, hrec)) stage_hit(hrec);
         };
         const uint32_t jbeg_a = a.triangle ? max(col0, row_a + 1) : col0;
+        uint4 *z4s = reinterpret_cast<uint4 *>(cnt);
         const uint32_t cells_end = has_b ? row_b_cell + ncol : ncol;   // cells in use
         // row-level reject while scanning: a reportable cell needs common >= min_jorc * denominator, and the
         // denominator is at least the row's sketch size (jaccard) / min(row, smallest non-empty sketch) (containment):
@@ -352,8 +362,14 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                         if (U16) n += ((w[wi] & 0xFFFFu) >= minc) + ((w[wi] >> 16) >= minc);
                         else n += w[wi] >= minc;
                     }
-                    if (!n) continue;
+                    if (!n) {
+                        if (keep_clean) z4s[q] = make_uint4(0, 0, 0, 0);
+                        continue;
+                    }
                     uint32_t at = atomicAdd(&s_ncand[ccur], n);
+                    // a quad whose cells do not all fit stays in the row (and is not cleared): the walk below finds it
+                    const bool fits = at + n <= kCandCap;
+                    if (keep_clean && fits) z4s[q] = make_uint4(0, 0, 0, 0);
                     const bool in_b = PAIR && cq >= row_b_cell;
                     const uint32_t erow = in_b ? row_b : row_a;
                     const uint32_t eq = (uint32_t)(in_b ? qsize_b : qsize_a);
@@ -369,7 +385,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                                 // (cells left of the diagonal / beyond the tile are never non-zero; an entry that fails
                                 // the test still occupies its slot, with a row no unit has)
                                 if (at < kCandCap)
-                                    cand[ccur * kCandCap + at] = make_uint4(j >= jbeg && j < col1 ? erow : kNone - 1, j, common, eq);
+                                    cand[ccur * kCandCap + at] = make_uint4(fits && j >= jbeg && j < col1 ? erow : kNone, j, common, eq);
                                 at++;
                             }
                         }
@@ -380,18 +396,22 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                 PROF_MARK(3);
                 const uint32_t n_cells = s_ncand[ccur];
                 if (n_cells > kCandCap) {
-                    // this unit brought more cells than the list had room for: evaluate what the list holds of EARLIER units,
-                    // walk this unit's rows directly, and start over with the other list
-                    eval_list(ccur, kCandCap, row_a, has_b ? row_b : row_a);
+                    // this unit brought more cells than the list had room for: evaluate the list, walk what the scan left in
+                    // the rows, and start over with the other list
+                    eval_list(ccur, kCandCap);
                     for (uint32_t c = (jbeg_a - col0) + tid; c < cells_end; c += kDistThreads) {
                         const uint32_t common = cell(c);
                         if (common >= (PAIR && c >= row_b_cell ? minc_b : minc_a)) eval_cell(c, common);
                     }
                     if (tid == 0) s_ncand[ccur ^ 1] = 0;
                     ccur ^= 1;
-                    __syncthreads();  // the rows are zeroed next
+                    __syncthreads();
+                    if (keep_clean) {  // the leftovers
+                        for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4s[i] = make_uint4(0, 0, 0, 0);
+                        __syncthreads();
+                    }
                 } else if (n_cells >= a.cand_flush) {
-                    eval_list(ccur, n_cells, kNone - 1, kNone - 1);
+                    eval_list(ccur, n_cells);
                     if (tid == 0) s_ncand[ccur ^ 1] = 0;  // (its entries were evaluated at least one unit ago)
                     ccur ^= 1;
                 }
@@ -416,15 +436,21 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                         if (U16) n += ((w[wi] & 0xFFFFu) >= minc) + ((w[wi] >> 16) >= minc);
                         else n += w[wi] >= minc;
                     }
-                    if (!n) continue;
+                    if (!n) {
+                        if (keep_clean) z4s[q] = make_uint4(0, 0, 0, 0);
+                        continue;
+                    }
                     uint32_t at = atomicAdd(&s_ncand[par], n);
+                    // a quad whose cells do not all fit stays in the row (and is not cleared): the walk below finds it
+                    const bool fits = at + n <= kCandCap;
+                    if (keep_clean && fits) z4s[q] = make_uint4(0, 0, 0, 0);
 #pragma unroll
                     for (int wi = 0; wi < 4; wi++) {
 #pragma unroll
                         for (uint32_t h = 0; h < kPerWord; h++) {
                             const uint32_t common = U16 ? (w[wi] >> (16 * h)) & 0xFFFFu : w[wi];
                             if (common >= minc) {
-                                if (at < kCandCap) cand2[at] = make_uint2(cq + wi * kPerWord + h, common);
+                                if (at < kCandCap) cand2[at] = make_uint2(fits ? cq + wi * kPerWord + h : kNone, common);
                                 at++;
                             }
                         }
@@ -434,18 +460,21 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                 __syncthreads();
                 PROF_MARK(3);
                 const uint32_t n_cells = s_ncand[par];
-                if (n_cells <= kCandCap) {
-                    for (uint32_t i = tid; i < n_cells; i += kDistThreads) {
-                        const uint2 cj = cand2[i];
-                        eval_cell(cj.x, cj.y);
-                    }
-                } else {
-                    // more sharing columns than the list holds: walk the rows, one cell per lane
+                for (uint32_t i = tid; i < min(n_cells, kCandCap); i += kDistThreads) {
+                    const uint2 cj = cand2[i];
+                    if (cj.x != kNone) eval_cell(cj.x, cj.y);
+                }
+                if (n_cells > kCandCap) {
+                    // more cells than the list holds: walk what the scan left in the rows, one cell per lane
                     for (uint32_t c = (jbeg_a - col0) + tid; c < cells_end; c += kDistThreads) {
                         const uint32_t common = cell(c);
                         if (common >= (PAIR && c >= row_b_cell ? minc_b : minc_a)) eval_cell(c, common);
                     }
                     __syncthreads();  // the rows are zeroed next
+                    if (keep_clean) {
+                        for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4s[i] = make_uint4(0, 0, 0, 0);
+                        __syncthreads();
+                    }
                 }
             }
             PROF_MARK(4);
@@ -540,25 +569,26 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         nxt.qsize_a = nxt.qsize_b = 0;
         if (nrow != kNone) open_unit(nrow, nxt);
 
-        uint4 *z4 = reinterpret_cast<uint4 *>(cnt);  // memset row (src/dist.cpp:179)
-        if (!FILTER && row != kNone) {
-            // self join: only columns behind the row are ever incremented and only they are scanned, so only they are
-            // zeroed (a workgroup takes its rows in ascending order; what an earlier row left further left is never read)
-            const uint32_t row_quads = (a.pair_stride / kPerWord) / 4;
-            const uint32_t q0 = ((row + 1 - col0) / kPerWord) / 4;
-            const uint32_t span = row_quads - min(q0, row_quads);
-            for (uint32_t i = tid; i < span * (PAIR ? 2u : 1u); i += kDistThreads) {
-                const uint32_t which = PAIR && i >= span ? 1u : 0u;
-                z4[which * row_quads + q0 + (i - which * span)] = make_uint4(0, 0, 0, 0);
+        if (!keep_clean) {
+            uint4 *z4 = reinterpret_cast<uint4 *>(cnt);  // memset row (src/dist.cpp:179)
+            if (!FILTER && row != kNone) {
+                // self join: only columns behind the row are ever incremented and only they are read
+                const uint32_t row_quads = (a.pair_stride / kPerWord) / 4;
+                const uint32_t q0 = ((row + 1 - col0) / kPerWord) / 4;
+                const uint32_t span = row_quads - min(q0, row_quads);
+                for (uint32_t i = tid; i < span * (PAIR ? 2u : 1u); i += kDistThreads) {
+                    const uint32_t which = PAIR && i >= span ? 1u : 0u;
+                    z4[which * row_quads + q0 + (i - which * span)] = make_uint4(0, 0, 0, 0);
+                }
+            } else {
+                for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
             }
-        } else {
-            for (uint32_t i = tid; i < a.cnt_words / 4; i += kDistThreads) z4[i] = make_uint4(0, 0, 0, 0);
+            if (tid == 0) {
+                s_dense = 0;
+                if (!BATCH) s_ncand[parity] = 0;  // per-unit cell counter, alternating so that a slow wave still reads its unit's
+            }
+            __syncthreads();
         }
-        if (tid == 0) {
-            s_dense = 0;
-            if (!BATCH) s_ncand[parity] = 0;  // per-unit cell counter, alternating so that a slow wave still reads its unit's
-        }
-        __syncthreads();
         PROF_MARK(6);
 
         const uint32_t lo_id = tri_filter ? row + 1 : 0;  // ids below are not needed (j > i)
@@ -725,6 +755,8 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
         }
         if (nb == 0) pre = load_slice(nxt.e0 + tid, nxt.e1);  // a unit without slices still hands over the prefetch
         __syncthreads();  // all scatters of the unit done
+        // (clean rows: the counter of the NEXT unit's list; every thread read it for the unit before this one ahead of the barrier)
+        if (keep_clean && !BATCH && tid == 0) s_ncand[parity ^ 1] = 0;
         PROF_MARK(1);
         if (row != kNone) epilogue(row, row_b, cur.qsize_a, cur.qsize_b, parity);
         parity ^= 1;
@@ -736,7 +768,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
 
     // the cells still waiting in the current list
     __syncthreads();
-    if (BATCH) eval_list(ccur, min(s_ncand[ccur], kCandCap), kNone - 1, kNone - 1);
+    if (BATCH) eval_list(ccur, min(s_ncand[ccur], kCandCap));
     // flush the staged hits of this workgroup: one device-scope atomic, coalesced 8-byte stores
     __syncthreads();
     const uint32_t n_st = min(s_cursor, kStageHits);

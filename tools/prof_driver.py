@@ -58,7 +58,7 @@ def dist(n_genomes=10000, steps=5, row_step=1, row_block=0):
         ev1.record(stream)
         t_host = time.time() - t0   # time the host needed to enqueue everything
         torch.cuda.synchronize()
-    print("dist %.3f ms/step (events; host enqueue %.3f ms/step), hits %d (row_step %d, row_block %d)" % (
+    print("dist %.4f ms/step (events; host enqueue %.3f ms/step), hits %d (row_step %d, row_block %d)" % (
         ev0.elapsed_time(ev1) / steps, t_host * 1e3 / steps, int(counters[0].item()), row_step, row_block))
 
 
