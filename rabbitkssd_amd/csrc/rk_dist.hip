@@ -656,14 +656,8 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
                 const uint32_t ma = PAIR && held_in_b ? 0u : mw;
                 const uint32_t mb = PAIR ? (held_in_b ? mw : (c_shared ? mw & ~1u : 0u)) : 0u;  // bit 0 = the partner itself
                 uint32_t ca = 0, cb = 0;
-                for (uint32_t p = 0; p < 32u && __ballot(((ma | mb) >> p) != 0); p++) {
-                    const unsigned long long ba = __ballot((ma >> p) & 1u);
-                    const unsigned long long bb = PAIR ? __ballot((mb >> p) & 1u) : 0ULL;
-                    if (lane == p) {
-                        ca = (uint32_t)__popcll(ba);
-                        cb = (uint32_t)__popcll(bb);
-                    }
-                }
+                const uint32_t occupied = wave_or(ma | mb);  // uniform: the columns any list names
+                count_columns<PAIR, 0>(occupied, ma, mb, ca, cb);
                 bump_n(base + lane, ca, false);
                 if (PAIR) bump_n(base + lane, cb, true);
                 // compact lists that reach beyond those 32 columns: lane by lane, starting at rotated bits
