@@ -125,9 +125,11 @@ __device__ unsigned long long g_prof[kProfWaves][16];  // one row per wave, summ
 // CU keeps 16-28 waves to hide the gather latency (measured at 28,284 / 50,000 columns: 768 / 1024
 // threads are 1.8x / 2.2x faster than 256).
 enum { kFiltered = 0, kSelf = 1, kSelfPair = 2 };
+constexpr int kBatchFromThreads = 512;  // workgroups of at least this many threads evaluate their cells in batches across units
 
 template <bool U16, int MODE, int THREADS>
-__global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
+// (second launch bound: waves per SIMD the plan counts on -- 3 x 512 or 2 x 768 threads per CU are 6 per SIMD, i.e. <= 80 VGPRs)
+__global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4) void rk_dist_kernel(DistArgs a)
 {
     constexpr uint32_t kDistThreads = THREADS;
     constexpr bool FILTER = MODE == kFiltered;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(THREADS) void rk_dist_kernel(DistArgs a)
     uint32_t *cnt = lds;
     // reportable cells: one workgroup per CU (1,024 threads) collects (row, column, common, row's sketch size) over
     // SEVERAL units in two lists taking turns (BATCH); smaller workgroups keep one (cell, common) list per unit
-    constexpr bool BATCH = THREADS >= 1024;
+    constexpr bool BATCH = THREADS >= kBatchFromThreads;
     uint4 *cand = reinterpret_cast<uint4 *>(lds + a.cnt_words);
     uint2 *cand2 = reinterpret_cast<uint2 *>(lds + a.cnt_words);
     rk_hit *stage = BATCH ? reinterpret_cast<rk_hit *>(cand + 2 * a.cand_cap) : reinterpret_cast<rk_hit *>(cand2 + a.cand_cap);
@@ -858,11 +860,12 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // workgroup size by row size: 7 x 256 threads fit up to ~22 KiB rows; bigger rows leave room for
     // fewer workgroups, which then need more waves each
     // 7 workgroups per CU: 4 waves each; 3: 8 waves; 2: 12 waves; 1: 16 waves (measured)
-    p->threads = p->lds_bytes <= 24 * 1024 ? 256 : (p->lds_bytes <= 53 * 1024 ? 512 : (p->lds_bytes <= 80 * 1024 ? 768 : 1024));
+    const size_t with_lists = p->lds_bytes + batch_extra;  // from 512 threads on: the two batch lists
+    p->threads = p->lds_bytes <= 24 * 1024 ? 256 : (with_lists <= 53 * 1024 ? 512 : (with_lists <= 80 * 1024 ? 768 : 1024));
     if (p->mode == kSelfPair && p->threads == 256) p->threads = 512;  // two rows' slices per unit: measured better
     const uint32_t forced = ctx->sw_dist_threads;
     if (forced == 256 || forced == 512 || forced == 1024 || forced == 768) p->threads = forced;
-    if (p->threads >= 1024) p->lds_bytes += batch_extra;
+    if (p->threads >= (uint32_t)kBatchFromThreads) p->lds_bytes += batch_extra;
     // does a pair with distance exactly 1.0 (common == 0) pass the threshold?
     p->dense_mode = rk_dense_mode(o) ? 1 : 0;
     return RK_OK;
