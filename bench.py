@@ -532,7 +532,7 @@ def main():
                      "frac": head["achieved"] / HBM_PEAK_GBS, "traffic": None, "hbm_frac": None,
                      "kernel": head["kernel"], "kernel_ms": head["kernel_ms"],
                      "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"],
-                     "limiter": "per-unit latency (3 barriers, slice stream, wave-level column counts) at 24 waves per CU; not HBM "
+                     "limiter": "vector issue (53 % of the SIMD cycles) and the two barriers per unit at 24 waves per CU; not HBM "
                                 "(DESIGN.md 4.3).  `frac` is the CONTRACT fraction on SURVEY 8d's byte model (12 B/query hash + 4 B/"
                                 "posting + 4 B/count cell): the kernel keeps the counts in LDS and, with compact slices, streams no "
                                 "postings at all, so the model bills bytes that never move and `frac` can exceed 1; `hbm_frac` is "
