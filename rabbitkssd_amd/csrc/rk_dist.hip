@@ -5,16 +5,19 @@
 // A workgroup processes "units": one query row, or in the self join a pair of neighbouring rows
 // (see rk_dist_kernel).  The counter row of the reference (`int intersectionArr[tid][numRef]`,
 // src/dist.cpp:167) lives in LDS, two 16-bit counters per word when no count can overflow.  Per
-// unit: the posting slices of its hashes stream from HBM into registers one per thread (the next
-// batch is always in flight), quads gather the first 8 postings of each list with one 8-byte load
-// per lane and scatter them into the LDS row with ds_add_u32.  The epilogue scans the row 16 B per
-// lane, compacts the non-zero cells into an LDS list and evaluates the Jaccard/Mash (or
-// containment/AafD) formula in FP64 one cell per lane; reported pairs are staged in LDS and flushed
-// with one device-scope atomic per workgroup.
-// Integer/index work: bound by LDS atomics, L1 tag lookups and latency -- no MFMA.
-// Developer switches (environment, read once when the context is created): RK_DIST_THREADS=256|512|1024, RK_DIST_ROWS=<units
-// per workgroup, non-persistent>, RK_DIST_PAIR=2 (no row pairs), RK_DIST_PAIR_MINWG, RK_DIST_PERSIST=2
-// (one run per workgroup), RK_DIST_CAND_CAP, RK_DIST_STAGE_HITS, RK_DIST_XCD_ROWS.
+// unit: the slices of its hashes stream from HBM into registers one per thread (the next batch is
+// always in flight).  Most slices are compact (first genome + bitmask of the next 32 ids): the wave
+// counts them column by column with ballots and adds each column's count with one LDS atomic; the
+// few posting ranges are gathered by quads (8 postings per list and step).  The epilogue scans the
+// row 16 B per lane, clears what it finds, compacts the reportable cells into an LDS list and
+// evaluates the Jaccard/Mash (or containment/AafD) formula in FP64 one cell per lane; reported
+// pairs are staged in LDS and flushed with one device-scope atomic per workgroup.
+// The rows of a self join run in bands (plan_bands): a band's LDS rows start at its first row.
+// Integer/index work: bound by vector issue and the two barriers per unit -- no MFMA.
+// Developer switches (environment, read once when the context is created): RK_DIST_THREADS=256|512|768|1024,
+// RK_DIST_ROWS=<units per workgroup, non-persistent>, RK_DIST_PAIR=2 (no row pairs), RK_DIST_PAIR_MINWG,
+// RK_DIST_PERSIST=2 (one run per workgroup), RK_DIST_CAND_CAP, RK_DIST_STAGE_HITS, RK_DIST_XCD_ROWS, RK_DIST_BANDS=0 (one
+// launch), RK_DIST_BAND_MIN_ROWS, RK_DIST_LDS_KB (plan as if a CU had less LDS: tiles and bands at test sizes).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -116,9 +119,11 @@ __device__ unsigned long long g_prof[kProfWaves][16];  // one row per wave, summ
 // One workgroup handles units_per_wg consecutive units (a unit = a row, or a pair of rows) and
 // stages the reported pairs in LDS, so the contended device-scope atomic on the hit counter is
 // paid once per workgroup instead of once per reporting wave.
-// Per unit: zero the LDS rows | barrier | gather + scatter all slices | barrier | scan the rows
-// into the cell list | barrier | evaluate the cells.  Three barriers; the evaluation of unit u
-// overlaps the zeroing and scattering of unit u+1 in the faster waves (cell counters alternate).
+// Per unit: scatter all slices | barrier | scan the rows into the cell list, clearing them | barrier |
+// evaluate the cells (in batches over several units from 512 threads on).  Two barriers; the evaluation
+// of unit u overlaps the scattering of unit u+1 in the faster waves (cell counters alternate).  Explicit
+// queries with dense output, tiled rows and the report-everything mode (-D >= 1) zero the rows per unit
+// behind a third barrier.
 //
 // THREADS (256, 512, 768, 1024): a counter row of N columns occupies 2N (U16) or 4N bytes of the
 // CU's 160 KiB, which caps the resident workgroups; bigger rows get bigger workgroups so that the
