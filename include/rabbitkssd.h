@@ -254,7 +254,9 @@ int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *querie
                      uint64_t *n_hits_dev, void *stream);
 
 /* Name (as a profiler prints it, e.g. "rk_dist_kernel<true, 2, 512>") of the kernel rk_dist_rows(_dev) launches for
- * these arguments: lets a harness check that a stored counter profile belongs to the variant it is timing. */
+ * these arguments: lets a harness check that a stored counter profile belongs to the variant it is timing.  A big self
+ * join runs as several launches (bands of rows, each with LDS rows as wide as the columns behind its first row): the
+ * name is then that of the first band followed by " [N bands]". */
 int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries, const rk_dist_opts *opts,
                         char *buf, size_t cap);
 
