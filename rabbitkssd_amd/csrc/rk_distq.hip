@@ -43,7 +43,8 @@ enum { kLookRank = 0, kLookDir32 = 1, kLookDir64 = 2 };
 struct DistQArgs {
     const void *q_hashes;        // u32[] or u64[] (kLookDir64)
     const uint64_t *q_off;       // u64[n_query+1]
-    const uint2 *rankbm;         // kLookRank
+    const uint2 *rankbm;         // kLookRank: entry of 48 hash values
+    const uint32_t *rankbase;    // kLookRank: rank at the start of every 64th entry
     const void *uhash;           // kLookDir*: sorted distinct hashes
     const uint32_t *dir;
     const uint32_t *upos;        // u32[U+1] posting offsets of the distinct hashes
@@ -176,14 +177,23 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
             uint32_t pos[kLookups];
             bool present[kLookups];
             if (LOOK == kLookRank) {
+                // one 8-byte entry answers "is h indexed, and which distinct hash is it" for 48 consecutive hash values
+                // (48 presence bits + a 16-bit rank relative to a base every 64 entries: the bases of a wave's 64 sorted
+                // hashes share a cache line).  48 values per entry instead of 32: a third fewer lines per query.
                 uint2 w[kLookups];
-#pragma unroll
-                for (uint32_t i = 0; i < kLookups; i++) w[i] = a.rankbm[inb[i] ? (uint32_t)(h[i] >> 5) : 0u];
+                uint32_t base[kLookups], ent[kLookups];
 #pragma unroll
                 for (uint32_t i = 0; i < kLookups; i++) {
-                    const uint32_t b = (uint32_t)h[i] & 31u;
-                    present[i] = inb[i] && ((w[i].x >> b) & 1u);
-                    pos[i] = w[i].y + __popc(w[i].x & ((1u << b) - 1u));
+                    ent[i] = inb[i] ? (uint32_t)(((uint64_t)(uint32_t)h[i] * 0xAAAAAAABull) >> 37) : 0u;  // h / 48
+                    w[i] = a.rankbm[ent[i]];
+                    base[i] = a.rankbase[ent[i] >> 6];
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    const uint32_t b = (uint32_t)h[i] - 48u * ent[i];
+                    const uint64_t bits = (uint64_t)w[i].x | ((uint64_t)(w[i].y & 0xFFFFu) << 32);
+                    present[i] = inb[i] && ((bits >> b) & 1u);
+                    pos[i] = base[i] + (w[i].y >> 16) + (uint32_t)__popcll(bits & ((1ULL << b) - 1ULL));
                 }
             } else {
                 // prefix directory + binary search in the sorted distinct hashes (k_resolve of round 1, inlined)
@@ -351,45 +361,46 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
 }
 
 // ---- rank bitmap over the hash space --------------------------------------------------------------------
-__global__ void k_rank_set(const uint32_t *uhash, uint64_t U, uint32_t *bits)
+// one thread per entry of 48 hash values: uhash is sorted, so a binary search finds the entry's first distinct hash
+// (its rank) and the few that follow set its presence bits -- no temporary, no atomics
+constexpr uint32_t kRankSpan = 48, kRankBlock = 64;  // values per entry, entries per rank base
+__device__ inline uint64_t first_at_least(const uint32_t *uhash, uint64_t U, uint64_t key)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < U) atomicOr(&bits[uhash[i] >> 5], 1u << (uhash[i] & 31));
-}
-
-// rank of a word = index of the first distinct hash >= 32 * word: uhash is sorted, so a binary search replaces
-// the scan of the popcounts (no temporary, one pass)
-__global__ void k_rank_fill(const uint32_t *uhash, uint64_t U, const uint32_t *bits, uint64_t n_words, uint2 *out)
-{
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    const uint64_t key = w << 5;
     uint64_t lo = 0, hi = U;
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
         if ((uint64_t)uhash[mid] < key) lo = mid + 1; else hi = mid;
     }
-    out[w] = make_uint2(bits[w], (uint32_t)lo);
+    return lo;
+}
+__global__ void k_rank_fill(const uint32_t *uhash, uint64_t U, uint64_t n_entries, uint2 *out, uint32_t *base)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    const uint64_t key = e * kRankSpan;
+    const uint64_t at = first_at_least(uhash, U, key);
+    const uint64_t at_block = first_at_least(uhash, U, (e / kRankBlock) * kRankBlock * kRankSpan);
+    uint64_t bits = 0;
+    for (uint64_t i = at; i < U && (uint64_t)uhash[i] < key + kRankSpan; i++) bits |= 1ULL << ((uint64_t)uhash[i] - key);
+    out[e] = make_uint2((uint32_t)bits, (uint32_t)(bits >> 32) | ((uint32_t)(at - at_block) << 16));  // < 64 * 48 distinct below
+    if (e % kRankBlock == 0) base[e / kRankBlock] = (uint32_t)at;
 }
 
-constexpr int kRankMaxBits = 30;  // 2^25 words x 8 B = 256 MiB; above that: directory + binary search
+constexpr int kRankMaxBits = 30;  // 2^30 / 48 entries x 8 B = 171 MiB; above that: directory + binary search
 
 int ensure_rankbm(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
 {
     if (idx->d_rankbm || idx->wide || idx->hash_bits > kRankMaxBits) return RK_OK;
-    const uint64_t n_words = idx->hash_bits > 5 ? 1ULL << (idx->hash_bits - 5) : 1ULL;
-    DevBuf<uint32_t> bits(ctx);
+    const uint64_t n_entries = ((1ULL << idx->hash_bits) + kRankSpan - 1) / kRankSpan;
     DevBuf<uint2> out(ctx);
-    if (bits.alloc(n_words) != hipSuccess || out.alloc(n_words) != hipSuccess)
-        return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate the %llu-word rank bitmap", (unsigned long long)n_words);
-    RK_HIP(ctx, hipMemsetAsync(bits.p, 0, n_words * 4, stream));
-    if (idx->U)
-        hipLaunchKernelGGL(k_rank_set, dim3((unsigned)((idx->U + 255) / 256)), dim3(256), 0, stream, idx->d_uhash, idx->U, bits.p);
-    hipLaunchKernelGGL(k_rank_fill, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, idx->d_uhash, idx->U,
-                       bits.p, n_words, out.p);
+    DevBuf<uint32_t> base(ctx);
+    if (out.alloc(n_entries) != hipSuccess || base.alloc(n_entries / kRankBlock + 1) != hipSuccess)
+        return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate the %llu-entry rank bitmap", (unsigned long long)n_entries);
+    hipLaunchKernelGGL(k_rank_fill, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, stream, idx->d_uhash, idx->U,
+                       n_entries, out.p, base.p);
     RK_HIP(ctx, hipGetLastError());
-    RK_HIP(ctx, hipStreamSynchronize(stream));  // `bits` dies with this scope
     idx->d_rankbm = out.release();
+    idx->d_rankbase = base.release();
     return RK_OK;
 }
 
@@ -480,6 +491,7 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     a.q_hashes = qs->wide ? (const void *)qs->d_hashes64 : (const void *)qs->d_hashes;
     a.q_off = qs->d_off;
     a.rankbm = idx->d_rankbm;
+    a.rankbase = idx->d_rankbase;
     a.uhash = idx->wide ? (const void *)idx->d_uhash64 : (const void *)idx->d_uhash;
     a.dir = idx->d_dir;
     a.upos = idx->d_upos;

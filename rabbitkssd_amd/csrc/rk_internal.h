@@ -132,8 +132,10 @@ struct rk_index {
     uint64_t min_ref_size = 0;       // smallest NON-EMPTY reference sketch (0: all empty): lower bound of a containment denominator
     bool ref_sets = false;           // no genome appears twice in a posting list (the sketches are sets): an
                                      // intersection count is then bounded by the smaller sketch
-    uint2 *d_rankbm = nullptr;       // lazily built by the query path (rk_distq.hip): per 32 consecutive hash values
-                                     // {presence bits, number of distinct indexed hashes below}; u32[2 * 2^(bits-5)]
+    uint2 *d_rankbm = nullptr;       // lazily built by the query path (rk_distq.hip): per 48 consecutive hash values
+                                     // {presence bits 0..31, presence bits 32..47 | 16-bit rank << 16}; the rank (number
+                                     // of distinct indexed hashes below) is relative to d_rankbase[entry / 64]
+    uint32_t *d_rankbase = nullptr;  // u32[entries / 64 + 1]
     uint32_t *d_postings = nullptr;  // u32[H]   (.dict order)
     bool wide = false;               // 64-bit hashes: d_uhash64 instead of d_uhash
     uint32_t *d_uhash = nullptr;     // u32[U]   sorted distinct hashes
