@@ -399,6 +399,7 @@ int ensure_rankbm(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
     hipLaunchKernelGGL(k_rank_fill, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, stream, idx->d_uhash, idx->U,
                        n_entries, out.p, base.p);
     RK_HIP(ctx, hipGetLastError());
+    RK_HIP(ctx, hipStreamSynchronize(stream));  // once per index: a later call may come on another stream
     idx->d_rankbm = out.release();
     idx->d_rankbase = base.release();
     return RK_OK;
