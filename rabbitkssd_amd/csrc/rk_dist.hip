@@ -20,6 +20,7 @@
 // launch), RK_DIST_BAND_MIN_ROWS, RK_DIST_LDS_KB (plan as if a CU had less LDS: tiles and bands at test sizes).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <tuple>
@@ -798,6 +799,11 @@ struct Plan {
 };
 
 // want_self: the ranges are the index's own "later genomes" slices (self join, triangle, no dense output)
+// Largest LDS footprint (bytes) with which n workgroups share a CU: the hardware hands LDS out in granules of 1,280 bytes
+// (measured: a 54,240-byte workgroup comes twice per CU, a 53,216-byte one three times)
+constexpr size_t kLdsGranule = 1280, kLdsPerCu = 160 * 1024;
+constexpr size_t lds_for_workgroups(size_t n) { return kLdsPerCu / n / kLdsGranule * kLdsGranule; }
+
 // n_cols: columns an LDS row must hold (the whole reference range, or what lies behind a band's first row)
 int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_query_size,
               const rk_dist_opts *o, bool want_self, uint32_t n_cols, Plan *p)
@@ -814,7 +820,7 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // per workgroup measured better, 0.134 vs 0.145 ms) live long, so they stage more hits before the
     // one flush at their end.  Capacity decisions below assume the bigger staging area.
     const uint64_t one_row = (uint64_t)n_cols * (p->u16 ? 2 : 4);
-    const bool small_rows = one_row + (size_t)p->cand_cap * sizeof(uint2) + kStageHitsDefault * sizeof(rk_hit) + 64 <= 24 * 1024;
+    const bool small_rows = one_row + (size_t)p->cand_cap * sizeof(uint2) + kStageHitsDefault * sizeof(rk_hit) + 64 <= lds_for_workgroups(7);
     p->persist = idx->n_ref && ctx->sw_dist_persist != 2;
     p->stage_hits = ctx->sw_dist_stage_hits ? ctx->sw_dist_stage_hits : 4 * kStageHitsDefault;
     // cell lists: (cell, common) per unit for workgroups below 1,024 threads; 1,024-thread workgroups (one per CU) keep two
@@ -845,7 +851,7 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // occupancy costs more than the saved walks: 14,142 columns 0.127 ms paired vs 0.113 single)
     // (pairs rest on set semantics: with a repeated hash inside a genome the "covered" test of the index build fails)
     const bool pair_ok = p->mode == kSelf && p->row_block % 2 == 0 && idx->d_self_split && idx->ref_sets &&
-                         (size_t)p->row_words * 8 + fixed <= lds_cap / ctx->sw_dist_pair_minwg &&
+                         (size_t)p->row_words * 8 + fixed + batch_extra <= lds_for_workgroups(std::max(1u, ctx->sw_dist_pair_minwg)) &&
                          ctx->sw_dist_pair != 2;
     if (pair_ok) p->mode = kSelfPair;
     const uint32_t unit_rows = p->mode == kSelfPair ? 2 : 1;
@@ -866,7 +872,7 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // fewer workgroups, which then need more waves each
     // 7 workgroups per CU: 4 waves each; 3: 8 waves; 2: 12 waves; 1: 16 waves (measured)
     const size_t with_lists = p->lds_bytes + batch_extra;  // from 512 threads on: the two batch lists
-    p->threads = p->lds_bytes <= 24 * 1024 ? 256 : (with_lists <= 53 * 1024 ? 512 : (with_lists <= 80 * 1024 ? 768 : 1024));
+    p->threads = p->lds_bytes <= lds_for_workgroups(7) ? 256 : (with_lists <= lds_for_workgroups(3) ? 512 : (with_lists <= lds_for_workgroups(2) ? 768 : 1024));
     if (p->mode == kSelfPair && p->threads == 256) p->threads = 512;  // two rows' slices per unit: measured better
     const uint32_t forced = ctx->sw_dist_threads;
     if (forced == 256 || forced == 512 || forced == 1024 || forced == 768) p->threads = forced;
@@ -975,7 +981,8 @@ int plan_bands(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, std::vec
     bands->clear();
     const uint64_t round_rows = (uint64_t)cur.row_step * cur.row_block;  // one block of every shard
     const uint64_t n_rounds = ((uint64_t)n + round_rows - 1) / round_rows;
-    const uint64_t min_rounds = std::max<uint64_t>(1, ((uint64_t)ctx->sw_dist_band_min_rows + round_rows - 1) / round_rows);
+    // a band must be worth its launch (ramp-up, the tail of its last round): at least sw_dist_band_min_rows rows of THIS shard
+    const uint64_t min_rounds = std::max<uint64_t>(1, ((uint64_t)ctx->sw_dist_band_min_rows + cur.row_block - 1) / cur.row_block);
     auto plan_at = [&](uint64_t round, Plan *q) -> int {
         const uint64_t row = round * round_rows;
         const uint32_t col_base = (uint32_t)row & ~63u;  // whole 128-byte stretches of a 16-bit row
@@ -1006,6 +1013,10 @@ int plan_bands(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, std::vec
     }
     cur.n_units = cur.n_units > cur.slot_base ? cur.n_units - cur.slot_base : 0;  // to the end of the shard
     bands->push_back(cur);
+    if (ctx->sw_dist_debug)
+        for (const Plan &b : *bands)
+            fprintf(stderr, "[rk] band: columns from %u, units %u from slot %u, kernel <%s, %d, %u>, %zu B LDS, %u tile(s)\n", b.col_base,
+                    b.n_units, b.slot_base, b.u16 ? "u16" : "u32", b.mode, b.threads, b.lds_bytes, b.n_tiles);
     return RK_OK;
 }
 

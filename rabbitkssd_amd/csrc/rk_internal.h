@@ -43,7 +43,8 @@ struct rk_ctx {
     uint32_t sw_dist_threads = 0, sw_dist_rows = 0, sw_dist_pair = 1, sw_dist_pair_minwg = 3, sw_dist_persist = 1;
     uint32_t sw_dist_cand_cap = 0, sw_dist_stage_hits = 0, sw_dist_xcd_rows = 0;
     int sw_dist_bands = 1;  // RK_DIST_BANDS=0: the self join in one launch, every row as wide as the whole collection
-    int sw_dist_band_min_rows = 4096;  // RK_DIST_BAND_MIN_ROWS: no band shorter than this (tests: small collections in several bands)
+    int sw_dist_band_min_rows = 3072;  // RK_DIST_BAND_MIN_ROWS: no band with fewer rows of the shard than this (tests: small collections in several bands)
+    int sw_dist_debug = 0;  // RK_DIST_DEBUG=1: the bands of every self join on stderr
     int sw_dist_lds_kb = 0;  // RK_DIST_LDS_KB: plan as if a CU had this much LDS (tests: tiled bands at small sizes)
     int sw_sketch_img = 1;  // RK_SKETCH_IMG=0: the 144 KiB LDS image with the exact table, one workgroup per CU
 };
