@@ -953,7 +953,10 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.units_per_chunk = a.runs_per_chunk;  // units_per_wg == 1 in persistent mode
     a.units_per_xcd = gx / 8;
     if (p.persist) {
-        const int per_cu = rk_occupancy(ctx, (const void *)kern, (int)p.threads, p.lds_bytes);
+        int per_cu = rk_occupancy(ctx, (const void *)kern, (int)p.threads, p.lds_bytes);
+        // (the runtime's answer has been seen to count LDS finer than the hardware allocates it: a workgroup too many per CU
+        // would start only when another ends and walk its static share of the units late)
+        per_cu = std::min<int>(per_cu, (int)(kLdsPerCu / ((p.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule)));
         const uint32_t resident = ((uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, ctx->num_cu) + 7) / 8 * 8;
         if (gx > resident) {  // otherwise every unit gets its own workgroup anyway
             a.persist = 1;
