@@ -1,4 +1,4 @@
-# usage: tools/r02_prof.sh <tag> <driver args...>   -> rocprofv3 kernel trace + stats under gpurun_out/<tag>/
+# usage: tools/kernel_trace.sh <tag> <driver args...>   -> rocprofv3 kernel trace + stats under gpurun_out/<tag>/
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
