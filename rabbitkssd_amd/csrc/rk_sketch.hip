@@ -931,14 +931,14 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
     char *pinned = static_cast<char *>(rk_pinned_scratch(ctx, std::max(rows_bytes, res_bytes)));
     if (!pinned) return rk_fail(ctx, RK_ERR_NOMEM, "cannot pin %llu bytes", (unsigned long long)std::max(rows_bytes, res_bytes));
     DevBuf<GenomeRow> d_rows(ctx);
-    DevBuf<char> d_res(ctx);
-    DevBuf<uint32_t> d_usize(ctx);
+    DevBuf<char> d_res(ctx);  // tail | off | gcount (read back) | per-genome sketch sizes: cleared with ONE fill per pass
+    const size_t work_bytes = (res_bytes + (size_t)n_genomes * 4 + 15) & ~(size_t)15;
     RK_HIP(ctx, d_rows.alloc(rows.size()));
-    RK_HIP(ctx, d_res.alloc(res_bytes));
-    RK_HIP(ctx, d_usize.alloc(n_genomes));
+    RK_HIP(ctx, d_res.alloc(work_bytes));
     SketchTail *d_tail = reinterpret_cast<SketchTail *>(d_res.p);
     uint64_t *d_off_copy = reinterpret_cast<uint64_t *>(d_res.p + sizeof(SketchTail));
     uint32_t *d_gcount = reinterpret_cast<uint32_t *>(d_res.p + sizeof(SketchTail) + ((size_t)n_genomes + 1) * 8);
+    struct { uint32_t *p; } d_usize{d_gcount + n_genomes};
 
     rk_sketches *s = new (std::nothrow) rk_sketches;
     if (!s) return RK_ERR_NOMEM;
@@ -976,8 +976,7 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
         else { rk_pool_free(ctx, s->d_hashes); s->d_hashes = nullptr; RK_TRY(pool_array(ctx, &s->d_hashes, total_cap + 1)); }
         memcpy(pinned, rows.data(), rows_bytes);
         RK_HIP(ctx, hipMemcpyAsync(d_rows.p, pinned, rows_bytes, hipMemcpyHostToDevice, stream));
-        RK_HIP(ctx, hipMemsetAsync(d_res.p, 0, res_bytes, stream));
-        if (n_genomes) RK_HIP(ctx, hipMemsetAsync(d_usize.p, 0, (size_t)n_genomes * 4, stream));
+        RK_HIP(ctx, hipMemsetAsync(d_res.p, 0, work_bytes, stream));
         if (n_chunks) {
             SketchArgs a;
             a.packed = packed_dev;
