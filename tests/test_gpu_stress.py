@@ -1,0 +1,72 @@
+"""Seeded sweep of the self join and the query path over many small shapes and plans (GPU): collection sizes around the
+workgroup / pair / band / tile boundaries, hash spaces from crowded to sparse, both metrics, sparse and dense
+thresholds, row shards -- every result against the oracle.  The developer switches shrink the planner's idea of the
+LDS so that tiles, bands, single rows and row pairs all occur at these sizes."""
+import numpy as np
+import pytest
+
+from oracle import oracle as ok
+from rabbitkssd_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(mine, want):
+    assert len(mine) == len(want)
+    for f in ("row", "col", "common", "size0", "size1"):
+        assert np.array_equal(mine[f], want[f]), f
+    assert np.array_equal(mine["jorc"], want["jorc"])
+    assert np.max(np.abs(mine["dist"] - want["dist"]), initial=0.0) <= 1e-12
+
+
+PLANS = [
+    {},                                                              # as shipped
+    {"RK_DIST_BAND_MIN_ROWS": "64"},                                 # bands wherever the variant changes
+    {"RK_DIST_BAND_MIN_ROWS": "64", "RK_DIST_LDS_KB": "16"},         # tiled first band, then single rows
+    {"RK_DIST_BAND_MIN_ROWS": "32", "RK_DIST_LDS_KB": "20", "RK_DIST_CAND_CAP": "16"},   # cell lists overflow
+    {"RK_DIST_BANDS": "0", "RK_DIST_PAIR": "2"},                     # one launch, no pairs
+    {"RK_DIST_THREADS": "1024", "RK_DIST_CAND_CAP": "8"},            # batched evaluation with tiny lists
+]
+
+
+@pytest.mark.parametrize("plan", range(len(PLANS)))
+def test_self_join_shapes(monkeypatch, plan):
+    for k, v in PLANS[plan].items():
+        monkeypatch.setenv(k, v)
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(100 + plan)
+    shapes = [(1, 5, 16), (2, 9, 16), (3, 40, 18), (17, 30, 14), (64, 64, 20), (129, 25, 12), (500, 33, 20), (1023, 12, 16),
+              (2049, 18, 22), (4100, 10, 18), (7001, 8, 24)]
+    for n, m, bits in shapes:
+        names, h, off = synth.clade_sketches(n, m, bits, seed=int(rng.integers(1 << 30)))
+        idx = ctx.index_build(ctx.sketches_from_host(h, off), bits)
+        postings, counts = ok.index_build32(h, off, bits)
+        sizes = np.diff(off).astype(np.uint32)
+        for metric, D in ((0, 0.05), (1, 0.15), (0, 1.5)):
+            want, _ = ok.index_dist32(counts, bits, postings, sizes, h, off, 1, metric, 20, D, threads=8)
+            _check(ctx.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+        if n >= 64:  # three uneven row shards
+            want, _ = ok.index_dist32(counts, bits, postings, sizes, h, off, 1, 0, 20, 0.08, threads=8)
+            parts = [ctx.dist_rows(idx, None, 1, 0, 20, 0.08, row_first=r, row_step=3, row_block=6)[0] for r in range(3)]
+            merged = np.concatenate(parts)
+            _check(merged[np.lexsort((merged["col"], merged["row"]))], want)
+        del idx
+    ctx.close()
+
+
+def test_query_path_shapes():
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(7)
+    for n_ref, m_ref, n_q, m_q, bits in [(1, 4, 1, 4, 12), (10, 20, 3, 500, 16), (300, 76, 40, 3000, 20), (2000, 30, 25, 9000, 24),
+                                         (5000, 12, 7, 70000, 22), (900, 40, 900, 40, 18)]:
+        rn, rh, roff = synth.clade_sketches(n_ref, m_ref, bits, seed=int(rng.integers(1 << 30)))
+        qn, qh, qoff = synth.clade_sketches(n_q, m_q, bits, seed=int(rng.integers(1 << 30)))
+        idx = ctx.index_build(ctx.sketches_from_host(rh, roff), bits)
+        qs = ctx.sketches_from_host(qh, qoff)
+        postings, counts = ok.index_build32(rh, roff, bits)
+        sizes = np.diff(roff).astype(np.uint32)
+        for metric, D in ((0, 0.2), (1, 0.3), (0, 1.5)):
+            want, _ = ok.index_dist32(counts, bits, postings, sizes, qh, qoff, 0, metric, 20, D, threads=8)
+            _check(ctx.dist_rows(idx, qs, 0, metric, 20, D)[0], want)
+        del idx, qs
+    ctx.close()
