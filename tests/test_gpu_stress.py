@@ -70,3 +70,25 @@ def test_query_path_shapes():
             _check(ctx.dist_rows(idx, qs, 0, metric, 20, D)[0], want)
         del idx, qs
     ctx.close()
+
+
+@pytest.mark.parametrize("img", [1, 0])
+def test_sketch_shapes(monkeypatch, img):
+    """random genomes (IUPAC codes, lower case, N runs, empty and tiny records, many records) under several parameter
+    sets, with the default 64 KiB LDS image and with the 144 KiB one (RK_SKETCH_IMG=0): hash sets == oracle"""
+    from test_gpu_parity import sketch_case
+    monkeypatch.setenv("RK_SKETCH_IMG", str(img))
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(900 + img)
+    alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNnRYKMSWBDHV-", dtype=np.uint8)
+    for k, s, l in [(10, 6, 3), (8, 5, 2), (7, 4, 1), (11, 6, 2), (12, 6, 3), (16, 6, 3)]:
+        genomes = []
+        for g in range(9):
+            n = int([0, 1, 2 * k - 1, 2 * k, 2 * k + 1, 1023, 1024 + 2 * k, 33333, 150001][g])
+            b = alphabet[rng.integers(0, 16 if g % 2 else len(alphabet), size=n)].copy()
+            if n > 1000:  # a repeat, so that the dedup has something to do
+                b[n // 2:n // 2 + 300] = b[100:400]
+            cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 6)))]))
+            genomes.append((b, np.array(cuts, dtype=np.uint64)))
+        sketch_case(ctx, k, s, l, genomes)
+    ctx.close()
