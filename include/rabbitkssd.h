@@ -87,7 +87,7 @@ void rk_ctx_trim(rk_ctx *ctx);
 void rk_ctx_pool_stats(rk_ctx *ctx, uint64_t out[4]);
 /* Measurement: with timing on, a pass brackets its dominant kernel with HIP events on the stream it is launched on;
  * rk_ctx_last_ms(ctx, RK_MS_SKETCH_KERNEL) then returns that kernel's duration in milliseconds for the last
- * rk_sketch_* call.  (The distance entry points launch one kernel per call: bracket rk_dist_rows_dev yourself.) */
+ * rk_sketch_* call.  (The distance entry points launch one kernel per call or band: bracket rk_dist_rows_dev yourself.) */
 #define RK_MS_SKETCH_KERNEL 0
 void rk_ctx_set_timing(rk_ctx *ctx, int on);
 double rk_ctx_last_ms(const rk_ctx *ctx, int which);
@@ -239,7 +239,10 @@ typedef struct rk_dist_opts {
 
 /* Counts |S_q n S_r| through the inverted index and applies the reference's epilogue.
  * queries == NULL is only valid with triangle=1 (the indexed sketches are the queries).
- * hits_out is library-allocated (rk_free_host), sorted by (row, col).
+ * hits_out is library-allocated (rk_free_host), sorted by (row, col).  The jaccard/containment and
+ * distance of every returned pair are recomputed on the host with the C library's log -- the
+ * expression of src/dist.cpp:218-231 / :239-252 -- and the threshold is applied to that value (the
+ * device reports with a threshold a few ulps wider): values and hit set are the reference's bit for bit.
  * common_dense (optional, host, n_query*n_ref int32, row-major) receives the full
  * counter rows of the selected rows (other rows untouched) -- used by parity tests. */
 int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
@@ -248,7 +251,8 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
 
 /* Asynchronous all-in-HBM variant: hits are appended (unordered) to hits_dev
  * (capacity hits_cap records); *n_hits_dev (uint64, zeroed by the caller) counts every
- * hit, including those beyond the capacity, so an overflow is detectable. */
+ * hit, including those beyond the capacity, so an overflow is detectable.  Distances here are the
+ * device's own FP64 evaluation (its log may differ from the C library's in the last bit: <= 1e-12). */
 int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
                      const rk_dist_opts *opts, rk_hit *hits_dev, uint64_t hits_cap,
                      uint64_t *n_hits_dev, void *stream);

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -1034,6 +1035,40 @@ int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, rk_hit 
     return rc;
 }
 
+// Host-side last word on the distances of the synchronous API.  The device evaluates the reference's formula in FP64 with
+// its own `log`, which may differ from glibc's in the last bit: enough to print a different sixth decimal once in ~10^10
+// hits, or to flip a pair that sits exactly on the threshold.  rk_dist_rows therefore lets the device report with a
+// threshold a few ulps wider, recomputes jaccard / distance of every reported pair here with the host's libm -- the
+// very expression of src/dist.cpp:218-231 / :239-252 -- and applies the reference's comparison to that value.
+uint64_t host_exact_distances(rk_hit *h, uint64_t n, const rk_dist_opts *o)
+{
+    const int metric = o->metric != 0;
+    auto fix = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) {
+            const JorcDist jd = rk_distance(h[i].common, h[i].size0, h[i].size1, metric, o->kmer_size);
+            h[i].jorc = jd.jorc;
+            h[i].dist = jd.dist;
+        }
+    };
+    const uint64_t kChunk = 1 << 18;
+    if (n <= kChunk) fix(0, n);
+    else {  // a dense report (tens of millions of pairs): share the logs out
+        const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<uint64_t>(16, n / kChunk));
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; t++) pool.emplace_back(fix, n * t / nt, n * (t + 1) / nt);
+        for (auto &th : pool) th.join();
+    }
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const bool keep = o->triangle ? (h[i].dist < o->max_dist) : (h[i].dist <= o->max_dist);  // :232 / :624
+        if (keep) {
+            if (w != i) h[w] = h[i];
+            w++;
+        }
+    }
+    return w;
+}
+
 }  // namespace
 
 #ifdef RK_DIST_PROFILE
@@ -1109,6 +1144,11 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
         return rk_fail(ctx, RK_ERR_ARG, "triangle mode needs the indexed sketches as queries (%u vs %u)",
                        n_query, idx->n_ref);
     int rc = RK_OK;
+    // the device reports with a threshold ~64 ulps wider; host_exact_distances() decides with the host's libm
+    const rk_dist_opts *exact_opts = opts;
+    rk_dist_opts widened = *opts;
+    if (widened.max_dist > 0.0) widened.max_dist += widened.max_dist * 0x1p-46;
+    opts = &widened;
     const bool dense_mode = rk_dense_mode(opts);
     hipStream_t stream = ctx->stream;
 
@@ -1184,7 +1224,7 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
                 return x.row != y.row ? x.row < y.row : x.col < y.col;
             });
         *hits_out = out;
-        *n_hits = n;
+        *n_hits = host_exact_distances(out, n, exact_opts);
         if (common_dense) {
             RK_HIP(ctx, hipMemcpyAsync(common_dense, dense.p, (size_t)n_query * idx->n_ref * 4, hipMemcpyDeviceToHost, stream));
             RK_HIP(ctx, hipStreamSynchronize(stream));

@@ -11,7 +11,7 @@ namespace {
 struct JorcDist {
     double jorc, dist;
 };
-__device__ __noinline__ JorcDist rk_distance(int common, int size0, int size1, int metric, int kmer_size)
+__host__ __device__ __noinline__ JorcDist rk_distance(int common, int size0, int size1, int metric, int kmer_size)
 {
     JorcDist r;
     if (!metric) {

@@ -23,7 +23,7 @@ def check_hits(mine, want):
     for f in ("row", "col", "common", "size0", "size1"):
         assert np.array_equal(mine[f], want[f]), f
     assert np.array_equal(mine["jorc"], want["jorc"])
-    assert np.max(np.abs(mine["dist"] - want["dist"]), initial=0.0) <= 1e-12
+    assert np.array_equal(mine["dist"], want["dist"])   # rk_dist_rows: the host libm has the last word
 
 
 def test_config2_alldist_10k_exact(ctx):
@@ -63,7 +63,12 @@ def test_config2_alldist_10k_exact(ctx):
     n = int(cnt.item())
     dev = np.frombuffer(hits.cpu().numpy().tobytes()[: n * capi.HIT_DTYPE.itemsize], dtype=capi.HIT_DTYPE)
     dev = dev[np.lexsort((dev["col"], dev["row"]))]
-    assert dev.tobytes() == full.tobytes()
+    # (the hits of the device-resident API carry the device's own `log`: north_star's 1e-12; the synchronous API's are
+    # recomputed with the host libm and equal the oracle's bit for bit, checked above)
+    assert len(dev) == len(full)
+    for f in ("row", "col", "common", "size0", "size1", "jorc"):
+        assert np.array_equal(dev[f], full[f]), f
+    assert np.max(np.abs(dev["dist"] - full["dist"])) <= 1e-12
 
 
 def test_config3_alldist_50k_properties_and_exact(ctx):
@@ -83,7 +88,7 @@ def test_config3_alldist_50k_properties_and_exact(ctx):
         b = h[int(off[j]):int(off[j + 1])]
         assert mine["common"][t] == len(np.intersect1d(a, b, assume_unique=True))
         jac, d = ok.distance(mine["common"][t], len(a), len(b), 0, 20)
-        assert mine["jorc"][t] == jac and abs(mine["dist"][t] - d) <= 1e-12
+        assert mine["jorc"][t] == jac and mine["dist"][t] == d
     # rows of one rank out of 8 (what a GPU of configs[3] computes) are a subset with the same records
     part, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=3, row_step=8)
     sel = mine[mine["row"] % 8 == 3]

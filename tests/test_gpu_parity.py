@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the oracle and the
 golden fixtures.  Integer results (hash sets, postings, intersection counts, sizes) must be
-bit-exact; FP64 jaccard/containment exact, Mash/AafD distance within 1e-12 (north_star)."""
+bit-exact; FP64 jaccard/containment exact; Mash/AafD distance bit-identical through the synchronous API (host libm has
+the last word), within 1e-12 (north_star) where the hits stay on the device."""
 import json
 import os
 
@@ -12,7 +13,8 @@ from oracle import oracle as ok
 from rabbitkssd_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
-DIST_TOL = 1e-12
+DIST_TOL = 0.0  # rk_dist_rows recomputes the distances of its hits with the host libm: bit-identical to the oracle (the
+                # device-resident API rk_dist_rows_dev stays within 1e-12, north_star's tolerance: tests/test_gpu_fullsize.py)
 
 
 @pytest.fixture(scope="module")

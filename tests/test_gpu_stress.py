@@ -16,7 +16,7 @@ def _check(mine, want):
     for f in ("row", "col", "common", "size0", "size1"):
         assert np.array_equal(mine[f], want[f]), f
     assert np.array_equal(mine["jorc"], want["jorc"])
-    assert np.max(np.abs(mine["dist"] - want["dist"]), initial=0.0) <= 1e-12
+    assert np.array_equal(mine["dist"], want["dist"])   # the host libm has the last word in rk_dist_rows
 
 
 PLANS = [

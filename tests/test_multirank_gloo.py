@@ -118,7 +118,7 @@ def _worker_gpu(rank, port, outdir):
             assert len(want) > 1000 and len(merged) == len(want)
             for f in ("row", "col", "common", "size0", "size1"):
                 assert np.array_equal(merged[f], want[f]), f
-            assert np.max(np.abs(merged["dist"] - want["dist"])) <= 1e-12
+            assert np.array_equal(merged["dist"], want["dist"])
             open(os.path.join(outdir, "ok"), "w").write("%d" % len(merged))
         del index
         ctx.close()

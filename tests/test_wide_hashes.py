@@ -125,7 +125,7 @@ def test_gpu_wide_sketch_vs_oracle(ctx, k, s, l):
     want, _ = ok.index_dist64(uhash, ucount, postings, np.diff(goff).astype(np.uint32), gh, goff, 1, 0, 2 * k, 0.2)
     mine, _ = ctx.dist_rows(idx, None, 1, 0, 2 * k, 0.2)
     assert len(mine) == len(want) and np.array_equal(mine["common"], want["common"])
-    assert np.max(np.abs(mine["dist"] - want["dist"]), initial=0.0) <= 1e-12
+    assert np.array_equal(mine["dist"], want["dist"])
 
 
 # ------------------------------------------------------------------ host tool on the 64-bit layout
