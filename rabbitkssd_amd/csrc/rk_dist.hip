@@ -1050,9 +1050,9 @@ uint64_t host_exact_distances(rk_hit *h, uint64_t n, const rk_dist_opts *o)
             h[i].dist = jd.dist;
         }
     };
-    const uint64_t kChunk = 1 << 18;
-    if (n <= kChunk) fix(0, n);
-    else {  // a dense report (tens of millions of pairs): share the logs out
+    const uint64_t kChunk = 8192;  // ~0.2 ms of divides and logs
+    if (n < 2 * kChunk) fix(0, n);
+    else {  // share the logs out (a dense report has tens of millions of pairs)
         const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<uint64_t>(16, n / kChunk));
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < nt; t++) pool.emplace_back(fix, n * t / nt, n * (t + 1) / nt);
