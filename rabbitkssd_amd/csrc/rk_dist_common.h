@@ -55,6 +55,25 @@ __device__ inline uint32_t wave_or(uint32_t x)
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+// unsigned minimum over the 64 lanes of the wave (uniform result); same data movement as wave_or (lanes without a
+// source keep ~0, the neutral element)
+#define RK_MIN_STEP(CTRL, ROWS)                                                                          \
+    do {                                                                                                 \
+        const uint32_t o__ = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, CTRL, ROWS, 0xF, false); \
+        x = o__ < x ? o__ : x;                                                                           \
+    } while (0)
+__device__ inline uint32_t wave_min(uint32_t x)
+{
+    RK_MIN_STEP(0x111, 0xF);  // row_shr:1
+    RK_MIN_STEP(0x112, 0xF);  // row_shr:2
+    RK_MIN_STEP(0x114, 0xF);  // row_shr:4
+    RK_MIN_STEP(0x118, 0xF);  // row_shr:8
+    RK_MIN_STEP(0x142, 0xA);  // row_bcast:15 -> rows 1, 3
+    RK_MIN_STEP(0x143, 0xC);  // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+#undef RK_MIN_STEP
+
 // Wave-level column counts.  Every lane holds the bitmask of one list (bit p = column p of a 32-column window) for the
 // unit's first row (ma) and its partner (mb).  For every occupied column one ballot counts the lanes that name it and
 // the count travels from the scalar unit straight into lane p (v_writelane_b32 with the lane as an inline constant: no

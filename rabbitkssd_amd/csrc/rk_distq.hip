@@ -45,6 +45,7 @@ struct DistQArgs {
     const uint64_t *q_off;       // u64[n_query+1]
     const uint2 *rankbm;         // kLookRank: entry of 48 hash values
     const uint32_t *rankbase;    // kLookRank: rank at the start of every 64th entry
+    const uint2 *urec;           // per distinct hash: posting range or compact list (rk_internal.h d_urec); null: ranges from upos
     const void *uhash;           // kLookDir*: sorted distinct hashes
     const uint32_t *dir;
     const uint32_t *upos;        // u32[U+1] posting offsets of the distinct hashes
@@ -128,14 +129,48 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
             const uint32_t c = id - col0;
             if (valid && c < ncol && id >= lo_id) bump_cell(c);
         };
+        auto bump_n = [&](uint32_t id, uint32_t n) {  // a wave-level count (<= 64; the counter width bounds the total)
+            const uint32_t c = id - col0;
+            if (n && c < ncol && id >= lo_id) {
+                if (CBITS == 32) atomicAdd(&cnt[c], n);
+                else atomicAdd(&cnt[c / kPerWord], n << ((c % kPerWord) * CBITS));
+            }
+        };
         uint32_t qn = 0;  // wave-uniform: ranges in this wave's queue
         // pops up to 64 ranges and walks the first 8 postings of each; longer lists re-enter the queue
         auto walk = [&]() {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const uint32_t take = min(qn, 64u);
             qn -= take;
-            uint2 rg = make_uint2(0, 0);
-            if (lane < take) rg = queue[qn + lane];
+            uint2 ent = make_uint2(0, 0);
+            if (lane < take) ent = queue[qn + lane];
+            // Compact records carry their posting list (the neighbouring ids of a clade): no posting load.  A query that
+            // has relatives among the references meets the same few columns in most of its lists: as in the self join the
+            // WAVE counts them -- every list is shifted onto the 32 columns from the smallest first genome on, one ballot
+            // per occupied column, one conflict-free add per column -- and only lists that reach beyond that window (the
+            // clades of an unrelated query) are scattered lane by lane.
+            const bool cpt = a.urec && (ent.x >> 31) != 0;
+            const uint2 rg = cpt ? make_uint2(0, 0) : ent;
+            if (__ballot(cpt)) {  // uniform
+                const uint32_t first = ent.x & 0x7FFFFFFFu;
+                const uint32_t base = wave_min(cpt ? first : 0xFFFFFFFFu);
+                const uint32_t rel = first - base;
+                const bool fits = cpt && rel < 32u && (rel == 0 || (ent.y >> (32u - rel)) == 0);
+                const uint32_t mw = fits ? ent.y << rel : 0u;
+                uint32_t ca = 0, cb = 0;
+                count_columns<false, 0>(wave_or(mw), mw, 0u, ca, cb);
+                bump_n(base + lane, ca);
+                uint32_t m = cpt && !fits ? ent.y : 0u;
+                while (__ballot(m != 0)) {
+                    const bool v = m != 0;
+                    bump(first + (v ? (uint32_t)__ffs((int)m) - 1u : 0u), v);
+                    m &= m - 1u;
+                }
+            }
+            if (!__ballot(rg.y > rg.x)) {  // uniform: no posting range among them
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                return;
+            }
             PostingPair id[4];
             bool ok0[4], ok1[4];
             auto step = [&](int j, uint32_t rx, uint32_t ry) {
@@ -220,7 +255,15 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
             PostingPair r[kLookups];
 #pragma unroll
             for (uint32_t i = 0; i < kLookups; i++)
-                if (present[i]) r[i] = *reinterpret_cast<const PostingPair *>(a.upos + pos[i]);
+                if (present[i]) {
+                    if (a.urec) {  // uniform
+                        const uint2 t = a.urec[pos[i]];
+                        r[i].x = t.x;
+                        r[i].y = t.y;
+                    } else {
+                        r[i] = *reinterpret_cast<const PostingPair *>(a.upos + pos[i]);
+                    }
+                }
 #pragma unroll
             for (uint32_t i = 0; i < kLookups; i++) {
                 const unsigned long long m = __ballot(present[i]);
@@ -386,6 +429,38 @@ __global__ void k_rank_fill(const uint32_t *uhash, uint64_t U, uint64_t n_entrie
     if (e % kRankBlock == 0) base[e / kRankBlock] = (uint32_t)at;
 }
 
+// per distinct hash: its posting range, or the list itself when it spans fewer than 32 genome ids
+__global__ void k_urec(const uint32_t *upos, const uint32_t *postings, uint64_t U, uint2 *out)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const uint32_t x = upos[u], y = upos[u + 1];
+    uint2 r = make_uint2(x, y);
+    if (y > x) {
+        const uint32_t first = postings[x];
+        if (postings[y - 1] - first < 32u) {  // (a list is sorted by genome)
+            uint32_t mask = 0;
+            for (uint32_t k = x; k < y; k++) mask |= 1u << (postings[k] - first);
+            r = make_uint2(0x80000000u | first, mask);
+        }
+    }
+    out[u] = r;
+}
+
+int ensure_urec(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
+{
+    // bit 31 tags a compact record: posting offsets and genome ids must stay below it; a genome that sits twice in a list
+    // (sketches with repeats) cannot be a bit
+    if (idx->d_urec || !idx->U || !idx->ref_sets || idx->H >= (1ULL << 31) || idx->n_ref >= (1u << 31)) return RK_OK;
+    DevBuf<uint2> out(ctx);
+    if (out.alloc(idx->U) != hipSuccess) return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu list records", (unsigned long long)idx->U);
+    hipLaunchKernelGGL(k_urec, dim3((unsigned)((idx->U + 255) / 256)), dim3(256), 0, stream, idx->d_upos, idx->d_postings, idx->U, out.p);
+    RK_HIP(ctx, hipGetLastError());
+    RK_HIP(ctx, hipStreamSynchronize(stream));  // once per index: a later call may come on another stream
+    idx->d_urec = out.release();
+    return RK_OK;
+}
+
 constexpr int kRankMaxBits = 30;  // 2^30 / 48 entries x 8 B = 171 MiB; above that: directory + binary search
 
 int ensure_rankbm(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
@@ -452,6 +527,8 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     p.cbits = counter_bits(idx, qs);
     int rc = ensure_rankbm(ctx, const_cast<rk_index *>(idx), stream);  // lazily built, cached in the index
     if (rc) return rc;
+    rc = ensure_urec(ctx, const_cast<rk_index *>(idx), stream);
+    if (rc) return rc;
     p.look = idx->wide ? kLookDir64 : (idx->d_rankbm ? kLookRank : kLookDir32);
     if (p.look != kLookRank) {  // prefix directory, lazily built like the rank bitmap
         rc = rk_index_ensure_dir(ctx, const_cast<rk_index *>(idx), stream);
@@ -493,6 +570,7 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     a.q_off = qs->d_off;
     a.rankbm = idx->d_rankbm;
     a.rankbase = idx->d_rankbase;
+    a.urec = idx->d_urec;
     a.uhash = idx->wide ? (const void *)idx->d_uhash64 : (const void *)idx->d_uhash;
     a.dir = idx->d_dir;
     a.upos = idx->d_upos;

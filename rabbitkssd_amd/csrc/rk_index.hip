@@ -354,6 +354,7 @@ void rk_index_free(rk_index *idx)
     rk_pool_free(ctx, idx->d_dir);
     rk_pool_free(ctx, idx->d_rankbm);
     rk_pool_free(ctx, idx->d_rankbase);
+    rk_pool_free(ctx, idx->d_urec);
     rk_pool_free(ctx, idx->d_sizes);
     rk_pool_free(ctx, idx->d_selfrange);
     rk_pool_free(ctx, idx->d_self_off);

@@ -137,6 +137,8 @@ struct rk_index {
                                      // {presence bits 0..31, presence bits 32..47 | 16-bit rank << 16}; the rank (number
                                      // of distinct indexed hashes below) is relative to d_rankbase[entry / 64]
     uint32_t *d_rankbase = nullptr;  // u32[entries / 64 + 1]
+    uint2 *d_urec = nullptr;         // lazily built by the query path: per distinct hash its posting range (upos[u], upos[u+1]) or, when
+                                     // the list spans < 32 genome ids, the list itself: (bit 31 | first genome, bitmask of first..first+31)
     uint32_t *d_postings = nullptr;  // u32[H]   (.dict order)
     bool wide = false;               // 64-bit hashes: d_uhash64 instead of d_uhash
     uint32_t *d_uhash = nullptr;     // u32[U]   sorted distinct hashes

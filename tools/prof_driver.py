@@ -80,12 +80,12 @@ def dist_rq(n_ref=100000, n_query=1000, steps=3):
               % (dt * 1e3, n_query, n_ref, n_query * n_ref, n_query * n_ref / dt, len(hits)))
 
 
-def dist_rq_dev(n_ref=100000, n_query=1000, steps=5, n_related=0):
-    """configs[4] shape, kernel only (rk_dist_rows_dev with explicit queries), HIP-event time per launch"""
+def dist_rq_dev(n_ref=100000, n_query=1000, steps=5, m_ref=76, m_query=45776, bits=24):
+    """configs[4] shape by default, kernel only (rk_dist_rows_dev with explicit queries), HIP-event time per launch"""
     ctx = capi.Context(0)
-    rn, rh, roff = synth.clade_sketches(n_ref, 76, 24, seed=31)
-    qn, qh, qoff = synth.clade_sketches(n_query, 45776, 24, seed=32)
-    index = ctx.index_build(ctx.sketches_from_host(rh, roff), 24)
+    rn, rh, roff = synth.clade_sketches(n_ref, m_ref, bits, seed=31)
+    qn, qh, qoff = synth.clade_sketches(n_query, m_query, bits, seed=32 if m_query != m_ref or n_query != n_ref else 31)
+    index = ctx.index_build(ctx.sketches_from_host(rh, roff), bits)
     qs = ctx.sketches_from_host(qh, qoff)
     hits = torch.empty((1 << 20) * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
     counters = torch.zeros(steps + 1, dtype=torch.int64, device="cuda")
