@@ -84,7 +84,19 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
     unsigned long long &s_base = *reinterpret_cast<unsigned long long *>(scal);
     uint32_t &s_total = scal[2];
     uint32_t &s_cursor = scal[3];
+    uint32_t *s_cells = scal + 4;  // [2] cell-list counters of consecutive units, taking turns
     if (tid == 0) s_cursor = 0;
+    // Sparse report without dense counter output: the row is zeroed ONCE.  The scan covers every cell a unit can
+    // touch and clears the non-zero quads it meets, so the row is clean again when the next unit scatters: no zero pass
+    // and two barriers less per unit (what matters for many small queries; a 45,776-hash query does not notice).
+    const bool keep_clean = !a.dense_mode && !a.common_dense;
+    if (keep_clean) {
+        uint4 *z = reinterpret_cast<uint4 *>(cnt);
+        for (uint32_t i = tid; i < a.cnt_words / 4; i += nthreads) z[i] = make_uint4(0, 0, 0, 0);
+        if (tid == 0) s_cells[0] = s_cells[1] = 0;
+        __syncthreads();
+    }
+    uint32_t par = 0;  // uniform: which of the two counters this unit's scan uses
 
     const K *qh = reinterpret_cast<const K *>(a.q_hashes);
     const K *uhash = reinterpret_cast<const K *>(a.uhash);
@@ -121,9 +133,11 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
         const uint32_t lo_id = tri_filter ? row + 1 : 0;   // src/dist.cpp:207: j > i
 
         uint4 *z4 = reinterpret_cast<uint4 *>(cnt);        // memset(row), src/dist.cpp:563
-        for (uint32_t i = tid; i < a.cnt_words / 4; i += nthreads) z4[i] = make_uint4(0, 0, 0, 0);
-        if (tid == 0) s_total = 0;
-        __syncthreads();
+        if (!keep_clean) {
+            for (uint32_t i = tid; i < a.cnt_words / 4; i += nthreads) z4[i] = make_uint4(0, 0, 0, 0);
+            if (tid == 0) s_total = 0;
+            __syncthreads();
+        }
 
         auto bump = [&](uint32_t id, bool valid) {
             const uint32_t c = id - col0;
@@ -276,6 +290,9 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
         }
         while (qn) walk();
         __syncthreads();  // all scatters of the unit done
+        // (clean rows: the counter of the NEXT unit's list; every thread read it for the unit before this one ahead of the barrier)
+        if (keep_clean && tid == 0) s_cells[par ^ 1] = 0;
+        uint32_t &s_ncells = keep_clean ? s_cells[par] : s_total;
 
         // ---- epilogue (src/dist.cpp:600-682; :207-255 in triangle mode) -------------------------------------
         if (a.common_dense) {
@@ -333,8 +350,14 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
                 for (int wi = 0; wi < 4; wi++)
 #pragma unroll
                     for (uint32_t s = 0; s < kPerWord; s++) n += ((w[wi] >> (s * CBITS % 32)) & kCellMask) >= min_common;
-                if (!n) continue;
-                uint32_t at = atomicAdd(&s_total, n);
+                if (!n) {
+                    if (keep_clean) z4[q] = make_uint4(0, 0, 0, 0);
+                    continue;
+                }
+                uint32_t at = atomicAdd(&s_ncells, n);
+                // a quad whose cells do not all fit the list stays in the row (and is not cleared): the walk below finds it
+                const bool fits = at + n <= a.cand_cap;
+                if (keep_clean && fits) z4[q] = make_uint4(0, 0, 0, 0);
                 const uint32_t cq = q * 4 * kPerWord;
 #pragma unroll
                 for (int wi = 0; wi < 4; wi++)
@@ -342,25 +365,31 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
                     for (uint32_t s = 0; s < kPerWord; s++) {
                         const uint32_t common = (w[wi] >> (s * CBITS % 32)) & kCellMask;
                         if (common >= min_common) {
-                            if (at < a.cand_cap) cand[at] = make_uint2(cq + wi * kPerWord + s, common);
+                            if (at < a.cand_cap) cand[at] = make_uint2(!keep_clean || fits ? cq + wi * kPerWord + s : 0xFFFFFFFFu, common);
                             at++;
                         }
                     }
             }
             __syncthreads();
-            const uint32_t n_cells = s_total;
-            if (n_cells <= a.cand_cap) {
-                for (uint32_t i = tid; i < n_cells; i += nthreads) {
+            const uint32_t n_cells = s_ncells;
+            if (n_cells <= a.cand_cap || keep_clean) {
+                for (uint32_t i = tid; i < min(n_cells, a.cand_cap); i += nthreads) {
                     const uint2 cj = cand[i];
                     const uint32_t j = col0 + cj.x;
                     rk_hit hrec;
-                    if (j >= jbeg && j < col1 && evaluate(j, (int)cj.y, hrec)) stage_hit(hrec);
+                    if (cj.x != 0xFFFFFFFFu && j >= jbeg && j < col1 && evaluate(j, (int)cj.y, hrec)) stage_hit(hrec);
                 }
-            } else {  // more sharing columns than the list holds: walk the row, one cell per lane
+            }
+            if (n_cells > a.cand_cap) {  // more sharing columns than the list holds: walk (what is left of) the row, one cell per lane
                 for (uint32_t c = (jbeg - col0) + tid; c < ncol; c += nthreads) {
                     const uint32_t common = cell(c);
                     rk_hit hrec;
                     if (common >= min_common && evaluate(col0 + c, (int)common, hrec)) stage_hit(hrec);
+                }
+                if (keep_clean) {  // the leftovers
+                    __syncthreads();
+                    for (uint32_t i = tid; i < a.cnt_words / 4; i += nthreads) z4[i] = make_uint4(0, 0, 0, 0);
+                    __syncthreads();
                 }
             }
         } else {
@@ -386,7 +415,8 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
                 }
             }
         }
-        __syncthreads();  // the row is zeroed next
+        if (!keep_clean) __syncthreads();  // the row is zeroed next
+        par ^= 1;
     }
 
     // flush the staged hits of this workgroup: one device-scope atomic, coalesced 8-byte stores
