@@ -583,9 +583,29 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     p.n_tiles = (idx->n_ref + tile - 1) / tile;
     p.cnt_words = (uint32_t)((((uint64_t)tile * p.cbits + 31) / 32 + 3) & ~3ULL);  // whole 16-byte quads
     // workgroup size follows the LDS footprint (it caps the resident workgroups): 7 x 256, 3 x 512, 2 x 768, 1 x 1024
+    // workgroup size: the one that keeps most waves resident per CU (registers admit ~5 waves per SIMD, LDS comes in
+    // 1,280-byte granules -- the runtime's occupancy answer, clamped by that rule); ties go to the bigger workgroup.
+    // Small counter rows therefore run as many 256-thread workgroups (10,000 16-bit columns: 5 per CU instead of 2 x 512).
     const size_t row_bytes = (size_t)p.cnt_words * 4;
-    p.threads = row_bytes + fixed_bytes(256) <= 22 * 1024 ? 256
-              : (row_bytes + fixed_bytes(512) <= 52 * 1024 ? 512 : (row_bytes + fixed_bytes(768) <= 79 * 1024 ? 768 : 1024));
+    distq_kernel_t kern_for_plan = pick_kernel(p.cbits, p.look);
+    auto resident_wgs = [&](uint32_t threads) -> int {
+        const size_t lds = row_bytes + fixed_bytes(threads);
+        if (lds > lds_max) return 0;
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute((const void *)kern_for_plan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        const int api = rk_occupancy(ctx, (const void *)kern_for_plan, (int)threads, lds);
+        const size_t granule = 1280;
+        return std::min<int>(api, (int)((160 * 1024) / ((lds + granule - 1) / granule * granule)));
+    };
+    p.threads = 1024;
+    int best_waves = -1;
+    for (uint32_t t : {256u, 512u, 768u, 1024u}) {
+        const int waves = resident_wgs(t) * (int)(t / 64);
+        if (waves >= best_waves && waves > 0) { best_waves = waves; p.threads = t; }
+    }
     p.lds_bytes = row_bytes + fixed_bytes(p.threads);
     p.row_step = o->row_step ? o->row_step : 1;
     p.row_first = o->row_first;
@@ -641,7 +661,7 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     if (p.lds_bytes > 48 * 1024)
         RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
     // persistent grid: as many workgroups as the chip holds, in whole rounds of 8 XCDs x n_tiles
-    const int per_cu = rk_occupancy(ctx, (const void *)kern, (int)p.threads, p.lds_bytes);
+    const int per_cu = resident_wgs(p.threads);
     const uint32_t per_round = 8 * p.n_tiles;
     const uint32_t total = p.n_units * p.n_tiles;
     const uint32_t total_padded = (total + per_round - 1) / per_round * per_round;
