@@ -7,23 +7,28 @@
 // the bound min(|largest query|, |largest reference|) on an intersection count allows, so that 100,000 reference
 // columns of 76-hash bacterial sketches are ONE 100 KB tile.
 //
-// Per unit:  zero the row | barrier | for every query hash: LOOK UP its posting list, keep the non-empty ones,
-//            WALK them with ds_add into the row | barrier | scan the row, evaluate, stage hits | barrier
+// Per unit:  for every query hash: LOOK UP its list record, keep the present ones, COUNT / WALK them into the row |
+//            barrier | scan the row into the cell list, clearing it | barrier | evaluate, stage hits.
+//            (The row is zeroed once per workgroup; a unit that reports every cell or copies the dense row out zeroes
+//            it per unit behind two more barriers.)
 //
 // Look-up (fused; round 1 ran it as a separate pass that wrote 8 B per query hash to HBM and read them back
-// through flags/scan/compact passes): the index's distinct hashes as a RANK BITMAP over the hash space, one
-// {32 presence bits, rank} pair per 32 consecutive hash values (2^(bits-5) x 8 B: 4 MiB for the 24-bit hashes of
-// L4K10, 64 MiB for the 28 bits of L3K10).  One 8-byte load answers "is h indexed" and "which distinct hash is
-// it"; a query's hashes are sorted, so consecutive lanes read consecutive words (a 3 Gb genome's 45,776 hashes touch
-// every 128-byte line of the 4 MiB table ~1.4 times: streaming, mostly L1/L2 hits).  Only present hashes (~11 % for
-// an unrelated mammal against 100,000 bacteria) go on to load their posting range (8 B from upos).  Hash spaces
-// above 2^30 and 64-bit hashes use the prefix directory + binary search instead.
+// through flags/scan/compact passes): the index's distinct hashes as a RANK BITMAP over the hash space, one 8-byte
+// entry per 48 consecutive hash values: 48 presence bits + a 16-bit rank relative to a u32 base every 64 entries
+// (2.8 MB for the 24-bit hashes of L4K10, 45 MB for the 28 bits of L3K10).  One 8-byte load (+ the base: one cache
+// line for the 64 sorted hashes of a wave) answers "is h indexed" and "which distinct hash is it"; a query's hashes
+// are sorted, so consecutive lanes read consecutive entries.  Only present hashes (~11 % for an unrelated mammal
+// against 100,000 bacteria) go on to load their LIST RECORD (8 B): the posting range, or -- for a list that spans
+// fewer than 32 genome ids, the neighbouring members of a clade -- the list itself as (bit 31 | first genome, bitmask).
+// Hash spaces above 2^30 and 64-bit hashes use the prefix directory + binary search instead of the bitmap.
 //
-// Compaction and walk: present ranges are appended to a per-wave LDS queue (ballot + popcount, no atomics); whenever
-// 64 are queued the wave pops them and walks 4 steps: in step j quad q serves the range held by lane 4q+j, every lane
-// fetching two postings with one 8-byte load, i.e. the first 8 postings of 16 lists per step.  Lists longer than 8
-// re-enter the queue as (x+8, y): any length is walked at full quad efficiency and there is no serial long-list
-// loop.  Integer/index work: bound by L1/L2 gather rate and LDS atomics -- no MFMA.
+// Compaction, counting and walk: present records are appended to a per-wave LDS queue (ballot + popcount, no atomics);
+// whenever 64 are queued the wave pops them.  Compact lists are counted by the WAVE when they fall into one 32-column
+// window (a query with relatives among the references names the same columns in most of its lists): one ballot per
+// occupied column, one conflict-free add per column; the others are scattered lane by lane.  Posting ranges are walked
+// in 4 steps: in step j quad q serves the range held by lane 4q+j, every lane fetching two postings with one 8-byte
+// load, i.e. the first 8 postings of 16 lists per step; lists longer than 8 re-enter the queue as (x+8, y).
+// Integer/index work: bound by the L1's pending misses (one cache line per probe) -- no MFMA.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
