@@ -14,9 +14,9 @@
 // 16 k-mer windows that END inside the lane are then cut out of that 96-bit string with
 // funnel shifts: no serial rolling dependency, 16 independent windows per lane.  The inner
 // 2*subk bases of the window are tested against bitmaps of the (symmetrised) selected .shuf
-// entries held in LDS; only the ~0.2 % survivors build both strands, pick the canonical
-// k-mer (dim_id, src/sketch.cpp:508-509), confirm it against the .shuf table (L2 / Infinity Cache; the big
-// LDS image variant holds an exact table) and append the dr_tuple to their genome's candidate region.
+// entries held in LDS; the ~0.2 % survivors wait in a per-wave LDS queue and are resolved 64 at a time: both strands,
+// the canonical k-mer (dim_id, src/sketch.cpp:508-509), confirmation against the .shuf table (L2 / Infinity Cache; the
+// big LDS image variant holds an exact table), and the dr_tuple goes to the genome's candidate region.
 // Per-genome dedup (the reference's unordered_set): one workgroup per genome sorts its region in LDS
 // (k_dedup), a scan and a placement kernel build the CSR; one upload and one read-back per batch.
 #include <cstring>
