@@ -807,7 +807,7 @@ constexpr size_t lds_for_workgroups(size_t n) { return kLdsPerCu / n / kLdsGranu
 
 // n_cols: columns an LDS row must hold (the whole reference range, or what lies behind a band's first row)
 int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_query_size,
-              const rk_dist_opts *o, bool want_self, uint32_t n_cols, Plan *p)
+              const rk_dist_opts *o, bool dense_mode, bool want_self, uint32_t n_cols, Plan *p)
 {
     if (o->kmer_size <= 0) return rk_fail(ctx, RK_ERR_ARG, "kmer_size must be positive");
     if (o->row_block < 0) return rk_fail(ctx, RK_ERR_ARG, "row_block must be >= 0");
@@ -878,8 +878,9 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     const uint32_t forced = ctx->sw_dist_threads;
     if (forced == 256 || forced == 512 || forced == 1024 || forced == 768) p->threads = forced;
     if (p->threads >= (uint32_t)kBatchFromThreads) p->lds_bytes += batch_extra;
-    // does a pair with distance exactly 1.0 (common == 0) pass the threshold?
-    p->dense_mode = rk_dense_mode(o) ? 1 : 0;
+    // does a pair with distance exactly 1.0 (common == 0) pass the threshold?  (decided by the caller from the EXACT
+    // options: rk_dist_rows hands the kernel a threshold a few ulps wider, which must not turn -D 1.0 into a dense report)
+    p->dense_mode = dense_mode ? 1 : 0;
     return RK_OK;
 }
 
@@ -976,11 +977,11 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
 // A boundary lies where the kernel variant changes (threads, mode, tiles) and at a multiple of row_step * row_block rows,
 // so that a band is a contiguous range of the shard's unit slots.
 
-int plan_bands(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, std::vector<Plan> *bands)
+int plan_bands(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool dense_mode, std::vector<Plan> *bands)
 {
     const uint32_t n = idx->n_ref;
     Plan cur;
-    int rc = make_plan(ctx, idx, n, idx->max_src_size, o, true, n, &cur);
+    int rc = make_plan(ctx, idx, n, idx->max_src_size, o, dense_mode, true, n, &cur);
     if (rc) return rc;
     bands->clear();
     const uint64_t round_rows = (uint64_t)cur.row_step * cur.row_block;  // one block of every shard
@@ -990,14 +991,14 @@ int plan_bands(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, std::vec
     auto plan_at = [&](uint64_t round, Plan *q) -> int {
         const uint64_t row = round * round_rows;
         const uint32_t col_base = (uint32_t)row & ~63u;  // whole 128-byte stretches of a 16-bit row
-        int prc = make_plan(ctx, idx, n, idx->max_src_size, o, true, n - col_base, q);
+        int prc = make_plan(ctx, idx, n, idx->max_src_size, o, dense_mode, true, n - col_base, q);
         q->col_base = col_base;
         q->slot_base = (uint32_t)(round * q->units_per_block);
         return prc;
     };
     auto differs = [&](const Plan &x, const Plan &y) { return x.threads != y.threads || x.mode != y.mode || x.n_tiles != y.n_tiles; };
     uint64_t t0 = 0;
-    while (ctx->sw_dist_bands && !rk_dense_mode(o)) {
+    while (ctx->sw_dist_bands && !dense_mode) {
         const uint64_t lo = t0 + min_rounds;
         if (lo + min_rounds > n_rounds) break;
         uint64_t hi = n_rounds - min_rounds;  // lo <= hi
@@ -1024,11 +1025,11 @@ int plan_bands(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, std::vec
     return RK_OK;
 }
 
-int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, rk_hit *hits_dev, uint64_t cap,
+int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool dense_mode, rk_hit *hits_dev, uint64_t cap,
                 unsigned long long *n_hits_dev, hipStream_t stream)
 {
     std::vector<Plan> bands;
-    int rc = plan_bands(ctx, idx, o, &bands);
+    int rc = plan_bands(ctx, idx, o, dense_mode, &bands);
     for (size_t b = 0; !rc && b < bands.size(); b++)
         rc = launch_dist(ctx, idx, idx->d_selfrange, idx->d_self_off, idx->d_src_off, idx->n_ref, o, bands[b], hits_dev, cap,
                          n_hits_dev, nullptr, stream);
@@ -1100,7 +1101,7 @@ int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *que
     if (!ctx || !idx || !opts || !buf || !cap) return RK_ERR_ARG;
     if (queries) return rk_distq_kernel_name(ctx, idx, queries, buf, cap);
     std::vector<Plan> bands;  // several bands: the variant of the first (widest rows)
-    int rc = plan_bands(ctx, idx, opts, &bands);
+    int rc = plan_bands(ctx, idx, opts, rk_dense_mode(opts), &bands);
     if (rc) return rc;
     const Plan &p = bands[0];
     if (bands.size() > 1)
@@ -1120,12 +1121,12 @@ int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *querie
         if (opts->triangle && queries->n != idx->n_ref)
             return rk_fail(ctx, RK_ERR_ARG, "triangle mode needs the indexed sketches as queries (%u vs %u)",
                            queries->n, idx->n_ref);
-        return rk_distq_launch(ctx, idx, queries, opts, hits_dev, hits_cap, (unsigned long long *)n_hits_dev, nullptr,
-                               (hipStream_t)stream);
+        return rk_distq_launch(ctx, idx, queries, opts, rk_dense_mode(opts), hits_dev, hits_cap, (unsigned long long *)n_hits_dev,
+                               nullptr, (hipStream_t)stream);
     }
     if (!opts->triangle || !idx->d_selfrange)
         return rk_fail(ctx, RK_ERR_ARG, "queries == NULL needs triangle=1 and an index built by rk_index_build");
-    return launch_self(ctx, idx, opts, hits_dev, hits_cap, (unsigned long long *)n_hits_dev, (hipStream_t)stream);
+    return launch_self(ctx, idx, opts, rk_dense_mode(opts), hits_dev, hits_cap, (unsigned long long *)n_hits_dev, (hipStream_t)stream);
 }
 
 int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
@@ -1144,12 +1145,14 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
         return rk_fail(ctx, RK_ERR_ARG, "triangle mode needs the indexed sketches as queries (%u vs %u)",
                        n_query, idx->n_ref);
     int rc = RK_OK;
-    // the device reports with a threshold ~64 ulps wider; host_exact_distances() decides with the host's libm
+    // the device reports with a threshold ~64 ulps wider; host_exact_distances() decides with the host's libm.
+    // Whether distance 1.0 (common == 0) is reportable -- the dense report: every cell a hit, O(n^2) records -- is decided
+    // from the EXACT threshold: the default -D 1.0 of alldist (`1.0 < 1.0` is false, src/dist.cpp:232) stays sparse.
     const rk_dist_opts *exact_opts = opts;
     rk_dist_opts widened = *opts;
     if (widened.max_dist > 0.0) widened.max_dist += widened.max_dist * 0x1p-46;
     opts = &widened;
-    const bool dense_mode = rk_dense_mode(opts);
+    const bool dense_mode = rk_dense_mode(exact_opts);
     hipStream_t stream = ctx->stream;
 
     DevBuf<int32_t> dense(ctx);
@@ -1179,9 +1182,9 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
                            (unsigned long long)cap);
         RK_HIP(ctx, hipMemsetAsync(counter.p, 0, 8, stream));
         if (self)
-            rc = launch_self(ctx, idx, opts, hits.p, cap, counter.p, stream);
+            rc = launch_self(ctx, idx, opts, dense_mode, hits.p, cap, counter.p, stream);
         else
-            rc = rk_distq_launch(ctx, idx, queries, opts, hits.p, cap, counter.p, common_dense ? dense.p : nullptr, stream);
+            rc = rk_distq_launch(ctx, idx, queries, opts, dense_mode, hits.p, cap, counter.p, common_dense ? dense.p : nullptr, stream);
         if (rc) return rc;
         unsigned long long n = 0;
         rc = rk_read_back(ctx, &n, counter.p, 8, stream);

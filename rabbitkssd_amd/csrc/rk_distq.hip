@@ -39,7 +39,7 @@
 
 namespace {
 
-constexpr uint32_t kQueueCap = 128;     // ranges per wave: < 64 left over + <= 64 appended
+constexpr uint32_t kQueueCap = 128;     // ranges per wave: < 64 left over (the append drains first) + <= 64 appended
 constexpr uint32_t kMaxThreads = 1024;
 constexpr uint32_t kLookups = 4;        // query hashes per lane and iteration (independent loads in flight)
 
@@ -289,7 +289,9 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
                 if (m) {  // uniform
                     if (present[i]) queue[qn + __popcll(m & lt_mask)] = make_uint2(r[i].x, r[i].y);
                     qn += __popcll(m);
-                    if (qn >= 64) walk();
+                    // a walk re-queues every list with more than 8 postings left, so one walk need not shrink the
+                    // queue: drain until fewer than 64 wait, then the next 64 fit
+                    while (qn >= 64) walk();
                 }
             }
         }
@@ -484,6 +486,7 @@ __global__ void k_urec(const uint32_t *upos, const uint32_t *postings, uint64_t 
 
 int ensure_urec(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
 {
+    std::lock_guard<std::mutex> lk(idx->lazy_mu);
     // bit 31 tags a compact record: posting offsets and genome ids must stay below it; a genome that sits twice in a list
     // (sketches with repeats) cannot be a bit
     if (idx->d_urec || !idx->U || !idx->ref_sets || idx->H >= (1ULL << 31) || idx->n_ref >= (1u << 31)) return RK_OK;
@@ -500,6 +503,7 @@ constexpr int kRankMaxBits = 30;  // 2^30 / 48 entries x 8 B = 171 MiB; above th
 
 int ensure_rankbm(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
 {
+    std::lock_guard<std::mutex> lk(idx->lazy_mu);
     if (idx->d_rankbm || idx->wide || idx->hash_bits > kRankMaxBits) return RK_OK;
     const uint64_t n_entries = ((1ULL << idx->hash_bits) + kRankSpan - 1) / kRankSpan;
     DevBuf<uint2> out(ctx);
@@ -551,8 +555,8 @@ int rk_distq_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs
     return RK_OK;
 }
 
-int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, const rk_dist_opts *o, rk_hit *hits_dev,
-                    uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev, hipStream_t stream)
+int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, const rk_dist_opts *o, bool dense_mode,
+                    rk_hit *hits_dev, uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev, hipStream_t stream)
 {
     if (o->kmer_size <= 0) return rk_fail(ctx, RK_ERR_ARG, "kmer_size must be positive");
     if (o->row_block < 0) return rk_fail(ctx, RK_ERR_ARG, "row_block must be >= 0");
@@ -647,7 +651,7 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     a.triangle = o->triangle;
     a.metric = o->metric != 0;  // the reference treats any non-zero isContainment as containment
     a.kmer_size = o->kmer_size;
-    a.dense_mode = rk_dense_mode(o) ? 1 : 0;
+    a.dense_mode = dense_mode ? 1 : 0;
     a.max_dist = o->max_dist;
     a.min_jorc = 0.0;
     a.min_ref_size = (uint32_t)std::min<uint64_t>(idx->min_ref_size, 0xFFFFFFFFu);

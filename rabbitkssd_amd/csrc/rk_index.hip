@@ -326,6 +326,7 @@ int classify_lists(rk_ctx *ctx, rk_index *idx, hipStream_t st)
 // prefix directory into the sorted distinct hashes: built on first use (64-bit hashes, hash spaces above 2^30)
 int rk_index_ensure_dir(rk_ctx *ctx, rk_index *idx, hipStream_t st)
 {
+    std::lock_guard<std::mutex> lk(idx->lazy_mu);
     if (idx->d_dir) return RK_OK;
     const uint32_t nb = 1u << idx->dir_bits;
     DevBuf<uint32_t> dir(ctx);
@@ -337,6 +338,7 @@ int rk_index_ensure_dir(rk_ctx *ctx, rk_index *idx, hipStream_t st)
         hipLaunchKernelGGL(k_dir<uint32_t>, dim3(blocks_for((uint64_t)nb + 1)), dim3(kThreads), 0, st,
                            idx->d_uhash, idx->U, idx->dir_shift, nb, dir.p);
     RK_HIP(ctx, hipGetLastError());
+    RK_HIP(ctx, hipStreamSynchronize(st));  // once per index: a later call may come on another stream
     idx->d_dir = dir.release();
     return RK_OK;
 }
@@ -372,6 +374,7 @@ uint64_t rk_index_sum_sq(const rk_index *cidx)
 {
     if (!cidx) return 0;
     rk_index *idx = const_cast<rk_index *>(cidx);  // cached on first use: only the roofline report asks for it
+    std::lock_guard<std::mutex> lk(idx->lazy_mu);
     if (idx->sum_sq_known) return idx->sum_sq;
     rk_ctx *ctx = idx->ctx;
     if (hipSetDevice(ctx->device) != hipSuccess) return 0;
@@ -763,13 +766,29 @@ extern "C" int rk_index_broadcast(const rk_index *src, rk_ctx *const *dst, uint3
     // every peer pulls the blob over its own xGMI link at the same time (the links are point to point, so a
     // one-to-all of direct copies moves the blob once per link, like a pipelined ring, without a communicator)
     std::vector<char *> peer(n_dst, nullptr);
+    for (uint32_t i = 0; i < n_dst; i++)
+        if (!dst[i]) return RK_ERR_ARG;
+    // error exit: copies already enqueued into the first n peer blobs may still be running -- wait for them before the
+    // blocks return to their pools (a later allocation could receive a block that is still being written), and leave
+    // the caller's device current
+    auto abandon = [&](uint32_t n) {
+        for (uint32_t j = 0; j < n; j++) {
+            if (!peer[j]) continue;
+            if (hipSetDevice(dst[j]->device) == hipSuccess) (void)hipStreamSynchronize(dst[j]->stream);
+            rk_pool_free(dst[j], peer[j]);
+        }
+        (void)hipGetLastError();
+        (void)hipSetDevice(sctx->device);
+    };
     for (uint32_t i = 0; i < n_dst; i++) {
         rk_ctx *d = dst[i];
-        if (!d) return RK_ERR_ARG;
-        RK_HIP(d, hipSetDevice(d->device));
+        if (hipSetDevice(d->device) != hipSuccess) {
+            abandon(i);
+            return rk_fail(d, RK_ERR_HIP, "cannot select device %d", d->device);
+        }
         peer[i] = static_cast<char *>(rk_pool_alloc(d, bytes));
         if (!peer[i]) {
-            for (uint32_t j = 0; j < i; j++) rk_pool_free(dst[j], peer[j]);
+            abandon(i);
             return rk_fail(d, RK_ERR_NOMEM, "cannot allocate the %llu-byte index blob on device %d", (unsigned long long)bytes, d->device);
         }
         hipError_t e;
@@ -785,7 +804,7 @@ extern "C" int rk_index_broadcast(const rk_index *src, rk_ctx *const *dst, uint3
             e = hipMemcpyPeerAsync(peer[i], d->device, blob.p, sctx->device, bytes, d->stream);
         }
         if (e != hipSuccess) {
-            for (uint32_t j = 0; j <= i; j++) rk_pool_free(dst[j], peer[j]);
+            abandon(i + 1);
             return rk_fail(d, RK_ERR_HIP, "index copy to device %d failed: %s", d->device, hipGetErrorString(e));
         }
     }
@@ -796,12 +815,15 @@ extern "C" int rk_index_broadcast(const rk_index *src, rk_ctx *const *dst, uint3
         else
             rc = rk_index_unpack_dev(d, peer[i], bytes, d->stream, &out[i]);
     }
-    for (uint32_t i = 0; i < n_dst; i++) rk_pool_free(dst[i], peer[i]);
-    if (rc)
+    if (rc) {
+        abandon(n_dst);  // waits for the copies of the peers behind the failing one
         for (uint32_t i = 0; i < n_dst; i++) {
             rk_index_free(out[i]);
             out[i] = nullptr;
         }
+        return rc;
+    }
+    for (uint32_t i = 0; i < n_dst; i++) rk_pool_free(dst[i], peer[i]);
     (void)hipSetDevice(sctx->device);
     return rc;
 }

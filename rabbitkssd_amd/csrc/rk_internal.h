@@ -153,13 +153,16 @@ struct rk_index {
                                       // (genome 2p+1 shares the hash with 2p): the pair kernel skips them
     uint64_t n_self = 0;
     uint64_t *d_src_off = nullptr;   // u64[n_ref+1] offsets of the source sketches (built only)
+    std::mutex lazy_mu;              // serialises the lazy builders (prefix directory, rank bitmap, list records, sum of
+                                     // squares): two host threads may query one index
 };
 
 // prefix directory into the sorted distinct hashes, built on first use (rk_index.hip)
 int rk_index_ensure_dir(rk_ctx *ctx, rk_index *idx, hipStream_t stream);
 // explicit queries (index_dist): lookup + counting + epilogue in one kernel (rk_distq.hip).  Enqueues on `stream`,
 // allocates nothing once the index's rank bitmap exists.  dense_dev: optional int32[n_query * n_ref].
-int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries, const rk_dist_opts *opts,
+// dense_mode: every cell is reportable (rk_dense_mode of the caller's EXACT options).
+int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries, const rk_dist_opts *opts, bool dense_mode,
                     rk_hit *hits_dev, uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev,
                     hipStream_t stream);
 // the kernel variant rk_distq_launch would pick, as a profiler prints it

@@ -140,6 +140,33 @@ def test_crowded_hash_space_long_lists_and_full_rows(ctx, n, m, bits):
     assert_hits_equal(mine, want_hits)
 
 
+def test_query_path_long_lists_keep_the_wave_queue_bounded(ctx):
+    # explicit queries of ~1,800 hashes against 3,000 references in a 13-bit hash space: every query hash is indexed and
+    # its list holds ~100 genomes spread over all ids (no compact record), so every walk re-queues all 64 lists it
+    # popped while the look-ups of the same wave keep appending 64 more: the per-wave queue must drain before it
+    # appends (round-2 advice: `if (qn >= 64) walk()` let it run past its 128 slots into the next wave's queue)
+    rng = np.random.default_rng(77)
+    bits = 13
+    parts = [np.unique(rng.integers(0, 1 << bits, size=300, dtype=np.uint64).astype(np.uint32)) for _ in range(3000)]
+    roff = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    rh = np.concatenate(parts)
+    qparts = [np.unique(rng.integers(0, 1 << bits, size=2000, dtype=np.uint64).astype(np.uint32)) for _ in range(24)]
+    qoff = np.concatenate([[0], np.cumsum([len(p) for p in qparts])]).astype(np.uint64)
+    qh = np.concatenate(qparts)
+    postings, counts = ok.index_build32(rh, roff, bits)
+    assert counts.min() > 64
+    sizes = np.diff(roff).astype(np.uint32)
+    idx = ctx.index_build(ctx.sketches_from_host(rh, roff), bits)
+    want_hits, want = ok.index_dist32(counts, bits, postings, sizes, qh, qoff, 0, 0, 20, 0.14, threads=4, want_dense=True)
+    hits, dense = ctx.dist_rows(idx, ctx.sketches_from_host(qh, qoff), 0, 0, 20, 0.14, want_dense=True)
+    assert np.array_equal(dense, want)
+    assert_hits_equal(hits, want_hits)
+    want_hits, _ = ok.index_dist32(counts, bits, postings, sizes, qh, qoff, 0, 1, 20, 0.07, threads=4)
+    assert len(want_hits) > 1000
+    hits, _ = ctx.dist_rows(idx, ctx.sketches_from_host(qh, qoff), 0, 1, 20, 0.07)   # sparse report, clean rows
+    assert_hits_equal(hits, want_hits)
+
+
 @pytest.mark.parametrize("n,block,world", [(500, 2, 4), (501, 16, 3), (37, 16, 8), (1000, 6, 5)])
 def test_block_cyclic_row_sharding_union_equals_full(ctx, n, block, world):
     # blocks of `block` rows dealt round-robin to `world` shards; even blocks run the pair kernel
@@ -153,6 +180,33 @@ def test_block_cyclic_row_sharding_union_equals_full(ctx, n, block, world):
         merged = np.concatenate(parts)
         merged = merged[np.lexsort((merged["col"], merged["row"]))]
         assert merged.tobytes() == full.tobytes()
+
+
+def test_default_threshold_of_alldist_stays_sparse():
+    # `alldist` without -D compares `dist < 1.0` (src/main.cpp:46, src/dist.cpp:232): pairs that share nothing are NOT
+    # reported.  The synchronous API hands the kernel a threshold a few ulps wider; that must not turn the call into the
+    # dense report (every pair a 40-byte record, sorted and downloaded, then dropped again on the host)
+    c = capi.Context(0)
+    n = 3000
+    names, h, off = synth.clade_sketches(n, 100, 22, seed=41)
+    postings, counts = ok.index_build32(h, off, 22)
+    sizes = np.diff(off).astype(np.uint32)
+    idx = c.index_build(c.sketches_from_host(h, off), 22)
+    want, _ = ok.index_dist32(counts, 22, postings, sizes, h, off, 1, 0, 20, 1.0, threads=4)
+    assert 0 < len(want) < n * (n - 1) // 2 // 10
+    before = c.pool_stats()[0]
+    mine, _ = c.dist_rows(idx, None, 1, 0, 20, 1.0)
+    assert_hits_equal(mine, want)
+    assert c.pool_stats()[0] - before < 40 * n * (n - 1) // 2 // 4   # no O(n^2) hit buffer
+    mine, _ = c.dist_rows(idx, c.sketches_from_host(h, off), 1, 0, 20, 1.0)   # explicit queries, same rule
+    assert_hits_equal(mine, want)
+    # `dist` compares `<=` (src/dist.cpp:624): there the default reports every pair
+    q = c.sketches_from_host(h[: int(off[40])], off[:41])
+    want, _ = ok.index_dist32(counts, 22, postings, sizes, h[: int(off[40])], off[:41], 0, 0, 20, 1.0, threads=4)
+    assert len(want) == 40 * n
+    mine, _ = c.dist_rows(idx, q, 0, 0, 20, 1.0)
+    assert_hits_equal(mine, want)
+    c.close()
 
 
 def test_pair_kernel_equals_single_row_kernel(ctx, monkeypatch):
