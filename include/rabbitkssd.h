@@ -200,6 +200,13 @@ int rk_index_export64(const rk_index *idx, uint32_t *postings, uint64_t *hashes,
 int rk_index_import64(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const uint64_t *hashes,
                       const uint32_t *counts, uint64_t n_hash, int hash_bits, const uint32_t *ref_sizes,
                       uint32_t n_ref, rk_index **out);
+/* Internal genome order.  rk_index_build renumbers the genomes so that relatives (genomes that share several of their
+ * smallest hashes) become neighbours, whatever order the collection was listed in -- the reference's OpenMP loop leaves
+ * them in completion order (src/sketch.cpp:558-568); the device layout (compact posting slices, row pairs) relies on
+ * neighbours being relatives.  Nothing of this is visible in results: hit records, dense counter rows and exported
+ * postings carry the caller's genome indices.  It only decides WHICH pairs a row shard (rk_dist_opts.row_first/row_step/
+ * row_block) computes: shards partition the rows of the internal order.  orig_out[i] = caller's index of internal genome i. */
+int rk_index_order(const rk_index *idx, uint32_t *orig_out);
 uint64_t rk_index_total(const rk_index *idx);    /* H = number of postings        */
 uint64_t rk_index_distinct(const rk_index *idx); /* U = number of distinct hashes */
 uint32_t rk_index_genomes(const rk_index *idx);
@@ -234,7 +241,9 @@ typedef struct rk_dist_opts {
                            value for multi-GPU runs)                                       */
     double max_dist;    /* -D                                                          */
     uint32_t row_first; /* this shard owns blocks row_first, row_first+row_step, ...:  */
-    uint32_t row_step;  /*   row sharding across GPUs; 0,1 = all rows                  */
+    uint32_t row_step;  /*   row sharding across GPUs; 0,1 = all rows.  queries == NULL (self join): rows of the
+                             index's internal genome order (rk_index_order); a reported pair belongs to the shard of
+                             its member that comes first in that order                                            */
 } rk_dist_opts;
 
 /* Counts |S_q n S_r| through the inverted index and applies the reference's epilogue.

@@ -23,7 +23,7 @@ EXPORTS = [
     "rk_sketches_from_host", "rk_sketches_from_host64", "rk_sketches_download64", "rk_sketches_is64", "rk_sketches_from_dev", "rk_sketches_count", "rk_sketches_total", "rk_sketches_windows",
     "rk_sketches_download", "rk_sketches_hashes_dev", "rk_sketches_off_dev", "rk_sketches_free",
     "rk_index_build", "rk_index_import", "rk_index_export", "rk_index_import64", "rk_index_export64", "rk_index_total",
-    "rk_index_distinct", "rk_index_genomes", "rk_index_hash_bits", "rk_index_sum_sq",
+    "rk_index_distinct", "rk_index_genomes", "rk_index_order", "rk_index_hash_bits", "rk_index_sum_sq",
     "rk_index_free", "rk_index_blob_bytes", "rk_index_pack_dev", "rk_index_unpack_dev", "rk_index_broadcast", "rk_dist_rows", "rk_dist_rows_dev", "rk_topn_rows", "rk_format_hit",
 ]
 
@@ -368,6 +368,21 @@ class Index(_Obj):
     @property
     def blob_bytes(self):
         return lib().rk_index_blob_bytes(self._h)
+
+    @property
+    def order(self):
+        """orig[i] = caller's index of internal genome i (rk_index_order)"""
+        orig = np.zeros(self.genomes, dtype=np.uint32)
+        self.ctx.check(lib().rk_index_order(self._h, _ptr(orig)))
+        return orig
+
+    def shard_of(self, hits, row_step, row_block=1):
+        """which row shard (rk_dist_opts.row_first) computes each hit of a self join: rows are dealt in blocks of row_block
+        consecutive genomes of the INTERNAL order, and a pair belongs to the member that comes first in that order"""
+        inv = np.empty(self.genomes, dtype=np.int64)
+        inv[self.order] = np.arange(self.genomes)
+        irow = np.minimum(inv[hits["row"]], inv[hits["col"]])
+        return (irow // max(1, row_block)) % max(1, row_step)
 
     def pack_dev(self, blob_dev_ptr, blob_cap, stream=0):
         self.ctx.check(lib().rk_index_pack_dev(self._h, C.c_void_p(blob_dev_ptr), C.c_uint64(blob_cap),

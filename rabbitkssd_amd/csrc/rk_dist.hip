@@ -53,6 +53,7 @@ struct DistArgs {
     const uint64_t *size_off;   // u64[n_query+1] offsets whose differences are the sketch sizes
     const uint32_t *postings;
     const uint32_t *ref_sizes;
+    const uint32_t *orig;        // internal genome id -> the caller's (null: identity); applied where a hit leaves the kernel
     const uint64_t *range_split; // pair mode: u64[n_query], a row's slices from here on are covered by its partner
     uint32_t n_query, n_ref;
     uint32_t row_first, row_step, row_block, units_per_block, n_units;
@@ -275,11 +276,20 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
         const int denom = a.metric ? min(size0, size1) : size0 + size1 - common;
         if ((double)common < a.min_jorc * (double)denom) return false;
         const JorcDist jd = rk_distance(common, size0, size1, a.metric, a.kmer_size);
-        hrec.row = row;
-        hrec.col = j;
+        // the caller's genome indices: a pair of the (internal) triangle is reported with its smaller index as the row,
+        // like the reference's loop `for j > i` does (src/dist.cpp:207); jaccard / containment are symmetric
+        uint32_t out_row = row, out_col = j;
+        bool flip = false;
+        if (a.orig) {
+            out_row = a.orig[row];
+            out_col = a.orig[j];
+            flip = a.triangle && out_row > out_col;
+        }
+        hrec.row = flip ? out_col : out_row;
+        hrec.col = flip ? out_row : out_col;
         hrec.common = common;
-        hrec.size0 = size0;
-        hrec.size1 = size1;
+        hrec.size0 = flip ? size1 : size0;
+        hrec.size1 = flip ? size0 : size1;
         hrec.pad_ = 0;
         hrec.jorc = jd.jorc;
         hrec.dist = jd.dist;
@@ -896,6 +906,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.size_off = size_off;
     a.postings = idx->d_postings;
     a.ref_sizes = idx->d_sizes;
+    a.orig = idx->relabeled ? idx->d_orig : nullptr;
     a.n_query = n_query;
     a.n_ref = idx->n_ref;
     a.row_first = p.row_first;

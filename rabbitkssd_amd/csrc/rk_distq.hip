@@ -56,6 +56,7 @@ struct DistQArgs {
     const uint32_t *upos;        // u32[U+1] posting offsets of the distinct hashes
     const uint32_t *postings;
     const uint32_t *ref_sizes;
+    const uint32_t *orig;        // internal reference id -> the caller's (null: identity)
     int32_t hash_bits, dir_shift;
     uint32_t n_query, n_ref;
     uint32_t row_first, row_step, row_block, n_units;   // block-cyclic row shard (rk_dist_opts)
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
         const uint32_t col0 = tile * a.tile_cols;
         const uint32_t col1 = min(a.n_ref, col0 + a.tile_cols);
         const uint32_t ncol = col1 - col0;
-        const bool tri_filter = a.triangle && !a.common_dense;
+        // (a renumbered index: the columns are internal ids, `j > i` is decided on the caller's ids where a cell is evaluated)
+        const bool tri_filter = a.triangle && !a.common_dense && !a.orig;
         if (tri_filter && col1 <= row + 1) continue;       // nothing right of the diagonal in this tile
         const uint32_t lo_id = tri_filter ? row + 1 : 0;   // src/dist.cpp:207: j > i
 
@@ -303,11 +305,11 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
 
         // ---- epilogue (src/dist.cpp:600-682; :207-255 in triangle mode) -------------------------------------
         if (a.common_dense) {
-            int32_t *dst = a.common_dense + (size_t)row * a.n_ref + col0;
-            for (uint32_t i = tid; i < ncol; i += nthreads) dst[i] = (int32_t)cell(i);
+            int32_t *dst = a.common_dense + (size_t)row * a.n_ref;
+            for (uint32_t i = tid; i < ncol; i += nthreads) dst[a.orig ? a.orig[col0 + i] : col0 + i] = (int32_t)cell(i);
         }
         const int qsize = (int)(qe - qb);
-        const uint32_t jbeg = a.triangle ? max(col0, row + 1) : col0;  // :207 / :600
+        const uint32_t jbeg = a.triangle && !a.orig ? max(col0, row + 1) : col0;  // :207 / :600
         // Row-level reject, applied while the row is scanned: a reportable cell needs common >= min_jorc * denominator
         // (the exact-safe pre-filter below) and the denominator is at least the query's size (jaccard: |q| + |r| - common
         // with |r| >= common) or min(|q|, smallest non-empty reference) (containment).  A 45,776-hash query shares 1-2
@@ -323,9 +325,11 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
             // and min_jorc sits strictly below the value at the threshold)
             const int denom = a.metric ? min(size0, size1) : size0 + size1 - common;
             if ((double)common < a.min_jorc * (double)denom) return false;
+            const uint32_t out_col = a.orig ? a.orig[j] : j;
+            if (a.orig && a.triangle && out_col <= row) return false;  // :207, on the caller's ids
             const JorcDist jd = rk_distance(common, size0, size1, a.metric, a.kmer_size);
             hrec.row = row;
-            hrec.col = j;
+            hrec.col = out_col;
             hrec.common = common;
             hrec.size0 = size0;
             hrec.size1 = size1;
@@ -635,6 +639,7 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     a.upos = idx->d_upos;
     a.postings = idx->d_postings;
     a.ref_sizes = idx->d_sizes;
+    a.orig = idx->relabeled ? idx->d_orig : nullptr;
     a.hash_bits = idx->hash_bits;
     a.dir_shift = idx->dir_shift;
     a.n_query = qs->n;

@@ -290,6 +290,210 @@ __global__ void k_scatter_counts(const uint32_t *uhash, const uint32_t *upos, ui
     if (i < U) counts[uhash[i]] = upos[i + 1] - upos[i];
 }
 
+
+// ---- internal genome order ------------------------------------------------------------------------------------
+// Compact slices, list records and row pairs pay off when the genomes that share a hash have neighbouring ids.  A
+// collection arrives in whatever order its files were listed (or completed, src/sketch.cpp:558-568), so the build
+// renumbers it: genomes are clustered by their kMinK smallest hashes (a bottom-k MinHash of the sketch: two genomes
+// with Jaccard similarity j share each of them with probability ~j), every genome attaches to the smallest-id genome
+// that shares at least two of them, clusters become runs of consecutive internal ids (ordered by their smallest
+// member, members by their original id -- a collection that already lists relatives together keeps its order).
+// The clustering only shapes the data layout: every count stays exact whatever it decides.
+constexpr uint32_t kMinK = 16;
+constexpr unsigned long long kEmptySlot = ~0ULL;
+__device__ inline uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+template <class K> __device__ inline uint32_t fold_hash(K h)
+{
+    if constexpr (sizeof(K) == 8) return (uint32_t)(h ^ (h >> 32));
+    else return (uint32_t)h;
+}
+
+// table slot = (hash << 32 | smallest genome that lists the hash among its kMinK smallest); open addressing
+template <class K>
+__global__ void k_minhash_insert(const K *hashes, const uint64_t *off, uint32_t n_genomes, unsigned long long *table, uint32_t mask)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = (uint32_t)(t / kMinK), i = (uint32_t)(t % kMinK);
+    if (g >= n_genomes) return;
+    const uint64_t e = off[g] + i;
+    if (e >= off[g + 1]) return;
+    const uint32_t h = fold_hash(hashes[e]);
+    const unsigned long long mine = ((unsigned long long)h << 32) | g;
+    uint32_t slot = mix32(h) & mask;
+    for (uint32_t probe = 0; probe <= mask; probe++) {
+        unsigned long long cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmptySlot) {
+            cur = atomicCAS(&table[slot], kEmptySlot, mine);
+            if (cur == kEmptySlot) return;
+        }
+        if ((uint32_t)(cur >> 32) == h) {
+            atomicMin(&table[slot], mine);
+            return;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+
+// parent[g] = the smallest genome below g that shares at least two of g's kMinK smallest hashes (g itself if none)
+template <class K>
+__global__ void k_minhash_vote(const K *hashes, const uint64_t *off, uint32_t n_genomes, const unsigned long long *table,
+                               uint32_t mask, uint32_t *parent)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_genomes) return;
+    const uint64_t e0 = off[g];
+    const uint32_t n = (uint32_t)min((uint64_t)kMinK, off[g + 1] - e0);
+    uint32_t r[kMinK];
+#pragma unroll
+    for (uint32_t i = 0; i < kMinK; i++) {
+        r[i] = g;
+        if (i < n) {
+            const uint32_t h = fold_hash(hashes[e0 + i]);
+            uint32_t slot = mix32(h) & mask;
+            for (uint32_t probe = 0; probe <= mask; probe++) {
+                const unsigned long long cur = table[slot];
+                if (cur == kEmptySlot) break;
+                if ((uint32_t)(cur >> 32) == h) { r[i] = (uint32_t)cur; break; }
+                slot = (slot + 1) & mask;
+            }
+        }
+    }
+    uint32_t best = g;
+#pragma unroll
+    for (uint32_t i = 0; i < kMinK; i++) {
+        uint32_t votes = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kMinK; j++) votes += r[j] == r[i];
+        if (votes >= 2 && r[i] < best) best = r[i];
+    }
+    parent[g] = best;
+}
+
+// key[g] = (root of g's cluster, g): parents only ever point to smaller ids, so the walk ends at a fixed point
+__global__ void k_cluster_keys(const uint32_t *parent, uint32_t n_genomes, int id_bits, unsigned long long *keys)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_genomes) return;
+    uint32_t p = parent[g];
+    for (uint32_t hop = 0; hop < n_genomes; hop++) {
+        const uint32_t q = parent[p];
+        if (q == p) break;
+        p = q;
+    }
+    keys[g] = ((unsigned long long)p << id_bits) | g;
+}
+
+// sorted keys -> orig[internal id], sizes in internal order
+__global__ void k_order_from_keys(const unsigned long long *keys, uint32_t n_genomes, int id_bits, const uint64_t *off,
+                                  uint32_t *orig, uint32_t *sizes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_genomes) return;
+    const uint32_t g = (uint32_t)(keys[i] & ((1ULL << id_bits) - 1ULL));
+    orig[i] = g;
+    sizes[i] = (uint32_t)(off[g + 1] - off[g]);
+}
+
+// single workgroup: off_new = exclusive scan of the sizes in internal order
+__global__ void k_offsets_scan(const uint32_t *sizes, uint32_t n_genomes, uint64_t *off_new)
+{
+    __shared__ unsigned long long part[1024 / 64];
+    __shared__ unsigned long long carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_genomes; base += blockDim.x) {
+        const uint32_t g = base + tid;
+        const unsigned long long len = g < n_genomes ? sizes[g] : 0ULL;
+        unsigned long long incl = len;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += t;
+        }
+        if (lane == 63) part[wave] = incl;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (uint32_t w = 0; w < wave; w++) before += part[w];
+        if (g < n_genomes) off_new[g] = before + incl - len;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = carry;
+            for (uint32_t w = 0; w < nw; w++) t += part[w];
+            carry = t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) off_new[n_genomes] = carry;
+}
+
+// one wave per internal genome: its hashes move to their place in the internal-order CSR
+template <class K>
+__global__ void k_gather_sketches(const K *hashes, const uint64_t *off, const uint32_t *orig, const uint64_t *off_new,
+                                  uint32_t n_genomes, K *out)
+{
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n_genomes) return;
+    const uint64_t src = off[orig[i]], dst = off_new[i], n = off_new[i + 1] - dst;
+    for (uint64_t k = threadIdx.x & 63; k < n; k += 64) out[dst + k] = hashes[src + k];
+}
+
+__global__ void k_iota(uint32_t n, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+
+// .dict order of a renumbered index: within every list the genomes ascend by the CALLER's ids (src/sketch.cpp:979-985
+// pushes genome i onto hashMapId[hash] for i ascending).  key = (list number, original id), one radix sort.
+__global__ void k_export_keys(const uint32_t *postings, const uint32_t *upos, uint64_t U, uint64_t H, const uint32_t *orig,
+                              unsigned long long *keys)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= H) return;
+    uint64_t lo = 0, hi = U;  // largest u with upos[u] <= k
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (upos[mid] <= k) lo = mid; else hi = mid;
+    }
+    keys[k] = ((unsigned long long)lo << 32) | orig[postings[k]];
+}
+__global__ void k_low_halves(const unsigned long long *keys, uint64_t n, uint32_t *out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = (uint32_t)keys[k];
+}
+
+// the postings as the .dict file lists them, in a pool buffer the caller frees (null: the index's own array already is)
+int postings_in_caller_ids(rk_ctx *ctx, const rk_index *idx, hipStream_t st, uint32_t **out)
+{
+    *out = nullptr;
+    if (!idx->relabeled || !idx->H) return RK_OK;
+    DevBuf<unsigned long long> keys(ctx), sorted(ctx);
+    DevBuf<uint32_t> res(ctx);
+    DevBuf<char> tmp(ctx);
+    RK_HIP(ctx, keys.alloc(idx->H));
+    RK_HIP(ctx, sorted.alloc(idx->H));
+    RK_HIP(ctx, res.alloc(idx->H));
+    int ubits = 1;
+    while (ubits < 32 && (1ULL << ubits) < idx->U) ubits++;
+    hipLaunchKernelGGL(k_export_keys, dim3(blocks_for(idx->H)), dim3(kThreads), 0, st, idx->d_postings, idx->d_upos, idx->U, idx->H,
+                       idx->d_orig, keys.p);
+    size_t tb = 0;
+    RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, keys.p, sorted.p, idx->H, 0, (unsigned)(32 + ubits), st));
+    RK_HIP(ctx, tmp.alloc(tb));
+    RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, tb, keys.p, sorted.p, idx->H, 0, (unsigned)(32 + ubits), st));
+    hipLaunchKernelGGL(k_low_halves, dim3(blocks_for(idx->H)), dim3(kThreads), 0, st, sorted.p, idx->H, res.p);
+    RK_HIP(ctx, hipGetLastError());
+    RK_HIP(ctx, hipStreamSynchronize(st));  // the temporaries return to the pool
+    *out = res.release();
+    return RK_OK;
+}
+
 template <class T> int pool_array(rk_ctx *ctx, T **out, size_t n)
 {
     *out = static_cast<T *>(rk_pool_alloc(ctx, (n ? n : 1) * sizeof(T)));
@@ -362,7 +566,22 @@ void rk_index_free(rk_index *idx)
     rk_pool_free(ctx, idx->d_self_off);
     rk_pool_free(ctx, idx->d_self_split);
     rk_pool_free(ctx, idx->d_src_off);
+    rk_pool_free(ctx, idx->d_orig);
     delete idx;
+}
+
+int rk_index_order(const rk_index *idx, uint32_t *orig_out)
+{
+    if (!idx || (!orig_out && idx->n_ref)) return RK_ERR_ARG;
+    rk_ctx *ctx = idx->ctx;
+    if (!idx->relabeled || !idx->d_orig) {
+        for (uint32_t i = 0; i < idx->n_ref; i++) orig_out[i] = i;
+        return RK_OK;
+    }
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    RK_HIP(ctx, hipMemcpyAsync(orig_out, idx->d_orig, (size_t)idx->n_ref * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RK_OK;
 }
 
 uint64_t rk_index_total(const rk_index *idx) { return idx ? idx->H : 0; }
@@ -428,7 +647,62 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     RK_TRY(pool_array(ctx, &idx->d_selfrange, H + 1));
     RK_TRY(pool_array(ctx, &idx->d_self_off, (size_t)N + 1));
     RK_TRY(pool_array(ctx, &idx->d_self_split, (size_t)N + 1));
-    hipLaunchKernelGGL(k_sizes, dim3(blocks_for((uint64_t)N + 1)), dim3(kThreads), 0, st, s->d_off, N, idx->d_sizes, idx->d_src_off);
+    RK_TRY(pool_array(ctx, &idx->d_orig, (size_t)N + 1));
+
+    // ---- internal genome order: relatives next to each other (see k_minhash_insert) ---------------------------------
+    // the rest of the build, and every kernel that uses the index, works on the sketches in that order
+    const uint32_t *src_hashes = s->d_hashes;
+    const uint64_t *src_hashes64 = s->d_hashes64;
+    const uint64_t *src_off = s->d_off;
+    DevBuf<uint32_t> perm_hashes(ctx);
+    DevBuf<uint64_t> perm_hashes64(ctx);
+    if (ctx->sw_index_relabel && s->is_set && N > 1 && H) {
+        int id_bits = 1;
+        while ((1ULL << id_bits) < N) id_bits++;
+        uint32_t slots = 1024;
+        while (slots < 4ull * N * kMinK && slots < (1u << 30)) slots <<= 1;
+        DevBuf<unsigned long long> table(ctx), keys(ctx), keys_sorted(ctx);
+        DevBuf<uint32_t> parent(ctx);
+        DevBuf<char> tmp(ctx);
+        RK_HIP(ctx, table.alloc(slots));
+        RK_HIP(ctx, keys.alloc(N));
+        RK_HIP(ctx, keys_sorted.alloc(N));
+        RK_HIP(ctx, parent.alloc(N));
+        RK_HIP(ctx, hipMemsetAsync(table.p, 0xFF, (size_t)slots * 8, st));
+        const unsigned nb_k = blocks_for((uint64_t)N * kMinK), nb_n = blocks_for(N);
+        if (idx->wide) {
+            hipLaunchKernelGGL(k_minhash_insert<uint64_t>, dim3(nb_k), dim3(kThreads), 0, st, s->d_hashes64, s->d_off, N, table.p, slots - 1);
+            hipLaunchKernelGGL(k_minhash_vote<uint64_t>, dim3(nb_n), dim3(kThreads), 0, st, s->d_hashes64, s->d_off, N, table.p, slots - 1, parent.p);
+        } else {
+            hipLaunchKernelGGL(k_minhash_insert<uint32_t>, dim3(nb_k), dim3(kThreads), 0, st, s->d_hashes, s->d_off, N, table.p, slots - 1);
+            hipLaunchKernelGGL(k_minhash_vote<uint32_t>, dim3(nb_n), dim3(kThreads), 0, st, s->d_hashes, s->d_off, N, table.p, slots - 1, parent.p);
+        }
+        hipLaunchKernelGGL(k_cluster_keys, dim3(nb_n), dim3(kThreads), 0, st, parent.p, N, id_bits, keys.p);
+        size_t tb = 0;
+        RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, keys.p, keys_sorted.p, N, 0, (unsigned)(2 * id_bits), st));
+        RK_HIP(ctx, tmp.alloc(tb));
+        RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, tb, keys.p, keys_sorted.p, N, 0, (unsigned)(2 * id_bits), st));
+        hipLaunchKernelGGL(k_order_from_keys, dim3(nb_n), dim3(kThreads), 0, st, keys_sorted.p, N, id_bits, s->d_off, idx->d_orig, idx->d_sizes);
+        hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, st, idx->d_sizes, N, idx->d_src_off);
+        const unsigned wave_blocks_g = (N + 3) / 4;
+        if (idx->wide) {
+            RK_HIP(ctx, perm_hashes64.alloc(H));
+            hipLaunchKernelGGL(k_gather_sketches<uint64_t>, dim3(wave_blocks_g), dim3(kThreads), 0, st, s->d_hashes64, s->d_off, idx->d_orig,
+                               idx->d_src_off, N, perm_hashes64.p);
+            src_hashes64 = perm_hashes64.p;
+        } else {
+            RK_HIP(ctx, perm_hashes.alloc(H));
+            hipLaunchKernelGGL(k_gather_sketches<uint32_t>, dim3(wave_blocks_g), dim3(kThreads), 0, st, s->d_hashes, s->d_off, idx->d_orig,
+                               idx->d_src_off, N, perm_hashes.p);
+            src_hashes = perm_hashes.p;
+        }
+        src_off = idx->d_src_off;
+        idx->relabeled = true;
+        RK_HIP(ctx, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_iota, dim3(blocks_for((uint64_t)N + 1)), dim3(kThreads), 0, st, N, idx->d_orig);
+        hipLaunchKernelGGL(k_sizes, dim3(blocks_for((uint64_t)N + 1)), dim3(kThreads), 0, st, s->d_off, N, idx->d_sizes, idx->d_src_off);
+    }
 
     DevBuf<BuildResult> res(ctx);
     RK_HIP(ctx, res.alloc(1));
@@ -449,24 +723,24 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         if (idx->wide) RK_HIP(ctx, keys_sorted64.alloc(H));
         else RK_HIP(ctx, keys_sorted.alloc(H));
         const unsigned wave_blocks = (N + 3) / 4;  // 4 waves (genomes) per 256-thread workgroup
-        hipLaunchKernelGGL(k_fill_gid, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_off, N, gid.p, iota.p);
+        hipLaunchKernelGGL(k_fill_gid, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, gid.p, iota.p);
         // stable LSD radix sort by hash; values = source element index (genome-major), so equal hashes stay in
         // ascending genome order == hashMapId[hash].push_back(i) for i ascending (src/sketch.cpp:979-985)
         size_t t_sort = 0, t_scan = 0;
         if (idx->wide)
-            RK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t_sort, s->d_hashes64, keys_sorted64.p, iota.p, sorted_e.p, H, 0,
+            RK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t_sort, src_hashes64, keys_sorted64.p, iota.p, sorted_e.p, H, 0,
                                                   (unsigned)hash_bits, st));
         else
-            RK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t_sort, s->d_hashes, keys_sorted.p, iota.p, sorted_e.p, H, 0,
+            RK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t_sort, src_hashes, keys_sorted.p, iota.p, sorted_e.p, H, 0,
                                                   (unsigned)hash_bits, st));
         RK_HIP(ctx, rocprim::inclusive_scan(nullptr, t_scan, flags.p, iota.p, H, rocprim::plus<uint32_t>(), st));
         RK_HIP(ctx, tmp.alloc(std::max(t_sort, t_scan)));
         if (idx->wide) {
-            RK_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, t_sort, s->d_hashes64, keys_sorted64.p, iota.p, sorted_e.p, H, 0,
+            RK_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, t_sort, src_hashes64, keys_sorted64.p, iota.p, sorted_e.p, H, 0,
                                                   (unsigned)hash_bits, st));
             hipLaunchKernelGGL(k_head_flags<uint64_t>, dim3(blocks_for(H)), dim3(kThreads), 0, st, keys_sorted64.p, H, flags.p);
         } else {
-            RK_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, t_sort, s->d_hashes, keys_sorted.p, iota.p, sorted_e.p, H, 0,
+            RK_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, t_sort, src_hashes, keys_sorted.p, iota.p, sorted_e.p, H, 0,
                                                   (unsigned)hash_bits, st));
             hipLaunchKernelGGL(k_head_flags<uint32_t>, dim3(blocks_for(H)), dim3(kThreads), 0, st, keys_sorted.p, H, flags.p);
         }
@@ -485,9 +759,9 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             hipLaunchKernelGGL(k_postings_selfrange<true>, dim3(blocks_for(H)), dim3(kThreads), 0, st, sorted_e.p, gidx,
                                idx->d_upos, gid.p, H, idx->d_postings, self_raw.p, res.p);
         // drop the empty slices (26 % of the elements at 10,000 genomes), covered slices last in their row
-        hipLaunchKernelGGL(k_row_counts, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_off, N, self_raw.p, n_open.p, n_cov.p);
+        hipLaunchKernelGGL(k_row_counts, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, self_raw.p, n_open.p, n_cov.p);
         hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, res.p);
-        hipLaunchKernelGGL(k_row_place, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_off, N, self_raw.p,
+        hipLaunchKernelGGL(k_row_place, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, self_raw.p,
                            idx->d_self_off, idx->d_self_split, idx->d_postings, idx->d_selfrange);
         RK_HIP(ctx, hipGetLastError());
         RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));  // the one synchronisation of the build
@@ -582,8 +856,13 @@ int rk_index_export(const rk_index *idx, uint32_t *postings, uint32_t *counts)
         return rk_fail(ctx, RK_ERR_ARG, "64-bit index: use rk_index_export64 (sparse .index layout)");
     RK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    if (postings && idx->H)
-        RK_HIP(ctx, hipMemcpyAsync(postings, idx->d_postings, idx->H * 4, hipMemcpyDeviceToHost, st));
+    uint32_t *mapped = nullptr;
+    if (postings && idx->H) {
+        RK_TRY(postings_in_caller_ids(ctx, idx, st, &mapped));
+        struct Free { rk_ctx *c; uint32_t *p; ~Free() { rk_pool_free(c, p); } } guard{ctx, mapped};
+        RK_HIP(ctx, hipMemcpyAsync(postings, mapped ? mapped : idx->d_postings, idx->H * 4, hipMemcpyDeviceToHost, st));
+        RK_HIP(ctx, hipStreamSynchronize(st));
+    }
     if (counts) {
         const uint64_t hs = 1ULL << idx->hash_bits;
         DevBuf<uint32_t> d_counts(ctx);
@@ -607,11 +886,11 @@ namespace {
 struct BlobHeader {
     uint64_t magic, bytes;
     uint64_t H, U, max_src_size, max_ref_size, min_ref_size, n_self;
-    uint32_t n_ref, has_self, ref_sets;
-    int32_t hash_bits, wide;
-    uint64_t off_postings, off_uhash, off_upos, off_sizes, off_self, off_selfoff, off_src, off_split;
+    uint32_t n_ref, has_self, ref_sets, relabeled;
+    int32_t hash_bits, wide, pad_;
+    uint64_t off_postings, off_uhash, off_upos, off_sizes, off_self, off_selfoff, off_src, off_split, off_orig;
 };
-constexpr uint64_t kBlobMagic = 0x35584449444b5352ULL;  // "RSKDIDX5"
+constexpr uint64_t kBlobMagic = 0x36584449444b5352ULL;  // "RSKDIDX6"
 inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ULL; }
 
 // the layout this library produces for an index of these dimensions (derived arrays -- prefix directory, rank
@@ -624,7 +903,8 @@ void blob_layout(BlobHeader *h)
     h->off_uhash = p;    p = al256(p + (h->U + 1) * (wide ? 8 : 4));
     h->off_upos = p;     p = al256(p + (h->U + 2) * 4);
     h->off_sizes = p;    p = al256(p + ((uint64_t)h->n_ref + 1) * 4);
-    h->off_self = h->off_selfoff = h->off_src = h->off_split = 0;
+    h->off_self = h->off_selfoff = h->off_src = h->off_split = h->off_orig = 0;
+    if (h->relabeled) { h->off_orig = p; p = al256(p + ((uint64_t)h->n_ref + 1) * 4); }
     if (h->has_self) {
         h->off_self = p;    p = al256(p + (h->n_self + 1) * sizeof(uint2));
         h->off_selfoff = p; p = al256(p + ((uint64_t)h->n_ref + 1) * 8);
@@ -647,6 +927,7 @@ void blob_header(const rk_index *idx, BlobHeader *h)
     h->n_ref = idx->n_ref;
     h->has_self = idx->d_selfrange ? 1 : 0;
     h->ref_sets = idx->ref_sets ? 1 : 0;
+    h->relabeled = idx->relabeled && idx->d_orig ? 1 : 0;
     h->hash_bits = idx->hash_bits;
     h->wide = idx->wide ? 1 : 0;
     blob_layout(h);
@@ -679,6 +960,7 @@ int rk_index_pack_dev(const rk_index *idx, void *blob_dev, uint64_t blob_cap, vo
     else RK_HIP(ctx, hipMemcpyAsync(b + h.off_uhash, idx->d_uhash, idx->U * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(b + h.off_upos, idx->d_upos, (idx->U + 1) * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(b + h.off_sizes, idx->d_sizes, (uint64_t)idx->n_ref * 4, hipMemcpyDeviceToDevice, st));
+    if (h.relabeled) RK_HIP(ctx, hipMemcpyAsync(b + h.off_orig, idx->d_orig, (uint64_t)idx->n_ref * 4, hipMemcpyDeviceToDevice, st));
     if (h.has_self) {
         RK_HIP(ctx, hipMemcpyAsync(b + h.off_self, idx->d_selfrange, idx->n_self * sizeof(uint2), hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(b + h.off_selfoff, idx->d_self_off, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
@@ -732,6 +1014,11 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
     else RK_HIP(ctx, hipMemcpyAsync(idx->d_uhash, b + h.off_uhash, idx->U * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(idx->d_upos, b + h.off_upos, (idx->U + 1) * 4, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(idx->d_sizes, b + h.off_sizes, (uint64_t)idx->n_ref * 4, hipMemcpyDeviceToDevice, st));
+    if (h.relabeled) {
+        RK_TRY(pool_array(ctx, &idx->d_orig, (size_t)idx->n_ref + 1));
+        RK_HIP(ctx, hipMemcpyAsync(idx->d_orig, b + h.off_orig, (uint64_t)idx->n_ref * 4, hipMemcpyDeviceToDevice, st));
+        idx->relabeled = true;
+    }
     if (h.has_self) {
         RK_TRY(pool_array(ctx, &idx->d_selfrange, idx->n_self + 1));
         RK_TRY(pool_array(ctx, &idx->d_self_off, (size_t)idx->n_ref + 1));
@@ -847,7 +1134,13 @@ int rk_index_export64(const rk_index *idx, uint32_t *postings, uint64_t *hashes,
     if (!idx->wide) return rk_fail(ctx, RK_ERR_ARG, "32-bit index: use rk_index_export (dense .index layout)");
     RK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    if (postings && idx->H) RK_HIP(ctx, hipMemcpyAsync(postings, idx->d_postings, idx->H * 4, hipMemcpyDeviceToHost, st));
+    if (postings && idx->H) {
+        uint32_t *mapped = nullptr;
+        RK_TRY(postings_in_caller_ids(ctx, idx, st, &mapped));
+        struct Free { rk_ctx *c; uint32_t *p; ~Free() { rk_pool_free(c, p); } } guard{ctx, mapped};
+        RK_HIP(ctx, hipMemcpyAsync(postings, mapped ? mapped : idx->d_postings, idx->H * 4, hipMemcpyDeviceToHost, st));
+        RK_HIP(ctx, hipStreamSynchronize(st));
+    }
     if (hashes && idx->U) RK_HIP(ctx, hipMemcpyAsync(hashes, idx->d_uhash64, idx->U * 8, hipMemcpyDeviceToHost, st));
     DevBuf<uint32_t> c(ctx);
     if (counts && idx->U) {

@@ -47,6 +47,7 @@ struct rk_ctx {
     int sw_dist_debug = 0;  // RK_DIST_DEBUG=1: the bands of every self join on stderr
     int sw_dist_lds_kb = 0;  // RK_DIST_LDS_KB: plan as if a CU had this much LDS (tests: tiled bands at small sizes)
     int sw_sketch_img = 1;  // RK_SKETCH_IMG=0: the 144 KiB LDS image with the exact table, one workgroup per CU
+    int sw_index_relabel = 1;  // RK_INDEX_RELABEL=0: keep the caller's genome order inside the index
 };
 constexpr size_t kPinnedBytes = 1 << 16;
 
@@ -152,7 +153,14 @@ struct rk_index {
     uint64_t *d_self_split = nullptr; // u64[n_ref]: a row's slices from here on are "covered" by its pair partner
                                       // (genome 2p+1 shares the hash with 2p): the pair kernel skips them
     uint64_t n_self = 0;
-    uint64_t *d_src_off = nullptr;   // u64[n_ref+1] offsets of the source sketches (built only)
+    uint64_t *d_src_off = nullptr;   // u64[n_ref+1] offsets of the source sketches (built only), in INTERNAL genome order
+    // Internal genome order.  rk_index_build renumbers the genomes so that relatives (genomes that share several of their
+    // smallest hashes) get neighbouring ids, whatever order the collection arrived in: compact slices / list records
+    // (all members within 32 ids) and row pairs depend on that.  Every device array above is in internal ids; d_orig
+    // maps an internal id back to the caller's genome index (null: identity -- imported indexes), and the kernels apply
+    // it where a hit record or a dense counter row leaves the device.
+    uint32_t *d_orig = nullptr;      // u32[n_ref]
+    bool relabeled = false;          // d_orig may differ from the identity
     std::mutex lazy_mu;              // serialises the lazy builders (prefix directory, rank bitmap, list records, sum of
                                      // squares): two host threads may query one index
 };

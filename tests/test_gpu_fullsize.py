@@ -91,11 +91,11 @@ def test_config3_alldist_50k_properties_and_exact(ctx):
         assert mine["jorc"][t] == jac and mine["dist"][t] == d
     # rows of one rank out of 8 (what a GPU of configs[3] computes) are a subset with the same records
     part, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=3, row_step=8)
-    sel = mine[mine["row"] % 8 == 3]
+    sel = mine[idx.shard_of(mine, 8) == 3]
     assert part.tobytes() == sel.tobytes()
     # the block-cyclic shard the multi-GPU callers use (blocks of 16 rows)
     part, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=5, row_step=8, row_block=16)
-    sel = mine[(mine["row"] // 16) % 8 == 5]
+    sel = mine[idx.shard_of(mine, 8, 16) == 5]
     assert part.tobytes() == sel.tobytes()
 
 
@@ -123,7 +123,7 @@ def test_self_join_with_tiled_columns_90k(ctx):
     mine, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05)
     check_hits(mine, want)
     part, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=1, row_step=3, row_block=16)
-    sel = mine[(mine["row"] // 16) % 3 == 1]
+    sel = mine[idx.shard_of(mine, 3, 16) == 1]
     assert part.tobytes() == sel.tobytes()
 
 

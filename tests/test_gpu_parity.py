@@ -6,6 +6,7 @@ import json
 import os
 
 import numpy as np
+import torch
 import pytest
 
 from conftest import GOLDEN
@@ -176,7 +177,7 @@ def test_block_cyclic_row_sharding_union_equals_full(ctx, n, block, world):
         full, _ = ctx.dist_rows(idx, None, 1, 0, 20, D)
         parts = [ctx.dist_rows(idx, None, 1, 0, 20, D, row_first=r, row_step=world, row_block=block)[0] for r in range(world)]
         for r, p in enumerate(parts):
-            assert np.all((p["row"] // block) % world == r)
+            assert np.all(idx.shard_of(p, world, block) == r)   # blocks of the index's internal genome order
         merged = np.concatenate(parts)
         merged = merged[np.lexsort((merged["col"], merged["row"]))]
         assert merged.tobytes() == full.tobytes()
@@ -207,6 +208,68 @@ def test_default_threshold_of_alldist_stays_sparse():
     mine, _ = c.dist_rows(idx, q, 0, 0, 20, 1.0)
     assert_hits_equal(mine, want)
     c.close()
+
+
+@pytest.mark.parametrize("mode", ["shuffled", "jitter", "sorted"])
+def test_genome_order_does_not_matter(ctx, mode):
+    # The same collection listed in another order (a random permutation of the genome ids; OpenMP completion order, i.e.
+    # permuted inside windows, src/sketch.cpp:558-568).  rk_index_build renumbers the genomes internally so that relatives
+    # are neighbours again; hits, dense rows and the exported .dict postings must be the oracle's for the order GIVEN.
+    n = 1500
+    names, h, off = synth.clade_sketches(n, 220, 24, seed=61)
+    order = synth.genome_order(n, mode, seed=3, window=64)
+    names, h, off = synth.permute_genomes(names, h, off, order)
+    postings, counts = ok.index_build32(h, off, 24)
+    sizes = np.diff(off).astype(np.uint32)
+    sk = ctx.sketches_from_host(h, off)
+    idx = ctx.index_build(sk, 24)
+    assert np.array_equal(idx.export(want_counts=False)[0], postings)
+    # clades (10 consecutive genomes of the generator) end up as runs of consecutive internal ids
+    internal = order[idx.order.astype(np.int64)] // 10          # clade of every internal position
+    assert (np.diff(internal) != 0).sum() < 1.2 * (n // 10)
+    for metric, D in ((0, 0.05), (1, 0.2), (0, 1.5)):
+        want, _ = ok.index_dist32(counts, 24, postings, sizes, h, off, 1, metric, 20, D, threads=4)
+        assert len(want) > 0
+        mine, _ = ctx.dist_rows(idx, None, 1, metric, 20, D)
+        assert_hits_equal(mine, want)
+    # explicit queries against the renumbered index: triangle on the caller's ids, dense rows in the caller's columns
+    want, dense_want = ok.index_dist32(counts, 24, postings, sizes, h, off, 1, 0, 20, 0.08, threads=4, want_dense=True)
+    mine, dense = ctx.dist_rows(idx, sk, 1, 0, 20, 0.08, want_dense=True)
+    assert np.array_equal(dense, dense_want)
+    assert_hits_equal(mine, want)
+    q = ctx.sketches_from_host(h[: int(off[70])], off[:71])
+    for D in (0.08, 1.0):
+        want, _ = ok.index_dist32(counts, 24, postings, sizes, h[: int(off[70])], off[:71], 0, 0, 20, D, threads=4)
+        mine, _ = ctx.dist_rows(idx, q, 0, 0, 20, D)
+        assert_hits_equal(mine, want)
+    # row shards partition the pairs; a shard is a set of blocks of the internal order
+    full, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05)
+    parts = [ctx.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=r, row_step=3, row_block=16)[0] for r in range(3)]
+    for r, p in enumerate(parts):
+        assert np.all(idx.shard_of(p, 3, 16) == r)
+    merged = np.concatenate(parts)
+    assert merged[np.lexsort((merged["col"], merged["row"]))].tobytes() == full.tobytes()
+    # the single-blob form (multi-GPU broadcast) carries the order
+    blob = torch.empty(idx.blob_bytes, dtype=torch.uint8, device="cuda")
+    idx.pack_dev(blob.data_ptr(), blob.numel())
+    idx2 = ctx.index_unpack_dev(blob.data_ptr(), blob.numel())
+    assert np.array_equal(idx2.order, idx.order)
+    assert ctx.dist_rows(idx2, None, 1, 0, 20, 0.05)[0].tobytes() == full.tobytes()
+
+
+def test_index_without_renumbering_gives_the_same_results(monkeypatch):
+    names, h, off = synth.clade_sketches(900, 150, 24, seed=62)
+    names, h, off = synth.permute_genomes(names, h, off, synth.genome_order(900, "shuffled", seed=4))
+    monkeypatch.setenv("RK_INDEX_RELABEL", "0")
+    c0 = capi.Context(0)
+    monkeypatch.delenv("RK_INDEX_RELABEL")
+    c1 = capi.Context(0)
+    i0, i1 = c0.index_build(c0.sketches_from_host(h, off), 24), c1.index_build(c1.sketches_from_host(h, off), 24)
+    assert np.array_equal(i0.order, np.arange(900)) and not np.array_equal(i1.order, np.arange(900))
+    for D in (0.05, 0.3):
+        assert c0.dist_rows(i0, None, 1, 0, 20, D)[0].tobytes() == c1.dist_rows(i1, None, 1, 0, 20, D)[0].tobytes()
+    c0.close()
+    c1.close()
 
 
 def test_pair_kernel_equals_single_row_kernel(ctx, monkeypatch):
@@ -260,7 +323,7 @@ def test_self_join_in_bands(monkeypatch, n, lds_kb, world):
         else:
             parts = [banded.dist_rows(ib, None, 1, metric, 20, D, row_first=r, row_step=world, row_block=16)[0] for r in range(world)]
             for r, p in enumerate(parts):
-                assert np.all((p["row"] // 16) % world == r)
+                assert np.all(ib.shard_of(p, world, 16) == r)
             merged = np.concatenate(parts)
             assert_hits_equal(merged[np.lexsort((merged["col"], merged["row"]))], want)
     del ib, ip
@@ -288,7 +351,7 @@ def test_row_sharding_union_equals_full(ctx):
     full, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.08)
     parts = [ctx.dist_rows(idx, None, 1, 0, 20, 0.08, row_first=r, row_step=4)[0] for r in range(4)]
     for r, p in enumerate(parts):
-        assert np.all(p["row"] % 4 == r)
+        assert np.all(idx.shard_of(p, 4) == r)
     merged = np.concatenate(parts)
     merged = merged[np.lexsort((merged["col"], merged["row"]))]
     assert merged.tobytes() == full.tobytes()

@@ -109,8 +109,7 @@ def _worker_gpu(rank, port, outdir):
             dev_blob = blob.cuda()
             index = ctx.index_unpack_dev(dev_blob.data_ptr(), dev_blob.numel())
         mine, _ = ctx.dist_rows(index, None, 1, 0, 20, 0.1, row_first=rank, row_step=WORLD, row_block=shard.ROW_BLOCK)
-        rows = shard.rank_rows(len(names), rank, WORLD)[2]
-        assert set(np.unique(mine["row"])).issubset(set(rows.tolist()))
+        assert np.all(index.shard_of(mine, WORLD, shard.ROW_BLOCK) == rank)   # blocks of the index's internal genome order
         merged = shard.gather_hits(mine, dist, 0)
         if rank == 0:
             postings, counts = ok.index_build32(h, off, BITS)
