@@ -211,6 +211,9 @@ uint64_t rk_index_total(const rk_index *idx);    /* H = number of postings      
 uint64_t rk_index_distinct(const rk_index *idx); /* U = number of distinct hashes */
 uint32_t rk_index_genomes(const rk_index *idx);
 int rk_index_hash_bits(const rk_index *idx);
+/* 1 when rk_index_build took its bucket-sort path (set sketches with 32-bit hashes whose buckets fit the LDS sort),
+ * 0 for the general path (device-wide radix sort) or an imported index: lets a harness say which build it timed. */
+int rk_index_built_fast(const rk_index *idx);
 /* sum over all reference hashes h of c_h^2 = postings streamed by a full alldist
  * (the T of the roofline formula) */
 uint64_t rk_index_sum_sq(const rk_index *idx);

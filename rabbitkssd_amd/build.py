@@ -29,7 +29,7 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(ROOT, "include", "rabbitkssd.h"))
     jobs = []
     for s in srcs:

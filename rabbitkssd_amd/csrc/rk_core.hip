@@ -180,6 +180,7 @@ int rk_ctx_create(int device, rk_ctx **out)
     ctx->sw_dist_debug = getenv("RK_DIST_DEBUG") ? atoi(getenv("RK_DIST_DEBUG")) : 0;
     if (getenv("RK_DIST_LDS_KB")) ctx->sw_dist_lds_kb = std::max(0, atoi(getenv("RK_DIST_LDS_KB")));
     ctx->sw_sketch_img = getenv("RK_SKETCH_IMG") ? atoi(getenv("RK_SKETCH_IMG")) != 0 : 1;
+    ctx->sw_index_fast = getenv("RK_INDEX_FAST") ? atoi(getenv("RK_INDEX_FAST")) != 0 : 1;
     ctx->sw_index_relabel = getenv("RK_INDEX_RELABEL") ? atoi(getenv("RK_INDEX_RELABEL")) != 0 : 1;
     *out = ctx;
     return RK_OK;

@@ -32,7 +32,7 @@ constexpr int kThreads = 256;
 inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
 
 struct BuildResult {  // written by the kernels, read back once
-    unsigned long long U, n_self, dups, pad_;
+    unsigned long long U, n_self, dups, flags;
 };
 
 __global__ void k_sizes(const uint64_t *off, uint32_t n, uint32_t *sizes, uint64_t *off_copy)
@@ -494,6 +494,8 @@ int postings_in_caller_ids(rk_ctx *ctx, const rk_index *idx, hipStream_t st, uin
     return RK_OK;
 }
 
+#include "rk_index_fast.inc"
+
 template <class T> int pool_array(rk_ctx *ctx, T **out, size_t n)
 {
     *out = static_cast<T *>(rk_pool_alloc(ctx, (n ? n : 1) * sizeof(T)));
@@ -588,6 +590,7 @@ uint64_t rk_index_total(const rk_index *idx) { return idx ? idx->H : 0; }
 uint64_t rk_index_distinct(const rk_index *idx) { return idx ? idx->U : 0; }
 uint32_t rk_index_genomes(const rk_index *idx) { return idx ? idx->n_ref : 0; }
 int rk_index_hash_bits(const rk_index *idx) { return idx ? idx->hash_bits : 0; }
+int rk_index_built_fast(const rk_index *idx) { return idx && idx->built_fast ? 1 : 0; }
 
 uint64_t rk_index_sum_sq(const rk_index *cidx)
 {
@@ -619,7 +622,8 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
                        s->wide ? "64" : "32");
     const uint64_t H = s->total;
     const uint32_t N = s->n;
-    if (H >= 0xFFFFFFFFULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "more than 2^32-1 postings");
+    // (bit 31 of a slice / list record tags the compact form: posting offsets and genome ids stay below it)
+    if (H >= 0x7FFFFFFFULL || N >= 0x7FFFFFFFu) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "more than 2^31-1 postings or genomes");
     RK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     rk_index *idx = new (std::nothrow) rk_index;
@@ -648,14 +652,11 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     RK_TRY(pool_array(ctx, &idx->d_self_off, (size_t)N + 1));
     RK_TRY(pool_array(ctx, &idx->d_self_split, (size_t)N + 1));
     RK_TRY(pool_array(ctx, &idx->d_orig, (size_t)N + 1));
+    const unsigned wave_blocks = (N + 3) / 4;  // 4 waves (genomes) per 256-thread workgroup
 
     // ---- internal genome order: relatives next to each other (see k_minhash_insert) ---------------------------------
-    // the rest of the build, and every kernel that uses the index, works on the sketches in that order
-    const uint32_t *src_hashes = s->d_hashes;
-    const uint64_t *src_hashes64 = s->d_hashes64;
-    const uint64_t *src_off = s->d_off;
-    DevBuf<uint32_t> perm_hashes(ctx);
-    DevBuf<uint64_t> perm_hashes64(ctx);
+    // d_orig, d_sizes and d_src_off (the CSR offsets in internal order); the rest of the build, and every kernel that
+    // uses the index, works in that order
     if (ctx->sw_index_relabel && s->is_set && N > 1 && H) {
         int id_bits = 1;
         while ((1ULL << id_bits) < N) id_bits++;
@@ -684,19 +685,6 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, tb, keys.p, keys_sorted.p, N, 0, (unsigned)(2 * id_bits), st));
         hipLaunchKernelGGL(k_order_from_keys, dim3(nb_n), dim3(kThreads), 0, st, keys_sorted.p, N, id_bits, s->d_off, idx->d_orig, idx->d_sizes);
         hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, st, idx->d_sizes, N, idx->d_src_off);
-        const unsigned wave_blocks_g = (N + 3) / 4;
-        if (idx->wide) {
-            RK_HIP(ctx, perm_hashes64.alloc(H));
-            hipLaunchKernelGGL(k_gather_sketches<uint64_t>, dim3(wave_blocks_g), dim3(kThreads), 0, st, s->d_hashes64, s->d_off, idx->d_orig,
-                               idx->d_src_off, N, perm_hashes64.p);
-            src_hashes64 = perm_hashes64.p;
-        } else {
-            RK_HIP(ctx, perm_hashes.alloc(H));
-            hipLaunchKernelGGL(k_gather_sketches<uint32_t>, dim3(wave_blocks_g), dim3(kThreads), 0, st, s->d_hashes, s->d_off, idx->d_orig,
-                               idx->d_src_off, N, perm_hashes.p);
-            src_hashes = perm_hashes.p;
-        }
-        src_off = idx->d_src_off;
         idx->relabeled = true;
         RK_HIP(ctx, hipGetLastError());
     } else {
@@ -708,7 +696,105 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     RK_HIP(ctx, res.alloc(1));
     RK_HIP(ctx, hipMemsetAsync(res.p, 0, sizeof(BuildResult), st));
     BuildResult r{0, 0, 0, 0};
-    if (H) {
+    bool built = false;
+
+    // ---- fast path: two-level bucket sort, second level and all emission in LDS (rk_index_fast.inc) -----------------
+    int B = 1, gb = 1, rb = 1;
+    while (B < hash_bits && B < 31 && ((H + kBucketTarget - 1) / kBucketTarget) > (1ULL << B)) B++;
+    while ((1ULL << gb) < N) gb++;
+    while ((1ULL << rb) < s->max_size) rb++;
+    const int low_bits = hash_bits - B;
+    const bool fast_ok = ctx->sw_index_fast && H && !idx->wide && s->is_set && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 &&
+                         low_bits + gb + rb <= 63 && gb <= 31 && rb <= 31;
+    if (fast_ok) {
+        FastArgs fa;
+        fa.hashes = s->d_hashes;
+        fa.off = s->d_off;
+        fa.orig = idx->d_orig;
+        fa.off_new = idx->d_src_off;
+        fa.n_genomes = N;
+        fa.H = H;
+        fa.hash_bits = hash_bits;
+        fa.low_bits = low_bits;
+        fa.gb = gb;
+        fa.rb = rb;
+        fa.nb = 1u << B;
+        fa.n_chunks = (uint32_t)((H + kPartChunk - 1) / kPartChunk);
+        DevBuf<uint32_t> matrix(ctx), total(ctx), bstart(ctx), ucount(ctx), ubase(ctx), tmp_uhash(ctx), tmp_upos(ctx), n_open(ctx), n_cov(ctx);
+        DevBuf<unsigned long long> keys(ctx);
+        DevBuf<uint2> self_raw(ctx);
+        RK_HIP(ctx, matrix.alloc((size_t)fa.n_chunks * fa.nb));
+        RK_HIP(ctx, total.alloc(fa.nb));
+        RK_HIP(ctx, bstart.alloc((size_t)fa.nb + 1));
+        RK_HIP(ctx, ucount.alloc(fa.nb));
+        RK_HIP(ctx, ubase.alloc((size_t)fa.nb + 1));
+        RK_HIP(ctx, tmp_uhash.alloc(H));
+        RK_HIP(ctx, tmp_upos.alloc(H));
+        RK_HIP(ctx, keys.alloc(H));
+        RK_HIP(ctx, self_raw.alloc(H));
+        RK_HIP(ctx, n_open.alloc((size_t)N + 1));
+        RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
+        const size_t part_lds = (size_t)fa.nb * 4;
+        if (part_lds > 48 * 1024) {
+            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
+            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
+        }
+        hipLaunchKernelGGL(k_part_hist, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, matrix.p, res.p);
+        hipLaunchKernelGGL(k_part_colscan, dim3(blocks_for(fa.nb)), dim3(kThreads), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
+        hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart.p, res.p);
+        hipLaunchKernelGGL(k_part_scatter, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, matrix.p, bstart.p, keys.p);
+        EmitArgs ea;
+        ea.keys = keys.p;
+        ea.bstart = bstart.p;
+        ea.off_new = idx->d_src_off;
+        ea.low_bits = low_bits;
+        ea.gb = gb;
+        ea.rb = rb;
+        ea.nb = fa.nb;
+        ea.postings = idx->d_postings;
+        ea.tmp_uhash = tmp_uhash.p;
+        ea.tmp_upos = tmp_upos.p;
+        ea.ucount = ucount.p;
+        ea.self_raw = self_raw.p;
+        ea.res = res.p;
+        hipLaunchKernelGGL(k_bucket_emit, dim3(fa.nb), dim3(kEmitThreads), 0, st, ea);
+        hipLaunchKernelGGL(k_heads_scan, dim3(1), dim3(1024), 0, st, ucount.p, fa.nb, ubase.p, res.p);
+        hipLaunchKernelGGL(k_heads_place, dim3(fa.nb), dim3(kThreads), 0, st, tmp_uhash.p, tmp_upos.p, bstart.p, ucount.p, ubase.p, fa.nb,
+                           (uint32_t)H, idx->d_uhash, idx->d_upos);
+        hipLaunchKernelGGL(k_row_counts2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, n_open.p, n_cov.p);
+        hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, res.p);
+        hipLaunchKernelGGL(k_row_place2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, idx->d_self_off,
+                           idx->d_self_split, idx->d_selfrange);
+        RK_HIP(ctx, hipGetLastError());
+        RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));  // the one synchronisation of the build
+        if (r.flags == 0) built = true;
+        else {  // a bucket beyond the LDS sort, or a hash outside the hash space: the general path decides
+            RK_HIP(ctx, hipMemsetAsync(res.p, 0, sizeof(BuildResult), st));
+            r = BuildResult{0, 0, 0, 0};
+        }
+    }
+
+    if (!built && H) {
+        // ---- general path: device-wide stable radix sort of (hash, source element) -------------------------------------
+        const uint32_t *src_hashes = s->d_hashes;
+        const uint64_t *src_hashes64 = s->d_hashes64;
+        const uint64_t *src_off = s->d_off;
+        DevBuf<uint32_t> perm_hashes(ctx);
+        DevBuf<uint64_t> perm_hashes64(ctx);
+        if (idx->relabeled) {  // the sketches in internal order
+            if (idx->wide) {
+                RK_HIP(ctx, perm_hashes64.alloc(H));
+                hipLaunchKernelGGL(k_gather_sketches<uint64_t>, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_hashes64, s->d_off, idx->d_orig,
+                                   idx->d_src_off, N, perm_hashes64.p);
+                src_hashes64 = perm_hashes64.p;
+            } else {
+                RK_HIP(ctx, perm_hashes.alloc(H));
+                hipLaunchKernelGGL(k_gather_sketches<uint32_t>, dim3(wave_blocks), dim3(kThreads), 0, st, s->d_hashes, s->d_off, idx->d_orig,
+                                   idx->d_src_off, N, perm_hashes.p);
+                src_hashes = perm_hashes.p;
+            }
+            src_off = idx->d_src_off;
+        }
         DevBuf<uint32_t> iota(ctx), keys_sorted(ctx), sorted_e(ctx), flags(ctx), gid(ctx), n_open(ctx), n_cov(ctx);
         DevBuf<uint64_t> keys_sorted64(ctx);
         DevBuf<uint2> self_raw(ctx);
@@ -722,7 +808,6 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
         if (idx->wide) RK_HIP(ctx, keys_sorted64.alloc(H));
         else RK_HIP(ctx, keys_sorted.alloc(H));
-        const unsigned wave_blocks = (N + 3) / 4;  // 4 waves (genomes) per 256-thread workgroup
         hipLaunchKernelGGL(k_fill_gid, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, gid.p, iota.p);
         // stable LSD radix sort by hash; values = source element index (genome-major), so equal hashes stay in
         // ascending genome order == hashMapId[hash].push_back(i) for i ascending (src/sketch.cpp:979-985)
@@ -765,7 +850,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
                            idx->d_self_off, idx->d_self_split, idx->d_postings, idx->d_selfrange);
         RK_HIP(ctx, hipGetLastError());
         RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));  // the one synchronisation of the build
-    } else {
+    } else if (!H) {
         RK_HIP(ctx, hipMemsetAsync(idx->d_upos, 0, 8, st));
         RK_HIP(ctx, hipMemsetAsync(idx->d_self_off, 0, ((size_t)N + 1) * 8, st));
         RK_HIP(ctx, hipMemsetAsync(idx->d_self_split, 0, ((size_t)N + 1) * 8, st));
@@ -774,6 +859,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     idx->U = r.U;
     idx->n_self = r.n_self;
     idx->ref_sets = s->is_set || r.dups == 0;
+    idx->built_fast = built;
     set_dir_shape(idx);
     guard.p = nullptr;
     *out = idx;

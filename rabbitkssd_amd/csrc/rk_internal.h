@@ -47,6 +47,7 @@ struct rk_ctx {
     int sw_dist_debug = 0;  // RK_DIST_DEBUG=1: the bands of every self join on stderr
     int sw_dist_lds_kb = 0;  // RK_DIST_LDS_KB: plan as if a CU had this much LDS (tests: tiled bands at small sizes)
     int sw_sketch_img = 1;  // RK_SKETCH_IMG=0: the 144 KiB LDS image with the exact table, one workgroup per CU
+    int sw_index_fast = 1;     // RK_INDEX_FAST=0: always the general (device-wide radix sort) build
     int sw_index_relabel = 1;  // RK_INDEX_RELABEL=0: keep the caller's genome order inside the index
 };
 constexpr size_t kPinnedBytes = 1 << 16;
@@ -161,6 +162,7 @@ struct rk_index {
     // it where a hit record or a dense counter row leaves the device.
     uint32_t *d_orig = nullptr;      // u32[n_ref]
     bool relabeled = false;          // d_orig may differ from the identity
+    bool built_fast = false;         // built by the bucket-sort path (rk_index_fast.inc)
     std::mutex lazy_mu;              // serialises the lazy builders (prefix directory, rank bitmap, list records, sum of
                                      // squares): two host threads may query one index
 };

@@ -120,7 +120,7 @@ def index(n_genomes=10000, reps=5):
         t0 = time.time()
         idx = ctx.index_build(sk, 28)
         dt = time.time() - t0
-        print("index build %d: %.3f ms (H=%d U=%d)" % (r, dt * 1e3, idx.total, idx.distinct))
+        print("index build %d: %.3f ms (H=%d U=%d fast=%d)" % (r, dt * 1e3, idx.total, idx.distinct, idx.built_fast))
         del idx
     for r in range(3):
         t0 = time.time()
