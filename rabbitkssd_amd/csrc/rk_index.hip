@@ -35,6 +35,35 @@ struct BuildResult {  // written by the kernels, read back once
     unsigned long long U, n_self, dups, flags;
 };
 
+// Single-workgroup exclusive scan in two sweeps over contiguous per-thread stretches (one block-wide exchange instead
+// of one per 1,024 entries): store(i, sum of load(j), j < i) for i < n; returns the grand total.
+template <class Acc, class L, class W> __device__ inline Acc block_scan_sweeps(uint32_t n, L load, W store)
+{
+    __shared__ Acc scan_part[1024 / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const uint32_t per = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t i0 = min(n, tid * per), i1 = min(n, i0 + per);
+    Acc sum = 0;
+    for (uint32_t i = i0; i < i1; i++) sum += load(i);
+    Acc incl = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const Acc t = __shfl_up(incl, o);
+        if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63) scan_part[wave] = incl;
+    __syncthreads();
+    Acc run = incl - sum, all = 0;
+    for (uint32_t w = 0; w < nw; w++) {
+        if (w < wave) run += scan_part[w];
+        all += scan_part[w];
+    }
+    for (uint32_t i = i0; i < i1; i++) {
+        store(i, run);
+        run += load(i);
+    }
+    return all;
+}
+
 __global__ void k_sizes(const uint64_t *off, uint32_t n, uint32_t *sizes, uint64_t *off_copy)
 {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -401,33 +430,65 @@ __global__ void k_order_from_keys(const unsigned long long *keys, uint32_t n_gen
 // single workgroup: off_new = exclusive scan of the sizes in internal order
 __global__ void k_offsets_scan(const uint32_t *sizes, uint32_t n_genomes, uint64_t *off_new)
 {
-    __shared__ unsigned long long part[1024 / 64];
-    __shared__ unsigned long long carry;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_genomes; base += blockDim.x) {
-        const uint32_t g = base + tid;
-        const unsigned long long len = g < n_genomes ? sizes[g] : 0ULL;
-        unsigned long long incl = len;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long t = __shfl_up(incl, o);
-            if ((int)lane >= o) incl += t;
-        }
-        if (lane == 63) part[wave] = incl;
-        __syncthreads();
-        unsigned long long before = carry;
-        for (uint32_t w = 0; w < wave; w++) before += part[w];
-        if (g < n_genomes) off_new[g] = before + incl - len;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long t = carry;
-            for (uint32_t w = 0; w < nw; w++) t += part[w];
-            carry = t;
-        }
-        __syncthreads();
+    const unsigned long long all = block_scan_sweeps<unsigned long long>(
+        n_genomes, [&](uint32_t g) { return (unsigned long long)sizes[g]; },
+        [&](uint32_t g, unsigned long long before) { off_new[g] = before; });
+    if (threadIdx.x == 0) off_new[n_genomes] = all;
+}
+
+// Small collections (<= 32,768 genomes): the (root, genome) keys are ordered by COUNTING -- the keys are distinct, so a
+// key's position is the number of smaller keys; every workgroup compares 256 keys with a stretch of 512 others (scalar
+// loads: the stretch is the same for all lanes) and adds its partial counts.  10,000 keys: 800 workgroups, a few
+// microseconds -- a device-wide sort of so few keys costs 70 us of launches.
+constexpr uint32_t kRankThreads = 256, kRankPer = 4, kRankQ = kRankThreads * kRankPer, kRankStretch = 256, kRankMaxN = 32768;
+// (root, genome) packed into 32 bits: 2 * id_bits <= 30 for up to 32,768 genomes
+__global__ void k_cluster_keys32(const uint32_t *parent, uint32_t n_genomes, int id_bits, uint32_t *keys)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_genomes) return;
+    uint32_t p = parent[g];
+    for (uint32_t hop = 0; hop < n_genomes; hop++) {
+        const uint32_t q = parent[p];
+        if (q == p) break;
+        p = q;
     }
-    if (tid == 0) off_new[n_genomes] = carry;
+    keys[g] = (p << id_bits) | g;
+}
+// every thread ranks kRankPer keys against a stretch of 256 others staged in LDS (16-byte broadcast reads: four
+// others per read, sixteen comparisons per read)
+__global__ __launch_bounds__(kRankThreads) void k_rank_keys(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *rank)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t others[kRankStretch];
+    const uint32_t j0 = blockIdx.y * kRankStretch;
+    for (uint32_t j = threadIdx.x; j < kRankStretch; j += kRankThreads) others[j] = j0 + j < n ? keys[j0 + j] : 0xFFFFFFFFu;
+    uint32_t mine[kRankPer], below[kRankPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kRankPer; i++) {
+        const uint32_t q = blockIdx.x * kRankQ + i * kRankThreads + threadIdx.x;
+        mine[i] = q < n ? keys[q] : 0u;
+        below[i] = 0;
+    }
+    __syncthreads();
+    const uint4 *o4 = reinterpret_cast<const uint4 *>(others);
+#pragma unroll 4
+    for (uint32_t j = 0; j < kRankStretch / 4; j++) {
+        const uint4 v = o4[j];
+#pragma unroll
+        for (uint32_t i = 0; i < kRankPer; i++) below[i] += (v.x < mine[i]) + (v.y < mine[i]) + (v.z < mine[i]) + (v.w < mine[i]);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kRankPer; i++) {
+        const uint32_t q = blockIdx.x * kRankQ + i * kRankThreads + threadIdx.x;
+        if (q < n && below[i]) atomicAdd(&rank[q], below[i]);
+    }
+}
+__global__ void k_order_from_rank(const uint32_t *rank, uint32_t n_genomes, const uint64_t *off, uint32_t *orig, uint32_t *sizes)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_genomes) return;
+    const uint32_t i = rank[g];   // (the g-th key belongs to genome g: k_cluster_keys32)
+    orig[i] = g;
+    sizes[i] = (uint32_t)(off[g + 1] - off[g]);
 }
 
 // one wave per internal genome: its hashes move to their place in the internal-order CSR
@@ -662,12 +723,9 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         while ((1ULL << id_bits) < N) id_bits++;
         uint32_t slots = 1024;
         while (slots < 4ull * N * kMinK && slots < (1u << 30)) slots <<= 1;
-        DevBuf<unsigned long long> table(ctx), keys(ctx), keys_sorted(ctx);
+        DevBuf<unsigned long long> table(ctx);
         DevBuf<uint32_t> parent(ctx);
-        DevBuf<char> tmp(ctx);
         RK_HIP(ctx, table.alloc(slots));
-        RK_HIP(ctx, keys.alloc(N));
-        RK_HIP(ctx, keys_sorted.alloc(N));
         RK_HIP(ctx, parent.alloc(N));
         RK_HIP(ctx, hipMemsetAsync(table.p, 0xFF, (size_t)slots * 8, st));
         const unsigned nb_k = blocks_for((uint64_t)N * kMinK), nb_n = blocks_for(N);
@@ -678,13 +736,29 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             hipLaunchKernelGGL(k_minhash_insert<uint32_t>, dim3(nb_k), dim3(kThreads), 0, st, s->d_hashes, s->d_off, N, table.p, slots - 1);
             hipLaunchKernelGGL(k_minhash_vote<uint32_t>, dim3(nb_n), dim3(kThreads), 0, st, s->d_hashes, s->d_off, N, table.p, slots - 1, parent.p);
         }
-        hipLaunchKernelGGL(k_cluster_keys, dim3(nb_n), dim3(kThreads), 0, st, parent.p, N, id_bits, keys.p);
-        size_t tb = 0;
-        RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, keys.p, keys_sorted.p, N, 0, (unsigned)(2 * id_bits), st));
-        RK_HIP(ctx, tmp.alloc(tb));
-        RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, tb, keys.p, keys_sorted.p, N, 0, (unsigned)(2 * id_bits), st));
-        hipLaunchKernelGGL(k_order_from_keys, dim3(nb_n), dim3(kThreads), 0, st, keys_sorted.p, N, id_bits, s->d_off, idx->d_orig, idx->d_sizes);
-        hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, st, idx->d_sizes, N, idx->d_src_off);
+        if (N <= kRankMaxN) {
+            DevBuf<uint32_t> keys32(ctx), rank(ctx);
+            RK_HIP(ctx, keys32.alloc(N));
+            RK_HIP(ctx, rank.alloc(N));
+            RK_HIP(ctx, hipMemsetAsync(rank.p, 0, (size_t)N * 4, st));
+            hipLaunchKernelGGL(k_cluster_keys32, dim3(nb_n), dim3(kThreads), 0, st, parent.p, N, id_bits, keys32.p);
+            hipLaunchKernelGGL(k_rank_keys, dim3((N + kRankQ - 1) / kRankQ, (N + kRankStretch - 1) / kRankStretch), dim3(kRankThreads), 0, st,
+                               keys32.p, N, rank.p);
+            hipLaunchKernelGGL(k_order_from_rank, dim3(nb_n), dim3(kThreads), 0, st, rank.p, N, s->d_off, idx->d_orig, idx->d_sizes);
+            hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, st, idx->d_sizes, N, idx->d_src_off);
+        } else {
+            DevBuf<unsigned long long> keys(ctx), keys_sorted(ctx);
+            DevBuf<char> tmp(ctx);
+            RK_HIP(ctx, keys.alloc(N));
+            RK_HIP(ctx, keys_sorted.alloc(N));
+            hipLaunchKernelGGL(k_cluster_keys, dim3(nb_n), dim3(kThreads), 0, st, parent.p, N, id_bits, keys.p);
+            size_t tb = 0;
+            RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, keys.p, keys_sorted.p, N, 0, (unsigned)(2 * id_bits), st));
+            RK_HIP(ctx, tmp.alloc(tb));
+            RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, tb, keys.p, keys_sorted.p, N, 0, (unsigned)(2 * id_bits), st));
+            hipLaunchKernelGGL(k_order_from_keys, dim3(nb_n), dim3(kThreads), 0, st, keys_sorted.p, N, id_bits, s->d_off, idx->d_orig, idx->d_sizes);
+            hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, st, idx->d_sizes, N, idx->d_src_off);
+        }
         idx->relabeled = true;
         RK_HIP(ctx, hipGetLastError());
     } else {
@@ -720,9 +794,10 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         fa.rb = rb;
         fa.nb = 1u << B;
         fa.n_chunks = (uint32_t)((H + kPartChunk - 1) / kPartChunk);
-        DevBuf<uint32_t> matrix(ctx), total(ctx), bstart(ctx), ucount(ctx), ubase(ctx), tmp_uhash(ctx), tmp_upos(ctx), n_open(ctx), n_cov(ctx);
+        DevBuf<uint32_t> chunk_first(ctx), matrix(ctx), total(ctx), bstart(ctx), ucount(ctx), ubase(ctx), tmp_uhash(ctx), tmp_upos(ctx), n_open(ctx), n_cov(ctx);
         DevBuf<unsigned long long> keys(ctx);
         DevBuf<uint2> self_raw(ctx);
+        RK_HIP(ctx, chunk_first.alloc((size_t)fa.n_chunks + 1));
         RK_HIP(ctx, matrix.alloc((size_t)fa.n_chunks * fa.nb));
         RK_HIP(ctx, total.alloc(fa.nb));
         RK_HIP(ctx, bstart.alloc((size_t)fa.nb + 1));
@@ -734,15 +809,16 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         RK_HIP(ctx, self_raw.alloc(H));
         RK_HIP(ctx, n_open.alloc((size_t)N + 1));
         RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
-        const size_t part_lds = (size_t)fa.nb * 4;
+        const size_t part_lds = (size_t)fa.nb * 4 + 2 * kStageGenomes * 8;   // bucket counters + the chunk's genome bounds
         if (part_lds > 48 * 1024) {
             RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
             RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
         }
-        hipLaunchKernelGGL(k_part_hist, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, matrix.p, res.p);
-        hipLaunchKernelGGL(k_part_colscan, dim3(blocks_for(fa.nb)), dim3(kThreads), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
+        hipLaunchKernelGGL(k_chunk_first, dim3(blocks_for((uint64_t)fa.n_chunks + 1)), dim3(kThreads), 0, st, idx->d_src_off, N, fa.n_chunks, chunk_first.p);
+        hipLaunchKernelGGL(k_part_hist, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, res.p);
+        hipLaunchKernelGGL(k_part_colscan, dim3((fa.nb + 63) / 64), dim3(1024), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
         hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart.p, res.p);
-        hipLaunchKernelGGL(k_part_scatter, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, matrix.p, bstart.p, keys.p);
+        hipLaunchKernelGGL(k_part_scatter, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
         EmitArgs ea;
         ea.keys = keys.p;
         ea.bstart = bstart.p;
@@ -757,7 +833,22 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         ea.ucount = ucount.p;
         ea.self_raw = self_raw.p;
         ea.res = res.p;
-        hipLaunchKernelGGL(k_bucket_emit, dim3(fa.nb), dim3(kEmitThreads), 0, st, ea);
+        ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
+        if (ea.debug) {  // developer ablations leave stages out: whatever they do not write must still be harmless downstream
+            RK_HIP(ctx, hipMemsetAsync(ucount.p, 0, (size_t)fa.nb * 4, st));
+            RK_HIP(ctx, hipMemsetAsync(self_raw.p, 0, H * sizeof(uint2), st));
+            RK_HIP(ctx, hipMemsetAsync(tmp_upos.p, 0, H * 4, st));
+        }
+        {
+            const int emit_t = getenv("RK_INDEX_EMIT_T") ? atoi(getenv("RK_INDEX_EMIT_T")) : 512;
+            const bool narrow = low_bits + gb <= 32;  // (hash_low, genome) fits 32 bits
+#define RK_EMIT(TT) do { if (narrow) hipLaunchKernelGGL((k_bucket_emit<TT, uint32_t>), dim3(fa.nb), dim3(TT), 0, st, ea); \
+                         else hipLaunchKernelGGL((k_bucket_emit<TT, unsigned long long>), dim3(fa.nb), dim3(TT), 0, st, ea); } while (0)
+            if (emit_t == 256) RK_EMIT(256);
+            else if (emit_t == 1024) RK_EMIT(1024);
+            else RK_EMIT(512);
+#undef RK_EMIT
+        }
         hipLaunchKernelGGL(k_heads_scan, dim3(1), dim3(1024), 0, st, ucount.p, fa.nb, ubase.p, res.p);
         hipLaunchKernelGGL(k_heads_place, dim3(fa.nb), dim3(kThreads), 0, st, tmp_uhash.p, tmp_upos.p, bstart.p, ucount.p, ubase.p, fa.nb,
                            (uint32_t)H, idx->d_uhash, idx->d_upos);
