@@ -158,7 +158,9 @@ int rk_pack_genomes(const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
                     const uint64_t *genome_rec, uint32_t n_genomes, const uint64_t *gbeg,
                     uint8_t *packed, uint64_t packed_bytes);
 
-/* device-resident CSR of sketches */
+/* device-resident CSR of sketches.  A genome's hashes may come in any order (the reference writes `unordered_set`
+ * iteration order, src/sketch.cpp:537-553): the library sorts them on the device, rk_sketches_download returns them
+ * ascending.  A sketch that repeats a hash keeps its repeats (they count, src/dist.cpp:199-202). */
 int rk_sketches_from_host(rk_ctx *ctx, const uint32_t *hashes, const uint64_t *off,
                           uint32_t n_genomes, rk_sketches **out);
 /* same from device-resident arrays (copied device-to-device into a library-owned object) */
@@ -217,6 +219,11 @@ int rk_index_built_fast(const rk_index *idx);
 /* sum over all reference hashes h of c_h^2 = postings streamed by a full alldist
  * (the T of the roofline formula) */
 uint64_t rk_index_sum_sq(const rk_index *idx);
+/* The all-vs-all join reads one 8-byte slice record per (genome, hash) pair with later sharers.  out[0] = records,
+ * out[1] = of which in compact form (first genome + bitmask: the record IS the posting list, no posting is gathered),
+ * out[2] = records the row-pair kernel walks (the rest are covered by the pair partner), out[3] = 0.  Computed on first
+ * request (one small kernel) and cached; 0s for an imported index. */
+int rk_index_self_stats(const rk_index *idx, uint64_t out[4]);
 /* Multi-GPU: the whole index as ONE contiguous device blob, so that the owner can hand it
  * to an RCCL broadcast (one collective, no reduction: query rows are independent) and every
  * peer rebuilds an identical rk_index from the received bytes.  pack/unpack only enqueue

@@ -121,6 +121,37 @@ int rk_occupancy(rk_ctx *ctx, const void *kernel, int threads, size_t lds_bytes)
     return per_cu;
 }
 
+// ---- counter calibration (developer): a streaming read of a known byte count at 4, 8 or 16 bytes per lane, so that
+// FETCH_SIZE can be calibrated on the access widths the kernels use (MI355X_MICROARCH.md: only the 16 B/lane
+// factor is documented).  tools/prof_driver.py calib
+template <class V> __global__ void k_calib_read(const V *p, size_t n, unsigned long long *sink)
+{
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const V v = p[i];
+        const unsigned char *b = reinterpret_cast<const unsigned char *>(&v);
+        acc += b[0] + b[sizeof(V) - 1];
+    }
+    if (acc == 0x1234567ULL) *sink = acc;  // (keeps the loads alive)
+}
+extern "C" int rk_debug_calib_read(rk_ctx *ctx, uint64_t bytes, int width)
+{
+    if (!ctx || (width != 4 && width != 8 && width != 16)) return RK_ERR_ARG;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<char> buf(ctx);
+    DevBuf<unsigned long long> sink(ctx);
+    RK_HIP(ctx, buf.alloc(bytes));
+    RK_HIP(ctx, sink.alloc(1));
+    RK_HIP(ctx, hipMemsetAsync(buf.p, 1, bytes, ctx->stream));
+    const unsigned grid = (unsigned)ctx->num_cu * 8;
+    if (width == 4) hipLaunchKernelGGL(k_calib_read<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t *)buf.p, bytes / 4, sink.p);
+    else if (width == 8) hipLaunchKernelGGL(k_calib_read<uint2>, dim3(grid), dim3(256), 0, ctx->stream, (const uint2 *)buf.p, bytes / 8, sink.p);
+    else hipLaunchKernelGGL(k_calib_read<uint4>, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)buf.p, bytes / 16, sink.p);
+    RK_HIP(ctx, hipGetLastError());
+    RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RK_OK;
+}
+
 extern "C" {
 
 const char *rk_version(void) { return "rabbitkssd-amd 0.1.0 (gfx950)"; }

@@ -228,8 +228,10 @@ __device__ inline uint2 compact_slice(uint2 r, const uint32_t *postings)
 
 // one wave per genome: open slices to the front of the row, covered ones behind them, empty ones dropped; the order
 // inside each class is the source order (ballot ranks)
+// compact: the sketches are sets.  A genome that repeats a hash sits several times in the list and must be counted as
+// often (src/dist.cpp:199-202): a bitmask cannot say that, so the slices of a multiset index stay posting ranges.
 __global__ void k_row_place(const uint64_t *off, uint32_t n_genomes, const uint2 *self_raw,
-                            const uint64_t *self_off, const uint64_t *self_split, const uint32_t *postings, uint2 *out)
+                            const uint64_t *self_off, const uint64_t *self_split, const uint32_t *postings, bool compact, uint2 *out)
 {
     const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= n_genomes) return;
@@ -242,7 +244,7 @@ __global__ void k_row_place(const uint64_t *off, uint32_t n_genomes, const uint2
         const uint2 raw = e < e1 ? self_raw[e] : make_uint2(0, 0);
         const uint8_t c = slice_class(raw);
         uint2 r = slice_range(raw);
-        if (c != kEmpty) r = compact_slice(r, postings);
+        if (c != kEmpty && compact) r = compact_slice(r, postings);
         const unsigned long long mo = __ballot(c == kOpen), mc = __ballot(c == kCovered);
         if (c == kOpen) out[at_open + __popcll(mo & lt)] = r;
         if (c == kCovered) out[at_cov + __popcll(mc & lt)] = r;
@@ -282,6 +284,23 @@ __global__ void k_sum_sq(const uint32_t *upos, uint64_t U, unsigned long long *a
         unsigned long long t = 0;
         for (int w = 0; w < kThreads / 64; w++) t += part[w];
         if (t) atomicAdd(acc, t);
+    }
+}
+
+// one wave per genome: compact records of its row, records the pair kernel walks (all of an even row, the uncovered of an odd one)
+__global__ void k_self_stats(const uint2 *selfrange, const uint64_t *self_off, const uint64_t *self_split, uint32_t n_genomes,
+                             unsigned long long *acc)
+{
+    const uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= n_genomes) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t e0 = self_off[g], e1 = self_off[g + 1];
+    unsigned long long cpt = 0;
+    for (uint64_t e = e0 + lane; e < e1; e += 64) cpt += selfrange[e].x >> 31;
+    for (int o = 32; o > 0; o >>= 1) cpt += __shfl_down(cpt, o);
+    if (lane == 0) {
+        if (cpt) atomicAdd(&acc[0], cpt);
+        atomicAdd(&acc[1], (unsigned long long)(((g & 1u) ? self_split[g] : e1) - e0));
     }
 }
 
@@ -672,6 +691,31 @@ uint64_t rk_index_sum_sq(const rk_index *cidx)
     return ss;
 }
 
+int rk_index_self_stats(const rk_index *cidx, uint64_t out[4])
+{
+    if (!cidx || !out) return RK_ERR_ARG;
+    rk_index *idx = const_cast<rk_index *>(cidx);
+    std::lock_guard<std::mutex> lk(idx->lazy_mu);
+    rk_ctx *ctx = idx->ctx;
+    if (!idx->self_stats_known && idx->d_selfrange && idx->n_ref) {
+        RK_HIP(ctx, hipSetDevice(ctx->device));
+        DevBuf<unsigned long long> acc(ctx);
+        RK_HIP(ctx, acc.alloc(2));
+        RK_HIP(ctx, hipMemsetAsync(acc.p, 0, 16, ctx->stream));
+        hipLaunchKernelGGL(k_self_stats, dim3((idx->n_ref + 3) / 4), dim3(kThreads), 0, ctx->stream, idx->d_selfrange, idx->d_self_off,
+                           idx->d_self_split, idx->n_ref, acc.p);
+        RK_HIP(ctx, hipGetLastError());
+        unsigned long long v[2] = {0, 0};
+        RK_TRY(rk_read_back(ctx, v, acc.p, 16, ctx->stream));
+        idx->self_stats[0] = idx->n_self;
+        idx->self_stats[1] = v[0];
+        idx->self_stats[2] = v[1];
+        idx->self_stats_known = true;
+    }
+    for (int i = 0; i < 4; i++) out[i] = idx->self_stats[i];
+    return RK_OK;
+}
+
 int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **out)
 {
     if (!ctx || !s || !out) return RK_ERR_ARG;
@@ -774,7 +818,8 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
 
     // ---- fast path: two-level bucket sort, second level and all emission in LDS (rk_index_fast.inc) -----------------
     int B = 1, gb = 1, rb = 1;
-    while (B < hash_bits && B < 31 && ((H + kBucketTarget - 1) / kBucketTarget) > (1ULL << B)) B++;
+    // (at most kMaxBucketBits: a bigger collection gets fuller buckets, up to the LDS capacity -- beyond it the kernels raise the overflow flag)
+    while (B < hash_bits && B < kMaxBucketBits && ((H + kBucketTarget - 1) / kBucketTarget) > (1ULL << B)) B++;
     while ((1ULL << gb) < N) gb++;
     while ((1ULL << rb) < s->max_size) rb++;
     const int low_bits = hash_bits - B;
@@ -938,7 +983,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         hipLaunchKernelGGL(k_row_counts, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, self_raw.p, n_open.p, n_cov.p);
         hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, res.p);
         hipLaunchKernelGGL(k_row_place, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, self_raw.p,
-                           idx->d_self_off, idx->d_self_split, idx->d_postings, idx->d_selfrange);
+                           idx->d_self_off, idx->d_self_split, idx->d_postings, s->is_set, idx->d_selfrange);
         RK_HIP(ctx, hipGetLastError());
         RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));  // the one synchronisation of the build
     } else if (!H) {

@@ -130,6 +130,8 @@ struct rk_index {
     int dir_bits = 0, dir_shift = 0;
     uint64_t sum_sq = 0;             // sum of squared list lengths, computed on first request
     bool sum_sq_known = false;
+    uint64_t self_stats[4] = {0, 0, 0, 0};  // rk_index_self_stats, computed on first request
+    bool self_stats_known = false;
     uint64_t max_src_size = 0;       // largest source sketch (built index only)
     uint64_t max_ref_size = 0;       // largest reference sketch (every index)
     uint64_t min_ref_size = 0;       // smallest NON-EMPTY reference sketch (0: all empty): lower bound of a containment denominator

@@ -1128,13 +1128,8 @@ int rk_sketch_batch_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *seq, cons
 
 }  // extern "C"
 
-// sketches that crossed the boundary from the host (or from caller-owned device arrays): are they sets in
-// ascending order?  An intersection count is then bounded by the smaller sketch (narrow LDS counters,
-// rk_distq.hip) and the index build needs no duplicate check.  Synchronises ctx->stream.
-int rk_sketches_classify(rk_ctx *ctx, rk_sketches *s)
+static int check_sets(rk_ctx *ctx, rk_sketches *s, bool *ascending)
 {
-    s->max_size = 0;
-    for (uint32_t g = 0; g < s->n; g++) s->max_size = std::max<uint64_t>(s->max_size, s->h_off[g + 1] - s->h_off[g]);
     DevBuf<uint32_t> bad(ctx);
     RK_HIP(ctx, bad.alloc(1));
     RK_HIP(ctx, hipMemsetAsync(bad.p, 0, 4, ctx->stream));
@@ -1148,6 +1143,50 @@ int rk_sketches_classify(rk_ctx *ctx, rk_sketches *s)
     }
     uint32_t b = 0;
     RK_TRY(rk_read_back(ctx, &b, bad.p, 4, ctx->stream));
-    s->is_set = b == 0;
+    *ascending = b == 0;
+    return RK_OK;
+}
+
+// Sketches that crossed the boundary from the host (or from caller-owned device arrays).  A `.sketch` written by the
+// reference lists every genome's hashes in `unordered_set` iteration order (src/sketch.cpp:537-553: the sort is commented
+// out): such sketches are SORTED here, on the device, genome by genome (one segmented radix sort; every consumer treats a
+// sketch as a set, and rk_sketches_download documents the ascending order) -- they then are sets in ascending order like the
+// sketcher's own output: an intersection count is bounded by the smaller sketch (narrow LDS counters, rk_distq.hip), the
+// index build takes its fast path and rows pair up.  Only a sketch that repeats a hash (a malformed or foreign file;
+// the reference would count the repeats, src/dist.cpp:199-202) stays a multiset: is_set = false, 32-bit counters, general
+// index build.  Synchronises ctx->stream.
+int rk_sketches_classify(rk_ctx *ctx, rk_sketches *s)
+{
+    s->max_size = 0;
+    for (uint32_t g = 0; g < s->n; g++) s->max_size = std::max<uint64_t>(s->max_size, s->h_off[g + 1] - s->h_off[g]);
+    bool ascending = true;
+    RK_TRY(check_sets(ctx, s, &ascending));
+    if (!ascending && s->total < 0xFFFFFFFFULL) {
+        size_t tb = 0;
+        const unsigned int n = (unsigned int)s->total;
+        if (s->wide) {
+            DevBuf<uint64_t> sorted(ctx);
+            DevBuf<char> tmp(ctx);
+            RK_HIP(ctx, sorted.alloc(s->total + 1));
+            RK_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, s->d_hashes64, sorted.p, n, s->n, s->d_off, s->d_off + 1, 0, 64, ctx->stream));
+            RK_HIP(ctx, tmp.alloc(tb));
+            RK_HIP(ctx, rocprim::segmented_radix_sort_keys(tmp.p, tb, s->d_hashes64, sorted.p, n, s->n, s->d_off, s->d_off + 1, 0, 64, ctx->stream));
+            RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            rk_pool_free(ctx, s->d_hashes64);
+            s->d_hashes64 = sorted.release();
+        } else {
+            DevBuf<uint32_t> sorted(ctx);
+            DevBuf<char> tmp(ctx);
+            RK_HIP(ctx, sorted.alloc(s->total + 1));
+            RK_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, s->d_hashes, sorted.p, n, s->n, s->d_off, s->d_off + 1, 0, 32, ctx->stream));
+            RK_HIP(ctx, tmp.alloc(tb));
+            RK_HIP(ctx, rocprim::segmented_radix_sort_keys(tmp.p, tb, s->d_hashes, sorted.p, n, s->n, s->d_off, s->d_off + 1, 0, 32, ctx->stream));
+            RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            rk_pool_free(ctx, s->d_hashes);
+            s->d_hashes = sorted.release();
+        }
+        RK_TRY(check_sets(ctx, s, &ascending));  // still not strictly ascending: some genome repeats a hash
+    }
+    s->is_set = ascending;
     return RK_OK;
 }

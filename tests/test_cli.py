@@ -128,6 +128,27 @@ def test_union_and_sub_set_algebra(tmp_path):
         assert h[int(off[i]):int(off[i + 1])].tolist() == want
 
 
+@pytest.mark.parametrize("tag", ["32", "64"])
+def test_info_union_sub_merge_equal_the_reference_outputs(tmp_path, tag):
+    # tests/golden/f4: what the reference's own command_info / command_union / command_sub / command_merge
+    # (src/subCommand.cpp:70-147, :307-543, :545-794, :796-892, compiled unmodified: tests/golden/make_f4_golden.py) wrote
+    # for the committed 32- and 64-bit sketch fixtures.  The paths are relative to tests/golden, like the generator's:
+    # the reference stores the path strings in its outputs.
+    man = json.load(open(os.path.join(GOLDEN, "f4", "manifest.json")))[tag]
+    ref, qry, lst = man["ref"], man["qry"], man["list"]
+    want = lambda name: open(os.path.join(GOLDEN, "f4", name), "rb").read()
+    run(["info", "-i", qry, "-o", tmp_path / "i.txt"], cwd=GOLDEN)
+    assert (tmp_path / "i.txt").read_bytes() == want("info%s.txt" % tag)
+    run(["info", "-i", qry, "-o", tmp_path / "d.txt", "-F"], cwd=GOLDEN)
+    assert (tmp_path / "d.txt").read_bytes() == want("info%s_detail.txt" % tag)
+    run(["union", "-i", ref, "-o", tmp_path / "u.sketch"], cwd=GOLDEN)
+    assert (tmp_path / "u.sketch").read_bytes() == want("union%s.sketch" % tag)
+    run(["sub", "--rs", ref, "--qs", qry, "-o", tmp_path / "s.sketch"], cwd=GOLDEN)
+    assert (tmp_path / "s.sketch").read_bytes() == want("sub%s.sketch" % tag)
+    run(["merge", "-i", lst, "-o", tmp_path / "m.sketch"], cwd=GOLDEN)
+    assert (tmp_path / "m.sketch").read_bytes() == want("merge%s.sketch" % tag)
+
+
 def test_convert_to_kssd_layout_and_back(tmp_path):
     # SURVEY Appendix A.5 / src/sketch.cpp:1288-1365
     src = os.path.join(GOLDEN, "dist", "qry.sketch")

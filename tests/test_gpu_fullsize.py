@@ -71,32 +71,62 @@ def test_config2_alldist_10k_exact(ctx):
     assert np.max(np.abs(dev["dist"] - full["dist"])) <= 1e-12
 
 
-def test_config3_alldist_50k_properties_and_exact(ctx):
-    """configs[3] (one rank's view): 50,000 sketches -> 1.25e9 pairs, 225,000 hits."""
+def dev_hits(ctx, idx, triangle, metric, kmer, D, queries=None, cap=1 << 19, **shard):
+    """hits of the asynchronous all-in-HBM entry point (what bench.py times), read back and ordered by (row, col)"""
+    import torch
+    buf = torch.empty(cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ctx.dist_rows_dev(idx, triangle, metric, kmer, D, buf.data_ptr(), cap, cnt.data_ptr(),
+                      stream=torch.cuda.current_stream().cuda_stream, queries=queries, **shard)
+    torch.cuda.synchronize()
+    n = int(cnt.item())
+    assert n <= cap
+    dev = np.frombuffer(buf.cpu().numpy().tobytes()[: n * capi.HIT_DTYPE.itemsize], dtype=capi.HIT_DTYPE)
+    return dev[np.lexsort((dev["col"], dev["row"]))]
+
+
+def check_dev_hits(dev, want):
+    # (the device-resident API keeps the device's own `log`: north_star's 1e-12; everything else is exact)
+    assert len(dev) == len(want)
+    for f in ("row", "col", "common", "size0", "size1", "jorc"):
+        assert np.array_equal(dev[f], want[f]), f
+    assert np.max(np.abs(dev["dist"] - want["dist"]), initial=0.0) <= 1e-12
+
+
+def test_config3_alldist_50k_exact(ctx):
+    """configs[3] (one rank's view): 50,000 sketches -> 1.25e9 pairs, 225,000 hits -- every hit identical to the oracle's
+    (all host cores), through the synchronous API and through rk_dist_rows_dev for the banded whole launch and for one
+    1/8 block-cyclic shard (what a GPU of the 8-GPU run computes)."""
     names, h, off = synth.clade_sketches(50000, 1220, 28)
     idx = ctx.index_build(ctx.sketches_from_host(h, off), 28)
+    assert idx.built_fast and "bands" in ctx.dist_kernel_name(idx, None, 1, 0, 20, 0.05)
+    postings, counts = ok.index_build32(h, off, 28)
+    want, _ = ok.index_dist32(counts, 28, postings, np.diff(off).astype(np.uint32), h, off, 1, 0, 20, 0.05, threads=CORES)
+    del counts
+    assert len(want) == 45 * 5000
     mine, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05)
-    assert len(mine) == 45 * 5000
-    assert np.all(mine["row"] // 10 == mine["col"] // 10) and np.all(mine["col"] > mine["row"])
-    sizes = np.diff(off).astype(np.int64)
-    assert np.array_equal(mine["size0"], sizes[mine["row"]]) and np.array_equal(mine["size1"], sizes[mine["col"]])
-    # exact check of the counts against set intersections on a sample of hits
-    rng = np.random.default_rng(0)
-    for t in rng.integers(0, len(mine), size=200):
-        i, j = int(mine["row"][t]), int(mine["col"][t])
-        a = h[int(off[i]):int(off[i + 1])]
-        b = h[int(off[j]):int(off[j + 1])]
-        assert mine["common"][t] == len(np.intersect1d(a, b, assume_unique=True))
-        jac, d = ok.distance(mine["common"][t], len(a), len(b), 0, 20)
-        assert mine["jorc"][t] == jac and mine["dist"][t] == d
-    # rows of one rank out of 8 (what a GPU of configs[3] computes) are a subset with the same records
+    check_hits(mine, want)
+    assert np.array_equal(idx.export(want_counts=False)[0], postings)
+    check_dev_hits(dev_hits(ctx, idx, 1, 0, 20, 0.05), want)
+    # rows of one rank out of 8 are a subset with the same records
     part, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=3, row_step=8)
-    sel = mine[idx.shard_of(mine, 8) == 3]
-    assert part.tobytes() == sel.tobytes()
+    assert part.tobytes() == mine[idx.shard_of(mine, 8) == 3].tobytes()
     # the block-cyclic shard the multi-GPU callers use (blocks of 16 rows)
     part, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=5, row_step=8, row_block=16)
-    sel = mine[idx.shard_of(mine, 8, 16) == 5]
-    assert part.tobytes() == sel.tobytes()
+    sel = idx.shard_of(mine, 8, 16) == 5
+    assert part.tobytes() == mine[sel].tobytes()
+    check_dev_hits(dev_hits(ctx, idx, 1, 0, 20, 0.05, row_first=5, row_step=8, row_block=16), want[sel])
+    # the same collection in shuffled order: renumbered internally, same pairs (mapped back), same kernel variants
+    order = synth.genome_order(50000, "shuffled", seed=11)
+    _, h2, off2 = synth.permute_genomes(names, h, off, order)
+    idx2 = ctx.index_build(ctx.sketches_from_host(h2, off2), 28)
+    assert ctx.dist_kernel_name(idx2, None, 1, 0, 20, 0.05) == ctx.dist_kernel_name(idx, None, 1, 0, 20, 0.05)
+    m2, _ = ctx.dist_rows(idx2, None, 1, 0, 20, 0.05)
+    a, b = order[m2["row"].astype(np.int64)], order[m2["col"].astype(np.int64)]
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    key = np.lexsort((hi, lo))
+    assert np.array_equal(lo[key], want["row"]) and np.array_equal(hi[key], want["col"])
+    assert np.array_equal(m2["common"][key], want["common"]) and np.array_equal(m2["dist"][key], want["dist"])
 
 
 def test_dense_output_ordered_on_the_device(ctx):
@@ -149,6 +179,7 @@ def test_config4_ref_vs_query_100k(ctx):
         mine, _ = ctx.dist_rows(idx, qs, 0, metric, 20, D)
         assert len(want) >= 24 * 6
         check_hits(mine, want)
+        check_dev_hits(dev_hits(ctx, idx, 0, metric, 20, D, queries=qs), want)   # the fused query kernel, hits left in HBM
 
 
 def test_config0_fasta_to_alldist_64x5mb(ctx):

@@ -92,6 +92,8 @@ def main(tag, traffic_only=False):
         factor = 2.0 if wide_stream else 1.0
         hbm = int(round((fetch * factor + write) * 1024))
         json.dump({"kernel": variant_of(dirs, base), "workload": workload, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+                   "SQ_ACTIVE_INST_VALU": v.get((base, "SQ_ACTIVE_INST_VALU")), "SQ_INSTS_VALU": v.get((base, "SQ_INSTS_VALU")),
+                   "GRBM_GUI_ACTIVE": v.get((base, "GRBM_GUI_ACTIVE")),
                    "fetch_correction": factor, "TCC_MISS_sum": miss, "TCC_MISS_x64B": miss * 64,
                    "hbm_bytes_per_launch": hbm,
                    "passes": "FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, see profiles/%s_pmc_summary.csv" % tag},

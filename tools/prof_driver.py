@@ -135,7 +135,20 @@ def index(n_genomes=10000, reps=5):
         del idx, sk2
 
 
+def calib(mbytes=1024, width=16):
+    """a streaming read of `mbytes` MiB at `width` bytes per lane (k_calib_read): FETCH_SIZE of this launch against the
+    known byte count calibrates the counter for that access width (run under rocprofv3 --pmc FETCH_SIZE)"""
+    import ctypes as C
+    ctx = capi.Context(0)
+    L = capi.lib()
+    L.rk_debug_calib_read.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+    for _ in range(2):
+        rc = L.rk_debug_calib_read(ctx._h, C.c_uint64(mbytes << 20), int(width))
+        assert rc == 0
+    print("calib: read %d bytes at %d B/lane" % (mbytes << 20, width))
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
     args = [int(x) for x in sys.argv[2:]]
-    {"sketch": sketch, "dist": dist, "dist_rq": dist_rq, "dist_rq_dev": dist_rq_dev, "index": index}[which](*args)
+    {"sketch": sketch, "dist": dist, "dist_rq": dist_rq, "dist_rq_dev": dist_rq_dev, "index": index, "calib": calib}[which](*args)
