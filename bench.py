@@ -87,7 +87,7 @@ class Env:
     def __init__(self, args):
         import torch
         import torch.distributed as dist
-        from rabbitkssd_amd import capi
+        from rabbitkssd_amd import capi, shard
         self.torch, self.dist, self.capi, self.args = torch, dist, capi, args
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -104,10 +104,10 @@ class Env:
         torch.cuda.set_device(self.local_rank)
         if self.world > 1:
             if args.backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, timeout=shard.init_timeout(),
                                         device_id=torch.device("cuda", self.local_rank))
             else:
-                dist.init_process_group(args.backend, rank=self.rank, world_size=self.world)
+                dist.init_process_group(args.backend, rank=self.rank, world_size=self.world, timeout=shard.init_timeout())
         self.ctx = capi.Context(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         # a stream of our own: torch.cuda.Event measures the stream it is recorded on
@@ -425,8 +425,63 @@ def sketch_block(env, n_genomes, length, steps=5):
         if pmc.get("SQ_ACTIVE_INST_VALU"):
             out["roofline"]["issue_frac"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / ENGINE_CLOCK_HZ / (kernel_ms * 1e-3)
     if not env.args.no_cpu_baseline:
-        out["cpu_baseline"] = sketch_cpu_baseline(packed, stride, length, n_genomes, table)
+        out["cpu_baseline"] = sketch_cpu_reference(packed, stride, length, n_genomes) or \
+            sketch_cpu_baseline(packed, stride, length, n_genomes, table)
     return out
+
+
+REF_SKETCH = os.path.join(ROOT, "oracle", "_ref", "ref_sketch_driver")
+
+
+def sketch_cpu_reference(packed, stride, length, n_genomes):
+    """the reference's own sketchFastaFile (src/sketch.cpp:455-566, small-file path; oracle/_ref/ref_sketch_driver) on FASTA
+    files of the same synthetic genomes, -t = host cores (capped at the file count: equal sizes keep every file below
+    totalSize/numThreads, i.e. off the RabbitFX big-file branch), and -- on the very same files -- `rabbit_kssd sketch`"""
+    from rabbitkssd_amd import synth
+    if not os.path.exists(REF_SKETCH) or not os.path.exists(TOOL):
+        return None
+    cores = host_cores()
+    sample = min(n_genomes, 128)
+    threads = max(1, min(cores, sample))
+    host = packed.view(n_genomes, stride)[:sample, :length].cpu().numpy()
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
+        names = []
+        for g in range(sample):
+            name = os.path.join(tmp, "g%03d.fna" % g)
+            open(name, "wb").write(synth.fasta_text("g%03d" % g, host[g]))
+            names.append(name)
+        open(os.path.join(tmp, "g.list"), "w").write("\n".join(names) + "\n")
+        shuf = os.path.join(tmp, "L3K10.shuf")
+        if subprocess.run([TOOL, "shuffle", "-k", "10", "-s", "6", "-l", "3", "-o", shuf], stdout=subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL).returncode != 0:
+            return None
+        t0 = time.time()
+        p = subprocess.run([REF_SKETCH, "sketch", shuf, os.path.join(tmp, "g.list"), os.path.join(tmp, "ref_out"), str(threads), "1"],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t_ref = time.time() - t0
+        if p.returncode != 0:
+            return None
+        walls = []
+        for _ in range(3):
+            t0 = time.time()
+            q = subprocess.run([TOOL, "sketch", "-i", os.path.join(tmp, "g.list"), "-L", shuf, "-o", os.path.join(tmp, "gpu_out"), "-q",
+                                "-t", str(min(cores, 16))], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            walls.append(time.time() - t0)
+            if q.returncode != 0:
+                walls = []
+                break
+        kmers = sample * (length - 19)
+        res = {"value": kmers / t_ref, "unit": "k-mers/s", "cores": threads, "kind": "reference",
+               "sample": "%d synthetic 5 Mb genomes as FASTA files (page cache), reference sketchFastaFile -t %d, process wall %.3f s "
+                         "(reads the 64 MiB .shuf + %d MB of FASTA, sketches, writes the .sketch)" % (sample, threads, t_ref, sample * length // 1000000),
+               "wall_s": t_ref}
+        if walls:
+            med = sorted(walls)[len(walls) // 2]
+            res["tool_wall_s"] = med
+            res["tool_wall_runs_s"] = walls
+            res["tool_vs_reference_wall"] = t_ref / med
+            res["tool_note"] = "`rabbit_kssd sketch` on the same list and .shuf (process start, HIP init, parse, upload, kernels, .sketch), median of 3"
+        return res
 
 
 def sketch_cpu_baseline(packed, stride, length, n_genomes, table):

@@ -208,6 +208,8 @@ int rk_ctx_create(int device, rk_ctx **out)
     ctx->sw_dist_xcd_rows = env_u32("RK_DIST_XCD_ROWS", 0);
     ctx->sw_dist_bands = getenv("RK_DIST_BANDS") ? atoi(getenv("RK_DIST_BANDS")) != 0 : 1;
     if (getenv("RK_DIST_BAND_MIN_ROWS")) ctx->sw_dist_band_min_rows = std::max(1, atoi(getenv("RK_DIST_BAND_MIN_ROWS")));
+    ctx->sw_dist_near = getenv("RK_DIST_NEAR") ? atoi(getenv("RK_DIST_NEAR")) != 0 : 1;
+    if (getenv("RK_DIST_NEAR_MIN")) ctx->sw_dist_near_min = std::max(1, atoi(getenv("RK_DIST_NEAR_MIN")));
     ctx->sw_dist_debug = getenv("RK_DIST_DEBUG") ? atoi(getenv("RK_DIST_DEBUG")) : 0;
     if (getenv("RK_DIST_LDS_KB")) ctx->sw_dist_lds_kb = std::max(0, atoi(getenv("RK_DIST_LDS_KB")));
     ctx->sw_sketch_img = getenv("RK_SKETCH_IMG") ? atoi(getenv("RK_SKETCH_IMG")) != 0 : 1;

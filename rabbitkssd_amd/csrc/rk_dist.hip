@@ -72,6 +72,10 @@ struct DistArgs {
     unsigned long long cap;
     unsigned long long *n_hits;
     int32_t *common_dense;      // optional [n_query, n_ref]
+    // list mode (the fallback of rk_near_kernel): the units are the ROWS unit_list[0 .. *unit_count); the last workgroup to
+    // finish resets *unit_count and *unit_done for the next launch
+    const uint32_t *unit_list;
+    uint32_t *unit_count, *unit_done;
 };
 
 #ifdef RK_DIST_PROFILE
@@ -178,12 +182,25 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
     // same time on the same XCD, and the slices of the next unit are always prefetched.  (Pulling
     // the positions with a fetch-add per unit instead was measured slower, 0.134 vs 0.122 ms: the
     // device-scope atomics cost more than the better balance at the end buys.)
+    const uint32_t n_units = a.unit_list ? *a.unit_count : a.n_units;   // (list mode: known on the device only)
+    // list mode: every workgroup counts itself out; the last one resets the list for the next launch
+    auto leave = [&]() {
+        if (a.unit_list && threadIdx.x == 0 && atomicAdd(a.unit_done, 1u) == gridDim.x * gridDim.y - 1) {
+            *a.unit_count = 0;
+            *a.unit_done = 0;
+        }
+    };
+    if (a.unit_list && n_units == 0) {   // the usual case of the fallback launch: nothing to do, before any LDS is touched
+        leave();
+        return;
+    }
+    const uint32_t units_per_xcd = a.unit_list ? ((n_units + 7) / 8 + a.units_per_chunk - 1) / a.units_per_chunk * a.units_per_chunk : a.units_per_xcd;
     const uint32_t xcd = blockIdx.x & 7, s8 = blockIdx.x >> 3;
     const uint32_t rpc = a.runs_per_chunk;
     const uint32_t run = ((s8 / rpc) * 8 + xcd) * rpc + s8 % rpc;
     const bool dynamic = a.persist != 0;
     const uint32_t slot0 = run * a.units_per_wg;
-    if (!dynamic && slot0 >= a.n_units) return;
+    if (!dynamic && slot0 >= n_units) return;
     const uint32_t col0 = a.col_base + blockIdx.y * a.tile_cols;
     const uint32_t col1 = min(a.n_ref, col0 + a.tile_cols);
     const uint32_t ncol = col1 - col0;
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
     const bool tri_filter = a.triangle && !a.common_dense;
     constexpr uint32_t kPerWord = U16 ? 2 : 1;
     const uint4 *c4 = reinterpret_cast<const uint4 *>(cnt);
-    const uint32_t slot_end = min(a.n_units, slot0 + a.units_per_wg);  // static runs
+    const uint32_t slot_end = min(n_units, slot0 + a.units_per_wg);  // static runs
     constexpr uint32_t kNone = 0xFFFFFFFFu;
     const uint32_t row_b_cell = a.pair_stride;  // first cell of the second row of a pair
 
@@ -213,6 +230,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
     // (block-cyclic; row_block 1 = plain interleave): this rank owns blocks row_first,
     // row_first + row_step, ...
     auto unit_row = [&](uint32_t slot) -> uint32_t {
+        if (a.unit_list) return a.unit_list[slot];
         slot += a.slot_base;
         const uint32_t upb = a.units_per_block;
         const uint32_t t = upb == 1 ? slot : slot / upb;
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
     };
     // the unit's first row, or kNone when the slot is past the end / has no work in this tile
     auto live_row = [&](uint32_t s) -> uint32_t {
-        if (s == kNone || s >= a.n_units) return kNone;
+        if (s == kNone || s >= n_units) return kNone;
         const uint32_t r = unit_row(s);
         return skipped(r) ? kNone : r;
     };
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
         const uint32_t upc = a.units_per_chunk;
         return ((q / upc) * 8 + x) * upc + q % upc;
     };
-    auto queue_unit = [&](uint32_t q) -> uint32_t { return q < a.units_per_xcd ? queue_slot(xcd, q) : kNone; };
+    auto queue_unit = [&](uint32_t q) -> uint32_t { return q < units_per_xcd ? queue_slot(xcd, q) : kNone; };
     auto load_slice = [&](uint64_t e, uint64_t e1) -> uint2 {
         return e < e1 ? a.ranges[e] : make_uint2(0, 0);
     };
@@ -787,6 +805,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
     const uint32_t n_st = min(s_cursor, kStageHits);
     PROF_MARK(11);
     PROF_FLUSH();
+    leave();
     if (n_st == 0) return;
     if (tid == 0) s_base = atomicAdd(a.n_hits, (unsigned long long)n_st);
     __syncthreads();
@@ -797,6 +816,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
     for (uint32_t i = tid; i < n_st * kW; i += kDistThreads)
         if (at0 + i / kW < a.cap) dst[at0 * kW + i] = src[i];
 }
+
+#include "rk_dist_near.inc"
 
 struct Plan {
     uint32_t n_units, tile_cols, n_tiles, cnt_words, row_words;
@@ -817,7 +838,7 @@ constexpr size_t lds_for_workgroups(size_t n) { return kLdsPerCu / n / kLdsGranu
 
 // n_cols: columns an LDS row must hold (the whole reference range, or what lies behind a band's first row)
 int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_query_size,
-              const rk_dist_opts *o, bool dense_mode, bool want_self, uint32_t n_cols, Plan *p)
+              const rk_dist_opts *o, bool dense_mode, bool want_self, uint32_t n_cols, Plan *p, bool allow_pair = true)
 {
     if (o->kmer_size <= 0) return rk_fail(ctx, RK_ERR_ARG, "kmer_size must be positive");
     if (o->row_block < 0) return rk_fail(ctx, RK_ERR_ARG, "row_block must be >= 0");
@@ -861,7 +882,7 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
     // each other with room for at least three workgroups per CU (measured: with fewer, the lost
     // occupancy costs more than the saved walks: 14,142 columns 0.127 ms paired vs 0.113 single)
     // (pairs rest on set semantics: with a repeated hash inside a genome the "covered" test of the index build fails)
-    const bool pair_ok = p->mode == kSelf && p->row_block % 2 == 0 && idx->d_self_split && idx->ref_sets &&
+    const bool pair_ok = allow_pair && p->mode == kSelf && p->row_block % 2 == 0 && idx->d_self_split && idx->ref_sets &&
                          (size_t)p->row_words * 8 + fixed + batch_extra <= lds_for_workgroups(std::max(1u, ctx->sw_dist_pair_minwg)) &&
                          ctx->sw_dist_pair != 2;
     if (pair_ok) p->mode = kSelfPair;
@@ -896,10 +917,13 @@ int make_plan(rk_ctx *ctx, const rk_index *idx, uint32_t n_query, uint64_t max_q
 
 int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uint64_t *range_off,
                 const uint64_t *size_off, uint32_t n_query, const rk_dist_opts *o, const Plan &p, rk_hit *hits_dev,
-                uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev, hipStream_t stream)
+                uint64_t cap, unsigned long long *n_hits_dev, int32_t *dense_dev, hipStream_t stream, uint32_t *fb = nullptr)
 {
-    if (!p.n_units || !idx->n_ref) return RK_OK;
+    if ((!p.n_units && !fb) || !idx->n_ref) return RK_OK;
     DistArgs a;
+    a.unit_list = fb ? fb + 4 : nullptr;   // fb: [0] count, [1] done, [4..] rows
+    a.unit_count = fb;
+    a.unit_done = fb ? fb + 1 : nullptr;
     a.ranges = ranges;
     a.range_off = range_off;
     a.range_split = p.mode == kSelfPair ? idx->d_self_split : nullptr;
@@ -936,9 +960,9 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.cap = cap;
     a.n_hits = n_hits_dev;
     a.common_dense = dense_dev;
-    a.units_per_wg = p.units_per_wg;
+    a.units_per_wg = fb ? 1 : p.units_per_wg;   // (list mode is always persistent: one unit at a time)
     const uint32_t unit_rows = p.mode == kSelfPair ? 2 : 1;
-    a.runs_per_chunk = std::max<uint32_t>(1, (ctx->sw_dist_xcd_rows ? ctx->sw_dist_xcd_rows : kRowsPerXcdChunk) / (p.units_per_wg * unit_rows));
+    a.runs_per_chunk = std::max<uint32_t>(1, (ctx->sw_dist_xcd_rows ? ctx->sw_dist_xcd_rows : kRowsPerXcdChunk) / (a.units_per_wg * unit_rows));
     a.cand_cap = p.cand_cap;
     a.stage_hits = p.stage_hits;
     // one workgroup per CU (rows of ~100 KB): nothing else hides the latency of evaluating a unit's handful of cells, so
@@ -965,15 +989,15 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.persist = 0;
     a.units_per_chunk = a.runs_per_chunk;  // units_per_wg == 1 in persistent mode
     a.units_per_xcd = gx / 8;
-    if (p.persist) {
+    if (p.persist || fb) {
         int per_cu = rk_occupancy(ctx, (const void *)kern, (int)p.threads, p.lds_bytes);
         // (the runtime's answer has been seen to count LDS finer than the hardware allocates it: a workgroup too many per CU
         // would start only when another ends and walk its static share of the units late)
         per_cu = std::min<int>(per_cu, (int)(kLdsPerCu / ((p.lds_bytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule)));
         const uint32_t resident = ((uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, ctx->num_cu) + 7) / 8 * 8;
-        if (gx > resident) {  // otherwise every unit gets its own workgroup anyway
+        if (gx > resident || fb) {  // otherwise every unit gets its own workgroup anyway (list mode: the count is on the device)
             a.persist = 1;
-            gx = resident;
+            gx = fb ? std::min<uint32_t>(resident, 512) : resident;
         }
     }
     hipLaunchKernelGGL(kern, dim3(gx, p.n_tiles), dim3(p.threads), p.lds_bytes, stream, a);
@@ -1036,9 +1060,101 @@ int plan_bands(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool den
     return RK_OK;
 }
 
+// The near-window self join (rk_dist_near.inc) applies when the report is sparse, the sketches are sets (compact slices
+// exist) and a reportable pair needs a count the handful of chance hashes of a row cannot reach.
+struct NearPlan {
+    bool use = false, pair = false;
+    uint32_t row_first, row_step, row_block, units_per_block, n_units;
+    double min_jorc = 0.0;
+};
+NearPlan plan_near(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool dense_mode)
+{
+    NearPlan np;
+    if (!ctx->sw_dist_near || dense_mode || !idx->ref_sets || !idx->d_selfrange || !idx->d_self_split || !idx->n_ref || o->kmer_size <= 0 ||
+        o->row_block < 0 || !(o->max_dist > 0.0))
+        return np;
+    const int metric = o->metric != 0;
+    const double t = exp(-(double)o->kmer_size * o->max_dist);
+    np.min_jorc = (metric ? t : t / (2.0 - t)) * (1.0 - 1e-6);
+    // the smallest count a reportable pair of the SMALLEST sketch needs: below ~16 the chance hashes of a row reach it too
+    // often and every unit would fall back (a loose -D: rk_dist_kernel alone is the better plan)
+    if (floor(np.min_jorc * (double)idx->min_ref_size) < (double)ctx->sw_dist_near_min) return np;
+    np.row_step = o->row_step ? o->row_step : 1;
+    np.row_first = o->row_first;
+    np.row_block = o->row_block > 0 ? (uint32_t)o->row_block : 1;
+    if (np.row_step == 1 && np.row_first == 0) np.row_block = kRowsPerXcdChunk;  // all rows: every block is this shard's
+    np.pair = np.row_block % 2 == 0 && ctx->sw_dist_pair != 2;
+    np.units_per_block = np.row_block / (np.pair ? 2 : 1);
+    const uint64_t n_blocks = ((uint64_t)idx->n_ref + np.row_block - 1) / np.row_block;
+    const uint64_t my_blocks = np.row_first < n_blocks ? (n_blocks - np.row_first + np.row_step - 1) / np.row_step : 0;
+    np.n_units = (uint32_t)std::min<uint64_t>(my_blocks * np.units_per_block, 0xFFFFFFF0u);
+    np.use = true;
+    return np;
+}
+
+// the fallback list of an index (allocated and zeroed once)
+int ensure_fallback(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(idx->lazy_mu);
+    if (idx->d_fb) return RK_OK;
+    DevBuf<uint32_t> fb(ctx);
+    if (fb.alloc((size_t)idx->n_ref + 8) != hipSuccess) return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate the fallback list");
+    RK_HIP(ctx, hipMemsetAsync(fb.p, 0, 16, stream));
+    RK_HIP(ctx, hipStreamSynchronize(stream));  // once per index: a later call may come on another stream
+    idx->d_fb = fb.release();
+    return RK_OK;
+}
+
 int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool dense_mode, rk_hit *hits_dev, uint64_t cap,
                 unsigned long long *n_hits_dev, hipStream_t stream)
 {
+    const NearPlan np = plan_near(ctx, idx, o, dense_mode);
+    if (np.use) {
+        int rc = ensure_fallback(ctx, const_cast<rk_index *>(idx), stream);
+        if (rc) return rc;
+        if (np.n_units) {
+            NearArgs a;
+            a.ranges = idx->d_selfrange;
+            a.range_off = idx->d_self_off;
+            a.range_split = idx->d_self_split;
+            a.size_off = idx->d_src_off;
+            a.postings = idx->d_postings;
+            a.ref_sizes = idx->d_sizes;
+            a.orig = idx->relabeled ? idx->d_orig : nullptr;
+            a.n_ref = idx->n_ref;
+            a.row_first = np.row_first;
+            a.row_step = np.row_step;
+            a.row_block = np.row_block;
+            a.units_per_block = np.units_per_block;
+            a.n_units = np.n_units;
+            a.metric = o->metric != 0;
+            a.kmer_size = o->kmer_size;
+            a.max_dist = o->max_dist;
+            a.min_jorc = np.min_jorc;
+            a.min_ref_size = (uint32_t)std::min<uint64_t>(idx->min_ref_size, 0xFFFFFFFFu);
+            a.hits = hits_dev;
+            a.cap = cap;
+            a.n_hits = n_hits_dev;
+            a.fb_count = idx->d_fb;
+            a.fb_rows = idx->d_fb + 4;
+            a.stage_hits = kNearStage;
+            const void *kern = np.pair ? (const void *)rk_near_kernel<true> : (const void *)rk_near_kernel<false>;
+            const int per_cu = std::max(1, rk_occupancy(ctx, kern, (int)kNearThreads, 0));
+            const uint32_t grid = std::min<uint32_t>(np.n_units, (uint32_t)per_cu * (uint32_t)std::max(1, ctx->num_cu));
+            if (np.pair) hipLaunchKernelGGL(rk_near_kernel<true>, dim3(grid), dim3(kNearThreads), 0, stream, a);
+            else hipLaunchKernelGGL(rk_near_kernel<false>, dim3(grid), dim3(kNearThreads), 0, stream, a);
+            RK_HIP(ctx, hipGetLastError());
+        }
+        // the rows whose far cells could be reportable (usually none): full counter rows, single rows, all columns
+        Plan fp;
+        rk_dist_opts all = *o;
+        all.row_first = 0;
+        all.row_step = 1;
+        rc = make_plan(ctx, idx, idx->n_ref, idx->max_src_size, &all, false, true, idx->n_ref, &fp, false);
+        if (rc) return rc;
+        return launch_dist(ctx, idx, idx->d_selfrange, idx->d_self_off, idx->d_src_off, idx->n_ref, o, fp, hits_dev, cap, n_hits_dev,
+                           nullptr, stream, idx->d_fb);
+    }
     std::vector<Plan> bands;
     int rc = plan_bands(ctx, idx, o, dense_mode, &bands);
     for (size_t b = 0; !rc && b < bands.size(); b++)
@@ -1111,6 +1227,11 @@ int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *que
 {
     if (!ctx || !idx || !opts || !buf || !cap) return RK_ERR_ARG;
     if (queries) return rk_distq_kernel_name(ctx, idx, queries, buf, cap);
+    const NearPlan np = plan_near(ctx, idx, opts, rk_dense_mode(opts));
+    if (np.use) {
+        snprintf(buf, cap, "rk_near_kernel<%s>", np.pair ? "true" : "false");
+        return RK_OK;
+    }
     std::vector<Plan> bands;  // several bands: the variant of the first (widest rows)
     int rc = plan_bands(ctx, idx, opts, rk_dense_mode(opts), &bands);
     if (rc) return rc;

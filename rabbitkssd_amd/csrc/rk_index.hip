@@ -22,7 +22,9 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 
 #include "rk_internal.h"
 
@@ -649,6 +651,7 @@ void rk_index_free(rk_index *idx)
     rk_pool_free(ctx, idx->d_self_split);
     rk_pool_free(ctx, idx->d_src_off);
     rk_pool_free(ctx, idx->d_orig);
+    rk_pool_free(ctx, idx->d_fb);
     delete idx;
 }
 
@@ -1105,6 +1108,30 @@ int rk_index_export(const rk_index *idx, uint32_t *postings, uint32_t *counts)
 
 // ---- single-blob form for the RCCL broadcast ------------------------------------------
 namespace {
+// a received blob is only trusted after its payload was checked against its own header: posting ids, posting offsets, the
+// genome order and every slice record must point inside the index (a corrupt record would index LDS out of range)
+__global__ void k_validate_blob(const uint32_t *postings, uint64_t H, const uint32_t *upos, uint64_t U, const uint32_t *orig,
+                                const uint2 *selfrange, uint64_t n_self, const uint64_t *self_off, const uint64_t *self_split,
+                                uint32_t n_ref, uint32_t *bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = true;
+    if (i < H) ok = ok && postings[i] < n_ref;
+    if (i < U) ok = ok && upos[i] < upos[i + 1] && upos[i + 1] <= H;
+    if (orig && i < n_ref) ok = ok && orig[i] < n_ref;
+    if (selfrange) {
+        if (i < n_self) {
+            const uint2 r = selfrange[i];
+            if (r.x >> 31) ok = ok && r.y != 0 && (uint64_t)(r.x & 0x7FFFFFFFu) + (31 - __clz((int)r.y)) < n_ref;
+            else ok = ok && r.x < r.y && r.y <= H;
+        }
+        if (i < n_ref) ok = ok && self_off[i] <= self_split[i] && self_split[i] <= self_off[i + 1] && self_off[i + 1] <= n_self;
+    }
+    if (!ok) *bad = 1;
+}
+}  // namespace
+
+namespace {
 struct BlobHeader {
     uint64_t magic, bytes;
     uint64_t H, U, max_src_size, max_ref_size, min_ref_size, n_self;
@@ -1251,7 +1278,20 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
         RK_HIP(ctx, hipMemcpyAsync(idx->d_src_off, b + h.off_src, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(idx->d_self_split, b + h.off_split, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
     }
-    RK_HIP(ctx, hipStreamSynchronize(st));
+    {
+        DevBuf<uint32_t> bad(ctx);
+        RK_HIP(ctx, bad.alloc(1));
+        RK_HIP(ctx, hipMemsetAsync(bad.p, 0, 4, st));
+        const uint64_t span = std::max<uint64_t>(std::max<uint64_t>(idx->H, idx->n_self), (uint64_t)idx->n_ref + 1);
+        if (span)
+            hipLaunchKernelGGL(k_validate_blob, dim3(blocks_for(span)), dim3(kThreads), 0, st, idx->d_postings, idx->H, idx->d_upos, idx->U,
+                               idx->relabeled ? idx->d_orig : nullptr, idx->d_selfrange, idx->n_self, idx->d_self_off, idx->d_self_split,
+                               idx->n_ref, bad.p);
+        RK_HIP(ctx, hipGetLastError());
+        uint32_t b = 0;
+        RK_TRY(rk_read_back(ctx, &b, bad.p, 4, st));  // synchronises: the copies above are complete
+        if (b) return rk_fail(ctx, RK_ERR_ARG, "index blob payload is inconsistent with its header (corrupt or foreign blob)");
+    }
     guard.p = nullptr;
     *out = idx;
     return RK_OK;
@@ -1260,6 +1300,7 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
 }  // extern "C"
 
 // ---- one-to-all replication inside one process (the host tool's --gpus N) -----------------------------------
+static constexpr int kPeerCopyTimeoutS = 120;
 extern "C" int rk_index_broadcast(const rk_index *src, rk_ctx *const *dst, uint32_t n_dst, rk_index **out)
 {
     if (!src || (n_dst && (!dst || !out))) return RK_ERR_ARG;
@@ -1317,15 +1358,28 @@ extern "C" int rk_index_broadcast(const rk_index *src, rk_ctx *const *dst, uint3
             return rk_fail(d, RK_ERR_HIP, "index copy to device %d failed: %s", d->device, hipGetErrorString(e));
         }
     }
+    bool stuck = false;  // a copy that never completed: its blocks are leaked rather than waited for
     for (uint32_t i = 0; i < n_dst && !rc; i++) {
         rk_ctx *d = dst[i];
-        if (hipSetDevice(d->device) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess)
-            rc = rk_fail(d, RK_ERR_HIP, "index copy to device %d did not complete", d->device);
+        // bounded wait: a peer copy that never completes (a link that is down) must end in an error, not in a hang
+        hipError_t qe = hipSetDevice(d->device);
+        const auto t_start = std::chrono::steady_clock::now();
+        while (qe == hipSuccess && (qe = hipStreamQuery(d->stream)) == hipErrorNotReady) {
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(kPeerCopyTimeoutS)) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        if (qe == hipErrorNotReady) stuck = true;
+        if (qe == hipErrorNotReady)
+            rc = rk_fail(d, RK_ERR_HIP, "index copy of %llu bytes from device %d to device %d did not complete within %d s", (unsigned long long)bytes,
+                         sctx->device, d->device, kPeerCopyTimeoutS);
+        else if (qe != hipSuccess)
+            rc = rk_fail(d, RK_ERR_HIP, "index copy to device %d failed: %s", d->device, hipGetErrorString(qe));
         else
             rc = rk_index_unpack_dev(d, peer[i], bytes, d->stream, &out[i]);
     }
     if (rc) {
-        abandon(n_dst);  // waits for the copies of the peers behind the failing one
+        if (!stuck) abandon(n_dst);  // waits for the copies of the peers behind the failing one
+        else (void)hipSetDevice(sctx->device);
         for (uint32_t i = 0; i < n_dst; i++) {
             rk_index_free(out[i]);
             out[i] = nullptr;

@@ -34,15 +34,30 @@ def weak_scaling_genomes(base_genomes, world):
 
 def broadcast_blob(blob, src, device, dist):
     """Broadcast a 1-D uint8 torch tensor from `src` (other ranks pass None): size first,
-    then the payload in one collective.  Returns the tensor on every rank."""
+    then the payload in one collective.  Returns the tensor on every rank.  A collective that
+    fails or times out (the process group's timeout: see init_timeout) is reported with the rank
+    and the byte count instead of a bare backend error."""
     import torch
     rank = dist.get_rank()
     size = torch.tensor([blob.numel() if rank == src else 0], dtype=torch.int64, device=device)
-    dist.broadcast(size, src)
-    if rank != src:
-        blob = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
-    dist.broadcast(blob, src)
+    try:
+        dist.broadcast(size, src)
+        if rank != src:
+            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
+        dist.broadcast(blob, src)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)   # RCCL errors surface at the synchronisation
+    except Exception as e:  # noqa: BLE001 -- every backend raises its own type
+        raise RuntimeError("rank %d/%d: index broadcast from rank %d (%d bytes) failed: %s"
+                           % (rank, dist.get_world_size(), src, int(size.item()), e)) from e
     return blob
+
+
+def init_timeout():
+    """timeout for torch.distributed.init_process_group: a rank that never arrives (a dead GPU, a missing xGMI link) must end
+    the job with an error after two minutes, not hang it"""
+    import datetime
+    return datetime.timedelta(seconds=120)
 
 
 def gather_hits(local_hits, dist, dst=0):

@@ -272,13 +272,50 @@ def test_index_without_renumbering_gives_the_same_results(monkeypatch):
     c1.close()
 
 
+@pytest.mark.parametrize("strains,n,m,D,metric", [(10, 2000, 400, 0.05, 0), (70, 1500, 300, 0.05, 0), (25, 1201, 500, 0.08, 1),
+                                                  (10, 900, 300, 0.02, 0)])
+def test_near_window_self_join_and_its_fallback(monkeypatch, strains, n, m, D, metric):
+    # rk_near_kernel keeps no counter rows: a unit's members inside the 32 columns behind its first row are counted in
+    # registers, and a unit whose members BEYOND the window could add up to a reportable pair goes to the fallback list
+    # (rk_dist_kernel in list mode).  Clades of 10: nothing falls back.  Clades of 25 / 70: the relatives of a row reach
+    # beyond the window -- most units fall back.  Results must be the oracle's either way, also for row shards, odd
+    # collection sizes, the containment metric and single rows (RK_DIST_PAIR=2).
+    names, h, off = synth.clade_sketches(n, m, 26, strains_per_clade=strains, seed=100 + strains)
+    order = synth.genome_order(n, "shuffled", seed=strains)
+    names, h, off = synth.permute_genomes(names, h, off, order)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=4)
+    assert len(want) > n
+    c = capi.Context(0)
+    monkeypatch.setenv("RK_DIST_PAIR", "2")
+    c1 = capi.Context(0)
+    monkeypatch.delenv("RK_DIST_PAIR")
+    for cc, pair in ((c, "true"), (c1, "false")):
+        idx = cc.index_build(cc.sketches_from_host(h, off), 26)
+        assert cc.dist_kernel_name(idx, None, 1, metric, 20, D) == "rk_near_kernel<%s>" % pair
+        assert_hits_equal(cc.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+        assert_hits_equal(cc.dist_rows(idx, None, 1, metric, 20, D)[0], want)      # again: the fallback list was reset
+        parts = [cc.dist_rows(idx, None, 1, metric, 20, D, row_first=r, row_step=3, row_block=16)[0] for r in range(3)]
+        for r, p in enumerate(parts):
+            assert np.all(idx.shard_of(p, 3, 16) == r)
+        merged = np.concatenate(parts)
+        assert_hits_equal(merged[np.lexsort((merged["col"], merged["row"]))], want)
+    c.close()
+    c1.close()
+
+
 def test_pair_kernel_equals_single_row_kernel(ctx, monkeypatch):
     # the same self join through the pair kernel (default) and the single-row kernel (RK_DIST_PAIR=2; the developer
     # switches are read when a context is created)
     names, h, off = synth.clade_sketches(777, 300, 24, seed=23)
+    monkeypatch.setenv("RK_DIST_NEAR", "0")     # the kernels with full counter rows (the near-window kernel's fallback)
+    ctx0 = capi.Context(0)
     monkeypatch.setenv("RK_DIST_PAIR", "2")
     ctx1 = capi.Context(0)
     monkeypatch.delenv("RK_DIST_PAIR")
+    monkeypatch.delenv("RK_DIST_NEAR")
+    ctx = ctx0
     idx = ctx.index_build(ctx.sketches_from_host(h, off), 24)
     idx1 = ctx1.index_build(ctx1.sketches_from_host(h, off), 24)
     assert ", 2, " in ctx.dist_kernel_name(idx, None, 1, 0, 20, 0.05) and ", 1, " in ctx1.dist_kernel_name(idx1, None, 1, 0, 20, 0.05)
@@ -300,13 +337,14 @@ def test_self_join_in_bands(monkeypatch, n, lds_kb, world):
     row (tiled -> single rows -> row pairs as the rows get shorter).  Developer switches bring the band boundaries
     down to test sizes; the result must equal the oracle's and the one-launch path's, also per shard."""
     names, h, off = synth.clade_sketches(n, 40, 24, seed=37)
+    monkeypatch.setenv("RK_DIST_NEAR", "0")     # the band planner belongs to the kernel with full counter rows
     monkeypatch.setenv("RK_DIST_BAND_MIN_ROWS", "256")
     if lds_kb:
         monkeypatch.setenv("RK_DIST_LDS_KB", str(lds_kb))
     banded = capi.Context(0)
     monkeypatch.setenv("RK_DIST_BANDS", "0")
     plain = capi.Context(0)
-    for v in ("RK_DIST_BAND_MIN_ROWS", "RK_DIST_BANDS"):
+    for v in ("RK_DIST_BAND_MIN_ROWS", "RK_DIST_BANDS", "RK_DIST_NEAR"):
         monkeypatch.delenv(v)
     ib = banded.index_build(banded.sketches_from_host(h, off), 24)
     ip = plain.index_build(plain.sketches_from_host(h, off), 24)

@@ -21,11 +21,14 @@ def _check(mine, want):
 
 PLANS = [
     {},                                                              # as shipped
-    {"RK_DIST_BAND_MIN_ROWS": "64"},                                 # bands wherever the variant changes
-    {"RK_DIST_BAND_MIN_ROWS": "64", "RK_DIST_LDS_KB": "16"},         # tiled first band, then single rows
-    {"RK_DIST_BAND_MIN_ROWS": "32", "RK_DIST_LDS_KB": "20", "RK_DIST_CAND_CAP": "16"},   # cell lists overflow
-    {"RK_DIST_BANDS": "0", "RK_DIST_PAIR": "2"},                     # one launch, no pairs
-    {"RK_DIST_THREADS": "1024", "RK_DIST_CAND_CAP": "8"},            # batched evaluation with tiny lists
+    # (RK_DIST_NEAR=0: the kernel with full counter rows, which is also the near-window kernel's fallback)
+    {"RK_DIST_NEAR": "0", "RK_DIST_BAND_MIN_ROWS": "64"},                                 # bands wherever the variant changes
+    {"RK_DIST_NEAR": "0", "RK_DIST_BAND_MIN_ROWS": "64", "RK_DIST_LDS_KB": "16"},         # tiled first band, then single rows
+    {"RK_DIST_NEAR": "0", "RK_DIST_BAND_MIN_ROWS": "32", "RK_DIST_LDS_KB": "20", "RK_DIST_CAND_CAP": "16"},   # cell lists overflow
+    {"RK_DIST_NEAR": "0", "RK_DIST_BANDS": "0", "RK_DIST_PAIR": "2"},                     # one launch, no pairs
+    {"RK_DIST_NEAR": "0", "RK_DIST_THREADS": "1024", "RK_DIST_CAND_CAP": "8"},            # batched evaluation with tiny lists
+    {"RK_DIST_NEAR_MIN": "1", "RK_DIST_LDS_KB": "16"},               # near-window kernel (also for tiny sketches), its fallback with tiled rows
+    {"RK_DIST_NEAR_MIN": "1", "RK_DIST_PAIR": "2", "RK_DIST_CAND_CAP": "8"},   # near-window kernel on single rows
 ]
 
 

@@ -57,7 +57,7 @@ def main(tag, traffic_only=False):
     carries the counter traffic measured in the same call"""
     d = None
     if not traffic_only:
-        d = json.loads(open(os.path.join(OUT, "bench_r2.json")).read().strip().split("\n")[-1])
+        d = json.loads(open(os.path.join(OUT, "bench_round.json")).read().strip().split("\n")[-1])
         json.dump(d, open(os.path.join(PROF, tag + "_bench.json"), "w"))
         f = glob.glob(os.path.join(OUT, "prof_final", "**", "*kernel_stats.csv"), recursive=True)[0]
         with open(os.path.join(PROF, tag + "_bench_kernel_stats.csv"), "w") as o:
@@ -66,13 +66,33 @@ def main(tag, traffic_only=False):
             for r in csv.DictReader(open(f)):
                 o.write('"%s",%s,%s,%s,%s,%s,%s\n' % (short_name(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                                                       r["Percentage"], r["MinNs"], r["MaxNs"]))
+        idx_txt = os.path.join(OUT, "index_kernels.txt")
+        if os.path.exists(idx_txt):
+            with open(os.path.join(PROF, tag + "_index_build_kernels.txt"), "w") as o:
+                o.write("# rocprofv3 --kernel-trace --stats -- python3 tools/prof_driver.py index 10000 6 (MI355X, tools/measure_round.sh): "
+                        "the kernels of rk_index_build at 10,000 genomes, and its wall time per call\n")
+                o.write(open(idx_txt).read())
+    # FETCH_SIZE calibration: a streaming read of 1 GiB at 4 / 8 / 16 bytes per lane (k_calib_read)
+    calib = {}
+    for w in (4, 8, 16):
+        v = values(summary(sorted(glob.glob(os.path.join(OUT, "pmcC%d_*" % w)))))
+        f = v.get(("k_calib_read", "FETCH_SIZE"))
+        if f:
+            calib[w] = (1024 << 20) / (f * 1024)
+    if calib:
+        with open(os.path.join(PROF, tag + "_fetch_calibration.txt"), "w") as o:
+            o.write("# FETCH_SIZE against a known byte count: k_calib_read streams 1 GiB at W bytes per lane (tools/prof_driver.py calib); "
+                    "factor = true bytes / (FETCH_SIZE x 1 KiB)\n")
+            for w, fct in sorted(calib.items()):
+                o.write("%2d B/lane: factor %.3f\n" % (w, fct))
     groups = {"dist": sorted(glob.glob(os.path.join(OUT, "pmcD_*"))),
+              "index": sorted(glob.glob(os.path.join(OUT, "pmcI_*"))),
               "rq": sorted(glob.glob(os.path.join(OUT, "pmcQ_*"))),
               "sketch": sorted(glob.glob(os.path.join(OUT, "pmcSk_*")) + glob.glob(os.path.join(OUT, "pmcS_*"))),
               "sketch_img0": sorted(glob.glob(os.path.join(OUT, "pmcS0_*")))}
     with open(os.path.join(PROF, tag + "_pmc_summary.csv"), "w") as o:
         o.write("# rocprofv3 --pmc <group> --kernel-include-regex <kernel> --kernel-trace -- python3 tools/prof_driver.py "
-                "{dist 10000 4 | dist_rq_dev 100000 1000 3 | sketch 128 5000000}; one group per pass (tools/pmc_pass.sh, "
+                "{dist 10000 4 | dist_rq_dev 100000 1000 3 | sketch 128 5000000 | index 10000 3}; one group per pass (tools/pmc_pass.sh, "
                 "groups in tools/pmc_groups_*.txt); mean over launches (tools/pmc_summary.py).  Section sketch_img0 = the "
                 "144 KiB LDS image (RK_SKETCH_IMG=0, one workgroup per CU) for comparison with the default 64 KiB image\n"
                 "Section,Kernel,Counter,Launches,MeanValue\n")
@@ -80,16 +100,17 @@ def main(tag, traffic_only=False):
             for line in summary(dirs).splitlines():
                 o.write(sec + "," + line + "\n")
     # counter-measured HBM bytes per launch, keyed by the exact kernel variant (bench.py refuses a mismatch)
-    def traffic(dirs, base, fname, workload, wide_stream):
+    def traffic(dirs, base, fname, workload, width):
         v = values(summary(dirs))
         fetch, write = v.get((base, "FETCH_SIZE")), v.get((base, "WRITE_SIZE"))
         if fetch is None or write is None:
             print("no FETCH_SIZE/WRITE_SIZE for", base)
             return None
         miss = v.get((base, "TCC_MISS_sum"), 0.0)
-        # gfx950: FETCH_SIZE reports half the bytes of a wide coalesced 16 B/lane stream (MI355X_MICROARCH.md, HBM);
-        # gathers of 4-8 B/lane leave L2 as 64-B requests and need no correction (checked against TCC_MISS x 64 B)
-        factor = 2.0 if wide_stream else 1.0
+        # gfx950: FETCH_SIZE reports half the bytes of a wide coalesced 16 B/lane stream (MI355X_MICROARCH.md, HBM); other
+        # widths are calibrated in this very run (k_calib_read above); width 0 = scattered 4-8 B gathers, which leave L2 as
+        # 64-B requests and need no correction (cross-check: TCC_MISS x 64 B)
+        factor = round(calib.get(width, 2.0 if width == 16 else 1.0), 2) if width else 1.0
         hbm = int(round((fetch * factor + write) * 1024))
         json.dump({"kernel": variant_of(dirs, base), "workload": workload, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
                    "SQ_ACTIVE_INST_VALU": v.get((base, "SQ_ACTIVE_INST_VALU")), "SQ_INSTS_VALU": v.get((base, "SQ_INSTS_VALU")),
@@ -99,11 +120,11 @@ def main(tag, traffic_only=False):
                    "passes": "FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, see profiles/%s_pmc_summary.csv" % tag},
                   open(os.path.join(PROF, fname), "w"), indent=1)
         return hbm
-    # the self join now streams only its 8-byte slice records (compact slices carry their posting list): a coalesced
-    # stream, FETCH_SIZE x 2 like every wide read on gfx950 (check: ~5.4 M uncovered slices x 8 B = 43 MB)
-    t_d = traffic(groups["dist"], "rk_dist_kernel", "pmc_traffic.json", "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X", True)
-    t_q = traffic(groups["rq"], "rk_distq_kernel", "pmc_traffic_rq.json", "dist 100,000 refs x 1,000 queries (tools/prof_driver.py dist_rq_dev), MI355X", False)
-    t_s = traffic(groups["sketch"], "rk_sketch_kernel", "pmc_traffic_sketch.json", "sketch 128 x 5 Mb (tools/prof_driver.py sketch 128 5000000), MI355X", True)
+    # the self join streams its 8-byte slice records (compact slices carry their posting list): a coalesced 8 B/lane
+    # stream, corrected by the factor calibrated above (check: ~5.4 M uncovered slices x 8 B = 43 MB)
+    t_d = traffic(groups["dist"], "rk_dist_kernel", "pmc_traffic.json", "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X", 8)
+    t_q = traffic(groups["rq"], "rk_distq_kernel", "pmc_traffic_rq.json", "dist 100,000 refs x 1,000 queries (tools/prof_driver.py dist_rq_dev), MI355X", 0)
+    t_s = traffic(groups["sketch"], "rk_sketch_kernel", "pmc_traffic_sketch.json", "sketch 128 x 5 Mb (tools/prof_driver.py sketch 128 5000000), MI355X", 16)
     print("traffic dist %s rq %s sketch %s B/launch" % (t_d, t_q, t_s))
     if d:
         print("value %.4g %s, %.4f ms/step, contract frac %.3f, hbm frac %s" % (
@@ -112,4 +133,4 @@ def main(tag, traffic_only=False):
 
 if __name__ == "__main__":
     args = [x for x in sys.argv[1:] if not x.startswith("--")]
-    main(args[0] if args else "r02", "--traffic-only" in sys.argv)
+    main(args[0] if args else "r03", "--traffic-only" in sys.argv)
