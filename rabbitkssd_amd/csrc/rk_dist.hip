@@ -76,6 +76,7 @@ struct DistArgs {
     // finish resets *unit_count and *unit_done for the next launch
     const uint32_t *unit_list;
     uint32_t *unit_count, *unit_done;
+    uint32_t *unit_seen_host;   // page-locked host word: the list length this launch found (hint for the next launch's grid)
 };
 
 #ifdef RK_DIST_PROFILE
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
         if (a.unit_list && threadIdx.x == 0 && atomicAdd(a.unit_done, 1u) == gridDim.x * gridDim.y - 1) {
             *a.unit_count = 0;
             *a.unit_done = 0;
+            if (a.unit_seen_host) __hip_atomic_store(a.unit_seen_host, n_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     };
     if (a.unit_list && n_units == 0) {   // the usual case of the fallback launch: nothing to do, before any LDS is touched
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
             // of one row name the same few relatives, so every lane starts at a different bit (mask rotated by lane & 7):
             // an LDS atomic instruction then spreads over ~8 columns instead of queueing 64 lanes on one counter.
             const bool cpt = (raw.x >> 31) != 0;
-            const uint2 rg = cpt ? make_uint2(0, 0) : raw;      // posting ranges for the gather path below
+            const uint2 rg = cpt ? make_uint2(0, 0) : make_uint2(raw.x, raw.y & 0x7FFFFFFFu);   // posting ranges for the gather path below (bit 31 of y: rk_near_kernel's near flag)
             if (__ballot(cpt)) {  // uniform
                 const uint32_t first = raw.x & 0x7FFFFFFFu;
                 // pair mode: a first-row slice is shared with the partner iff its first genome IS the partner, who then
@@ -924,6 +926,7 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
     a.unit_list = fb ? fb + 4 : nullptr;   // fb: [0] count, [1] done, [4..] rows
     a.unit_count = fb;
     a.unit_done = fb ? fb + 1 : nullptr;
+    a.unit_seen_host = fb ? idx->h_fb_seen : nullptr;
     a.ranges = ranges;
     a.range_off = range_off;
     a.range_split = p.mode == kSelfPair ? idx->d_self_split : nullptr;
@@ -997,7 +1000,9 @@ int launch_dist(rk_ctx *ctx, const rk_index *idx, const uint2 *ranges, const uin
         const uint32_t resident = ((uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, ctx->num_cu) + 7) / 8 * 8;
         if (gx > resident || fb) {  // otherwise every unit gets its own workgroup anyway (list mode: the count is on the device)
             a.persist = 1;
-            gx = fb ? std::min<uint32_t>(resident, 512) : resident;
+            // list mode: the whole chip when the previous launch over this index found rows in the list, else a token grid (the
+            // list is empty as a rule; any grid walks any list)
+            gx = fb ? (idx->h_fb_seen && *(volatile uint32_t *)idx->h_fb_seen == 0 ? 64u : std::min<uint32_t>(resident, 512)) : resident;
         }
     }
     hipLaunchKernelGGL(kern, dim3(gx, p.n_tiles), dim3(p.threads), p.lds_bytes, stream, a);
@@ -1101,6 +1106,8 @@ int ensure_fallback(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
     if (fb.alloc((size_t)idx->n_ref + 8) != hipSuccess) return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate the fallback list");
     RK_HIP(ctx, hipMemsetAsync(fb.p, 0, 16, stream));
     RK_HIP(ctx, hipStreamSynchronize(stream));  // once per index: a later call may come on another stream
+    if (hipHostMalloc((void **)&idx->h_fb_seen, 64, hipHostMallocDefault) == hipSuccess) *idx->h_fb_seen = 0xFFFFFFFFu;  // unknown: first launch at full size
+    else { (void)hipGetLastError(); idx->h_fb_seen = nullptr; }
     idx->d_fb = fb.release();
     return RK_OK;
 }
@@ -1138,11 +1145,18 @@ int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool de
             a.fb_count = idx->d_fb;
             a.fb_rows = idx->d_fb + 4;
             a.stage_hits = kNearStage;
-            const void *kern = np.pair ? (const void *)rk_near_kernel<true> : (const void *)rk_near_kernel<false>;
-            const int per_cu = std::max(1, rk_occupancy(ctx, kern, (int)kNearThreads, 0));
-            const uint32_t grid = std::min<uint32_t>(np.n_units, (uint32_t)per_cu * (uint32_t)std::max(1, ctx->num_cu));
-            if (np.pair) hipLaunchKernelGGL(rk_near_kernel<true>, dim3(grid), dim3(kNearThreads), 0, stream, a);
-            else hipLaunchKernelGGL(rk_near_kernel<false>, dim3(grid), dim3(kNearThreads), 0, stream, a);
+            a.debug = getenv("RK_NEAR_DEBUG") ? atoi(getenv("RK_NEAR_DEBUG")) : 0;
+            // waves per unit: one when the launch fills the chip's wave slots at least half, else 2 or 4 share a unit's steps
+            const int per_cu = std::max(1, rk_occupancy(ctx, (const void *)rk_near_kernel<true, 1>, (int)kNearThreads, 0));
+            const uint32_t wave_slots = (uint32_t)per_cu * (uint32_t)std::max(1, ctx->num_cu) * (kNearThreads / 64);
+            int uw = np.n_units >= wave_slots / 2 ? 1 : (np.n_units >= wave_slots / 4 ? 2 : 4);
+            if (ctx->sw_dist_near_uw == 1 || ctx->sw_dist_near_uw == 2 || ctx->sw_dist_near_uw == 4) uw = ctx->sw_dist_near_uw;
+            const uint32_t slots = (kNearThreads / 64) / (uint32_t)uw;
+            const uint32_t grid = std::min<uint32_t>((np.n_units + slots - 1) / slots, (uint32_t)per_cu * (uint32_t)std::max(1, ctx->num_cu));
+#define RK_NEAR(P, U) hipLaunchKernelGGL((rk_near_kernel<P, U>), dim3(grid), dim3(kNearThreads), 0, stream, a)
+            if (np.pair) { if (uw == 1) RK_NEAR(true, 1); else if (uw == 2) RK_NEAR(true, 2); else RK_NEAR(true, 4); }
+            else { if (uw == 1) RK_NEAR(false, 1); else if (uw == 2) RK_NEAR(false, 2); else RK_NEAR(false, 4); }
+#undef RK_NEAR
             RK_HIP(ctx, hipGetLastError());
         }
         // the rows whose far cells could be reportable (usually none): full counter rows, single rows, all columns

@@ -219,10 +219,12 @@ __global__ void k_row_scan(const uint32_t *n_open, const uint32_t *n_cov, uint32
 // shared by a handful of neighbouring strains -- is stored COMPACT: (bit 31 | first genome, bitmask of the genomes
 // first+0 .. first+31; bit 0 is always set).  The distance kernel then needs no posting load for it at all: the
 // 8-byte slice record IS the posting list.  Other slices stay posting ranges (x, y), x < 2^31.
-__device__ inline uint2 compact_slice(uint2 r, const uint32_t *postings)
+// A slice that stays a posting range carries the NEAR flag in bit 31 of y: its first genome lies within 32 ids of the
+// element's own genome g (only then can it have members inside the window of rk_near_kernel).
+__device__ inline uint2 compact_slice(uint2 r, const uint32_t *postings, uint32_t g, bool compact)
 {
     const uint32_t first = postings[r.x], last = postings[r.y - 1];
-    if (r.y > 0x7FFFFFFFu || (first >> 31) || last - first > 31u) return r;
+    if (!compact || last - first > 31u) return make_uint2(r.x, r.y | (first - g <= 32u ? 0x80000000u : 0u));
     uint32_t mask = 1;
     for (uint32_t k = r.x + 1; k < r.y; k++) mask |= 1u << (postings[k] - first);
     return make_uint2(0x80000000u | first, mask);
@@ -246,7 +248,7 @@ __global__ void k_row_place(const uint64_t *off, uint32_t n_genomes, const uint2
         const uint2 raw = e < e1 ? self_raw[e] : make_uint2(0, 0);
         const uint8_t c = slice_class(raw);
         uint2 r = slice_range(raw);
-        if (c != kEmpty && compact) r = compact_slice(r, postings);
+        if (c != kEmpty) r = compact_slice(r, postings, g, compact);
         const unsigned long long mo = __ballot(c == kOpen), mc = __ballot(c == kCovered);
         if (c == kOpen) out[at_open + __popcll(mo & lt)] = r;
         if (c == kCovered) out[at_cov + __popcll(mc & lt)] = r;
@@ -652,6 +654,7 @@ void rk_index_free(rk_index *idx)
     rk_pool_free(ctx, idx->d_src_off);
     rk_pool_free(ctx, idx->d_orig);
     rk_pool_free(ctx, idx->d_fb);
+    if (idx->h_fb_seen) (void)hipHostFree(idx->h_fb_seen);
     delete idx;
 }
 
@@ -826,7 +829,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     while ((1ULL << gb) < N) gb++;
     while ((1ULL << rb) < s->max_size) rb++;
     const int low_bits = hash_bits - B;
-    const bool fast_ok = ctx->sw_index_fast && H && !idx->wide && s->is_set && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 &&
+    const bool fast_ok = ctx->sw_index_fast && H && H < (1ULL << 30) && !idx->wide && s->is_set && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 &&
                          low_bits + gb + rb <= 63 && gb <= 31 && rb <= 31;
     if (fast_ok) {
         FastArgs fa;
@@ -1123,7 +1126,7 @@ __global__ void k_validate_blob(const uint32_t *postings, uint64_t H, const uint
         if (i < n_self) {
             const uint2 r = selfrange[i];
             if (r.x >> 31) ok = ok && r.y != 0 && (uint64_t)(r.x & 0x7FFFFFFFu) + (31 - __clz((int)r.y)) < n_ref;
-            else ok = ok && r.x < r.y && r.y <= H;
+            else ok = ok && r.x < (r.y & 0x7FFFFFFFu) && (r.y & 0x7FFFFFFFu) <= H;
         }
         if (i < n_ref) ok = ok && self_off[i] <= self_split[i] && self_split[i] <= self_off[i + 1] && self_off[i + 1] <= n_self;
     }

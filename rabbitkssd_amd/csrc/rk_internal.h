@@ -45,6 +45,7 @@ struct rk_ctx {
     int sw_dist_bands = 1;  // RK_DIST_BANDS=0: the self join in one launch, every row as wide as the whole collection
     int sw_dist_band_min_rows = 3072;  // RK_DIST_BAND_MIN_ROWS: no band with fewer rows of the shard than this (tests: small collections in several bands)
     int sw_dist_near = 1;   // RK_DIST_NEAR=0: the self join always with full counter rows (rk_dist_kernel)
+    int sw_dist_near_uw = 0;    // RK_DIST_NEAR_UW=1|2|4: waves that share a unit of the near-window kernel (default: by the launch's size)
     int sw_dist_near_min = 16;  // RK_DIST_NEAR_MIN: the near-window kernel is used when a reportable pair of the smallest sketch needs at least this count
     int sw_dist_debug = 0;  // RK_DIST_DEBUG=1: the bands of every self join on stderr
     int sw_dist_lds_kb = 0;  // RK_DIST_LDS_KB: plan as if a CU had this much LDS (tests: tiled bands at small sizes)
@@ -169,6 +170,8 @@ struct rk_index {
     bool built_fast = false;         // built by the bucket-sort path (rk_index_fast.inc)
     uint32_t *d_fb = nullptr;        // fallback list of the near-window self join (rk_dist_near.inc): [0] count, [1] done, [4..] rows;
                                      // allocated on first use; one self join per index in flight at a time
+    uint32_t *h_fb_seen = nullptr;   // page-locked host word: rows the last fallback launch found in the list (a hint for the next
+                                     // launch's grid: an empty list is the rule, and an empty launch should be a small one)
     std::mutex lazy_mu;              // serialises the lazy builders (prefix directory, rank bitmap, list records, sum of
                                      // squares): two host threads may query one index
 };
