@@ -1069,6 +1069,8 @@ int plan_bands(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool den
 // exist) and a reportable pair needs a count the handful of chance hashes of a row cannot reach.
 struct NearPlan {
     bool use = false, pair = false;
+    int uw = 1;             // waves that share a unit
+    uint32_t grid = 0;
     uint32_t row_first, row_step, row_block, units_per_block, n_units;
     double min_jorc = 0.0;
 };
@@ -1093,6 +1095,13 @@ NearPlan plan_near(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool
     const uint64_t n_blocks = ((uint64_t)idx->n_ref + np.row_block - 1) / np.row_block;
     const uint64_t my_blocks = np.row_first < n_blocks ? (n_blocks - np.row_first + np.row_step - 1) / np.row_step : 0;
     np.n_units = (uint32_t)std::min<uint64_t>(my_blocks * np.units_per_block, 0xFFFFFFF0u);
+    // waves per unit: one when the launch fills the chip's wave slots at least half, else 2 or 4 share a unit's steps
+    const int per_cu = std::max(1, rk_occupancy(ctx, (const void *)rk_near_kernel<true, 1>, (int)kNearThreads, 0));
+    const uint32_t wgs = (uint32_t)per_cu * (uint32_t)std::max(1, ctx->num_cu), wave_slots = wgs * (kNearThreads / 64);
+    np.uw = np.n_units >= wave_slots / 2 ? 1 : (np.n_units >= wave_slots / 4 ? 2 : 4);
+    if (ctx->sw_dist_near_uw == 1 || ctx->sw_dist_near_uw == 2 || ctx->sw_dist_near_uw == 4) np.uw = ctx->sw_dist_near_uw;
+    const uint32_t slots = (kNearThreads / 64) / (uint32_t)np.uw;
+    np.grid = std::min<uint32_t>((np.n_units + slots - 1) / slots, wgs);
     np.use = true;
     return np;
 }
@@ -1146,13 +1155,8 @@ int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool de
             a.fb_rows = idx->d_fb + 4;
             a.stage_hits = kNearStage;
             a.debug = getenv("RK_NEAR_DEBUG") ? atoi(getenv("RK_NEAR_DEBUG")) : 0;
-            // waves per unit: one when the launch fills the chip's wave slots at least half, else 2 or 4 share a unit's steps
-            const int per_cu = std::max(1, rk_occupancy(ctx, (const void *)rk_near_kernel<true, 1>, (int)kNearThreads, 0));
-            const uint32_t wave_slots = (uint32_t)per_cu * (uint32_t)std::max(1, ctx->num_cu) * (kNearThreads / 64);
-            int uw = np.n_units >= wave_slots / 2 ? 1 : (np.n_units >= wave_slots / 4 ? 2 : 4);
-            if (ctx->sw_dist_near_uw == 1 || ctx->sw_dist_near_uw == 2 || ctx->sw_dist_near_uw == 4) uw = ctx->sw_dist_near_uw;
-            const uint32_t slots = (kNearThreads / 64) / (uint32_t)uw;
-            const uint32_t grid = std::min<uint32_t>((np.n_units + slots - 1) / slots, (uint32_t)per_cu * (uint32_t)std::max(1, ctx->num_cu));
+            const int uw = np.uw;
+            const uint32_t grid = np.grid;
 #define RK_NEAR(P, U) hipLaunchKernelGGL((rk_near_kernel<P, U>), dim3(grid), dim3(kNearThreads), 0, stream, a)
             if (np.pair) { if (uw == 1) RK_NEAR(true, 1); else if (uw == 2) RK_NEAR(true, 2); else RK_NEAR(true, 4); }
             else { if (uw == 1) RK_NEAR(false, 1); else if (uw == 2) RK_NEAR(false, 2); else RK_NEAR(false, 4); }
@@ -1243,7 +1247,7 @@ int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *que
     if (queries) return rk_distq_kernel_name(ctx, idx, queries, buf, cap);
     const NearPlan np = plan_near(ctx, idx, opts, rk_dense_mode(opts));
     if (np.use) {
-        snprintf(buf, cap, "rk_near_kernel<%s>", np.pair ? "true" : "false");
+        snprintf(buf, cap, "rk_near_kernel<%s, %d>", np.pair ? "true" : "false", np.uw);
         return RK_OK;
     }
     std::vector<Plan> bands;  // several bands: the variant of the first (widest rows)

@@ -1367,10 +1367,14 @@ extern "C" int rk_index_broadcast(const rk_index *src, rk_ctx *const *dst, uint3
         // bounded wait: a peer copy that never completes (a link that is down) must end in an error, not in a hang
         hipError_t qe = hipSetDevice(d->device);
         const auto t_start = std::chrono::steady_clock::now();
-        while (qe == hipSuccess && (qe = hipStreamQuery(d->stream)) == hipErrorNotReady) {
+        while (qe == hipSuccess) {
+            qe = hipStreamQuery(d->stream);
+            if (qe != hipErrorNotReady) break;
             if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(kPeerCopyTimeoutS)) break;
             std::this_thread::sleep_for(std::chrono::microseconds(50));
+            qe = hipSuccess;
         }
+        (void)hipGetLastError();  // (hipStreamQuery's hipErrorNotReady is sticky for the next hipGetLastError check)
         if (qe == hipErrorNotReady) stuck = true;
         if (qe == hipErrorNotReady)
             rc = rk_fail(d, RK_ERR_HIP, "index copy of %llu bytes from device %d to device %d did not complete within %d s", (unsigned long long)bytes,
@@ -1381,6 +1385,9 @@ extern "C" int rk_index_broadcast(const rk_index *src, rk_ctx *const *dst, uint3
             rc = rk_index_unpack_dev(d, peer[i], bytes, d->stream, &out[i]);
     }
     if (rc) {
+        // the caller asks the SOURCE context for the message: carry the failing peer's text over
+        for (uint32_t i = 0; i < n_dst; i++)
+            if (dst[i] != sctx && !dst[i]->err.empty()) sctx->err = "device " + std::to_string(dst[i]->device) + ": " + dst[i]->err;
         if (!stuck) abandon(n_dst);  // waits for the copies of the peers behind the failing one
         else (void)hipSetDevice(sctx->device);
         for (uint32_t i = 0; i < n_dst; i++) {

@@ -122,7 +122,7 @@ def main(tag, traffic_only=False):
         return hbm
     # the self join streams its 8-byte slice records (compact slices carry their posting list): a coalesced 8 B/lane
     # stream, corrected by the factor calibrated above (check: ~5.4 M uncovered slices x 8 B = 43 MB)
-    t_d = traffic(groups["dist"], "rk_dist_kernel", "pmc_traffic.json", "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X", 8)
+    t_d = traffic(groups["dist"], "rk_near_kernel", "pmc_traffic.json", "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X", 8)
     t_q = traffic(groups["rq"], "rk_distq_kernel", "pmc_traffic_rq.json", "dist 100,000 refs x 1,000 queries (tools/prof_driver.py dist_rq_dev), MI355X", 0)
     t_s = traffic(groups["sketch"], "rk_sketch_kernel", "pmc_traffic_sketch.json", "sketch 128 x 5 Mb (tools/prof_driver.py sketch 128 5000000), MI355X", 16)
     print("traffic dist %s rq %s sketch %s B/launch" % (t_d, t_q, t_s))

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 for w in 4 8 16; do
   printf 'FETCH_SIZE\n' | tools/pmc_pass.sh pmcC$w k_calib_read calib 1024 $w || exit 1
 done
-tools/pmc_pass.sh pmcD rk_dist_kernel dist 10000 4 < tools/pmc_groups_dist.txt || exit 1
+tools/pmc_pass.sh pmcD rk_near_kernel dist 10000 4 < tools/pmc_groups_dist.txt || exit 1
 tools/pmc_pass.sh pmcQ rk_distq_kernel dist_rq_dev 100000 1000 3 < tools/pmc_groups_rq.txt || exit 1
 printf 'FETCH_SIZE\nWRITE_SIZE\nTCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum\n' | tools/pmc_pass.sh pmcSk rk_sketch_kernel sketch 128 5000000 || exit 1
 tools/pmc_pass.sh pmcS rk_sketch_kernel sketch 128 5000000 < tools/pmc_groups_sketch.txt || exit 1
