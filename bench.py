@@ -659,10 +659,11 @@ def dist_roofline(block, pmc_file=None):
             "issue_frac": None,
             "kernel": block["kernel"], "kernel_ms": block["kernel_ms"],
             "kernel_ms_min_median_max": block["kernel_ms_min_median_max"],
-            "limited_by": "vector-instruction issue and the two workgroup barriers per unit (DESIGN.md 4.3), not HBM: the "
-                          "fraction of the HBM roofline is small by construction -- the counts never leave LDS and a compact "
-                          "slice record is its own posting list; issue_frac = share of the kernel's duration the SIMDs spent "
-                          "issuing vector instructions (SQ_ACTIVE_INST_VALU x 4 / 1,024 SIMDs / 2.4 GHz)"}
+            "limited_by": "the dependent memory round trips of a unit (row bounds -> slice records -> sizes and ids of the "
+                          "reportable cells) with one short unit per wave, and vector issue; not HBM bandwidth: the kernel's whole "
+                          "stream is the 8-byte slice records (a compact record is its own posting list; the window counts stay in "
+                          "registers), DESIGN.md 4.3; issue_frac = share of the kernel's duration the SIMDs spent issuing vector "
+                          "instructions (SQ_ACTIVE_INST_VALU x 4 / 1,024 SIMDs / 2.4 GHz)"}
     if pmc_file:
         apply_pmc(roof, load_pmc(block["kernel"], pmc_file))
     return roof
@@ -745,6 +746,7 @@ def main():
     head["distinct"] = distinct
     n_pairs = head["pairs"]
     u16 = head["kernel"].startswith("rk_dist_kernel<true")
+    near = head["kernel"].startswith("rk_near_kernel")
     out = {
         "metric": "genome-pairs/sec alldist (10k bacteria, L3K10)",
         "value": head["value"],
@@ -756,7 +758,8 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": ("u16 intersection counters in LDS (exact: a count is bounded by the sketch size, < 65536)" if u16 else
+        "dtype": ("u32 window counts in registers, accumulated bit-sliced per lane (exact)" if near else
+                  "u16 intersection counters in LDS (exact: a count is bounded by the sketch size, < 65536)" if u16 else
                   "u32 intersection counters in LDS") + " / f64 jaccard + distance",
         "data": "synthetic",
         "config": {"workload": "alldist over %d synthetic bacterial sketches (sketch-level clade generator, seed 20261003, "
