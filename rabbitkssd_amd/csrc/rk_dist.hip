@@ -1095,10 +1095,12 @@ NearPlan plan_near(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool
     const uint64_t n_blocks = ((uint64_t)idx->n_ref + np.row_block - 1) / np.row_block;
     const uint64_t my_blocks = np.row_first < n_blocks ? (n_blocks - np.row_first + np.row_step - 1) / np.row_step : 0;
     np.n_units = (uint32_t)std::min<uint64_t>(my_blocks * np.units_per_block, 0xFFFFFFF0u);
-    // waves per unit: one when the launch fills the chip's wave slots at least half, else 2 or 4 share a unit's steps
+    // waves per unit: one, unless the launch has fewer units than an eighth of the chip's wave slots -- then two share a
+    // unit's steps (measured, 8,192 slots: 3,125 units 0.031 / 0.038 / 0.044 ms with 1 / 2 / 4 waves per unit, 625 units
+    // 0.020 / 0.015 / 0.017 ms)
     const int per_cu = std::max(1, rk_occupancy(ctx, (const void *)rk_near_kernel<true, 1>, (int)kNearThreads, 0));
     const uint32_t wgs = (uint32_t)per_cu * (uint32_t)std::max(1, ctx->num_cu), wave_slots = wgs * (kNearThreads / 64);
-    np.uw = np.n_units >= wave_slots / 2 ? 1 : (np.n_units >= wave_slots / 4 ? 2 : 4);
+    np.uw = np.n_units >= wave_slots / 8 ? 1 : 2;
     if (ctx->sw_dist_near_uw == 1 || ctx->sw_dist_near_uw == 2 || ctx->sw_dist_near_uw == 4) np.uw = ctx->sw_dist_near_uw;
     const uint32_t slots = (kNearThreads / 64) / (uint32_t)np.uw;
     np.grid = std::min<uint32_t>((np.n_units + slots - 1) / slots, wgs);

@@ -755,7 +755,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     const uint64_t Ucap = hash_bits < 40 ? std::min<uint64_t>(H, 1ULL << hash_bits) : H;
     RK_TRY(pool_array(ctx, &idx->d_sizes, (size_t)N + 1));
     RK_TRY(pool_array(ctx, &idx->d_src_off, (size_t)N + 1));
-    RK_TRY(pool_array(ctx, &idx->d_postings, H + 4));
+    RK_TRY(pool_array(ctx, &idx->d_postings, H + 8));   // (padded: the kernels read up to eight postings from any list start)
     if (idx->wide) RK_TRY(pool_array(ctx, &idx->d_uhash64, Ucap + 1));
     else RK_TRY(pool_array(ctx, &idx->d_uhash, Ucap + 1));
     RK_TRY(pool_array(ctx, &idx->d_upos, Ucap + 2));
@@ -1032,7 +1032,7 @@ int rk_index_import(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const
     struct Guard { rk_index *p; ~Guard() { if (p) rk_index_free(p); } } guard{idx};
 
     RK_TRY(pool_array(ctx, &idx->d_sizes, (size_t)n_ref + 1));
-    RK_TRY(pool_array(ctx, &idx->d_postings, total + 4));
+    RK_TRY(pool_array(ctx, &idx->d_postings, total + 8));
     RK_HIP(ctx, hipMemcpyAsync(idx->d_sizes, ref_sizes, (size_t)n_ref * 4, hipMemcpyHostToDevice, st));
     RK_HIP(ctx, hipMemcpyAsync(idx->d_postings, postings, total * 4, hipMemcpyHostToDevice, st));
 
@@ -1256,7 +1256,7 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
     idx->wide = h.wide != 0;
     set_dir_shape(idx);
     const char *b = (const char *)blob_dev;
-    RK_TRY(pool_array(ctx, &idx->d_postings, idx->H + 4));
+    RK_TRY(pool_array(ctx, &idx->d_postings, idx->H + 8));
     if (idx->wide) RK_TRY(pool_array(ctx, &idx->d_uhash64, idx->U + 1));
     else RK_TRY(pool_array(ctx, &idx->d_uhash, idx->U + 1));
     RK_TRY(pool_array(ctx, &idx->d_upos, idx->U + 2));
@@ -1486,7 +1486,7 @@ int rk_index_import64(rk_ctx *ctx, const uint32_t *postings, uint64_t total, con
     }
     hipStream_t st = ctx->stream;
     RK_TRY(pool_array(ctx, &idx->d_sizes, (size_t)n_ref + 1));
-    RK_TRY(pool_array(ctx, &idx->d_postings, total + 4));
+    RK_TRY(pool_array(ctx, &idx->d_postings, total + 8));
     RK_TRY(pool_array(ctx, &idx->d_uhash64, n_hash + 1));
     RK_TRY(pool_array(ctx, &idx->d_upos, n_hash + 2));
     RK_HIP(ctx, hipMemcpyAsync(idx->d_sizes, ref_sizes, (size_t)n_ref * 4, hipMemcpyHostToDevice, st));
