@@ -12,13 +12,17 @@
 //   convert [--reverse]                      (host formats, src/sketch.cpp:1179-1365; index on GPU)
 // Errors follow the reference: a message on stderr and exit(1).  There is no CPU fallback:
 // without a GPU the GPU subcommands fail at rk_ctx_create.
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <condition_variable>
+#include <deque>
 #include <cstdarg>
 #include <iostream>
 #include <map>
@@ -77,6 +81,174 @@ struct Gpu {
         if (rc) die("%s failed (%d): %s", what, rc, rk_last_error(ctx));
     }
 };
+
+// ---- one big plain FASTA file, streamed (the role of src/sketch.cpp:380-450: RabbitFX chunks of a big file go to the
+// consumers while the producer is still reading) --------------------------------------------------------------------
+// A 3 Gb genome used to be read completely, parsed in two passes into ordinary memory and only then uploaded
+// (0.71 s + 0.09 s).  Now the file is mapped and cut into pieces at line starts; parser threads turn piece after piece
+// into the packed layout -- ONE pass, straight into a small ring of page-locked buffers -- and the calling thread
+// uploads every finished piece to its own slot of the device buffer while the others are still being parsed.  A piece
+// starts with the last k-1 bases in front of it (unless a header line lies between), so that every window is seen
+// exactly once: by the piece it ENDS in.  Slots are sized for the piece's file bytes (newlines become padding: zero
+// bytes, which the kernel treats like any invalid base), so no piece has to know how much the pieces before it shrank.
+// Returns false -- nothing done -- for inputs this path does not take (FASTQ, '\r' line ends, no header at the start):
+// the caller falls back to the whole-file path.
+static bool sketch_big_fasta_streamed(Gpu &gpu, const rk_filter *flt, const string &path, int kmer, int threads, uint32_t min_count,
+                                      void *stream, rk_sketches **sk_out, bool timing)
+{
+    const double t0 = get_sec();
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) || st.st_size < 64) { close(fd); return false; }
+    const size_t sz = (size_t)st.st_size;
+    const uint8_t *b = (const uint8_t *)mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (b == MAP_FAILED) return false;
+    (void)madvise((void *)b, sz, MADV_SEQUENTIAL);
+    struct Unmap { const uint8_t *p; size_t n; ~Unmap() { munmap((void *)p, n); } } unmap{b, sz};
+    if (b[0] != '>') return false;   // (kseq skips to the first header: leave odd files to the serial reader)
+
+    size_t piece = (size_t)(getenv("RK_BIG_PIECE_MB") ? std::max(1, atoi(getenv("RK_BIG_PIECE_MB"))) : 32) << 20;
+    if (getenv("RK_BIG_PIECE_KB")) piece = (size_t)std::max(1, atoi(getenv("RK_BIG_PIECE_KB"))) << 10;   // tests
+    vector<size_t> cut{0};
+    while (cut.back() < sz) {
+        size_t p = std::min(sz, cut.back() + piece);
+        if (p < sz) {
+            const void *e = memchr(b + p, '\n', sz - p);
+            p = e ? (size_t)((const uint8_t *)e - b) + 1 : sz;
+        }
+        cut.push_back(p);
+    }
+    const size_t n_pieces = cut.size() - 1;
+    vector<uint64_t> slot_off(n_pieces + 1, 0);
+    uint64_t max_slot = 0;
+    for (size_t i = 0; i < n_pieces; i++) {
+        const uint64_t cap = ((cut[i + 1] - cut[i]) + (uint64_t)kmer + 2 + 1023) & ~1023ULL;   // prefix + separator + the piece
+        slot_off[i + 1] = slot_off[i] + cap;
+        max_slot = std::max(max_slot, cap);
+    }
+    const uint64_t dev_bytes = slot_off[n_pieces];
+    const int n_ring = (int)std::min<size_t>(n_pieces, (size_t)std::max(2, std::min(threads, 8)));
+    vector<uint8_t *> ring((size_t)n_ring, nullptr);
+    void *d_buf = nullptr;
+    gpu.check(rk_dev_alloc(gpu.ctx, dev_bytes, &d_buf), "rk_dev_alloc");
+    for (int j = 0; j < n_ring; j++) gpu.check(rk_pinned_alloc(gpu.ctx, max_slot, (void **)&ring[(size_t)j]), "rk_pinned_alloc");
+    if (timing) fprintf(stderr, "[timing] big file: %zu piece(s), %d x %.1f MB page-locked + %.1f MB device: %.3f s\n", n_pieces, n_ring,
+                        max_slot / 1e6, dev_bytes / 1e6, get_sec() - t0);
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> free_slots;
+    std::deque<std::pair<size_t, int>> ready;   // (piece, ring slot)
+    for (int j = 0; j < n_ring; j++) free_slots.push_back(j);
+    std::atomic<size_t> next_piece{0};
+    std::atomic<bool> bad{false};
+
+    // the last k-1 bases in front of position `pos` (a line start), unless a header line lies between: walked backwards
+    // line by line.  Returns the number of bases written to the END of tmp[0 .. k-1).
+    auto bases_before = [&](size_t pos, uint8_t *tmp, size_t need) -> size_t {
+        size_t got = 0;
+        size_t le = pos;   // one past the newline that ends the line being looked at
+        while (got < need && le > 0) {
+            const size_t nl = le - 1;   // b[nl] == '\n'
+            const void *q = nl ? memrchr(b, '\n', nl) : nullptr;
+            const size_t ls = q ? (size_t)((const uint8_t *)q - b) + 1 : 0;
+            if (b[ls] == '>') return got;   // a record starts here: nothing in front of it belongs to the windows of this piece
+            if (b[ls] == '+' || b[ls] == '@') { bad = true; return 0; }
+            for (size_t c = nl; c > ls && got < need; c--) tmp[need - 1 - got++] = b[c - 1];
+            le = ls;
+        }
+        return got;
+    };
+    auto parse_piece = [&](size_t i, uint8_t *dst) {
+        const uint64_t cap = slot_off[i + 1] - slot_off[i];
+        uint8_t *w = dst;
+        if (i > 0) {
+            uint8_t tmp[64];
+            const size_t need = (size_t)std::min(63, kmer - 1);
+            const size_t got = bases_before(cut[i], tmp, need);
+            memcpy(w, tmp + (need - got), got);
+            w += got;
+        }
+        size_t pos = cut[i];
+        const size_t end = cut[i + 1];
+        while (pos < end) {
+            const void *q = memchr(b + pos, '\n', end - pos);
+            const size_t e = q ? (size_t)((const uint8_t *)q - b) : end;
+            const uint8_t c = b[pos];
+            if (c == '>') {
+                if (pos != 0) *w++ = 0;   // record separator (a window never spans records, src/sketch.cpp:487-488)
+            } else if (c == '+' || c == '@') {
+                bad = true;
+                return;
+            } else if (e > pos) {
+                if (b[e - 1] == '\r') { bad = true; return; }
+                memcpy(w, b + pos, e - pos);
+                w += e - pos;
+            }
+            pos = e + 1;
+        }
+        memset(w, 0, (size_t)(dst + cap - w));   // padding: invalid bases
+    };
+
+    vector<std::thread> pool;
+    const int nt = (int)std::min<size_t>(n_pieces, (size_t)std::max(1, threads));
+    for (int t = 0; t < nt; t++)
+        pool.emplace_back([&]() {
+            for (;;) {
+                const size_t i = next_piece.fetch_add(1);
+                if (i >= n_pieces) return;
+                int j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !free_slots.empty(); });
+                    j = free_slots.front();
+                    free_slots.pop_front();
+                }
+                if (!bad) parse_piece(i, ring[(size_t)j]);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready.emplace_back(i, j);
+                }
+                cv.notify_all();
+            }
+        });
+    // this thread: every finished piece to its slot of the device buffer, while the others are parsed
+    for (size_t done = 0; done < n_pieces; done++) {
+        std::pair<size_t, int> pj;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty(); });
+            pj = ready.front();
+            ready.pop_front();
+        }
+        if (!bad) {
+            gpu.check(rk_upload_async(gpu.ctx, (uint8_t *)d_buf + slot_off[pj.first], ring[(size_t)pj.second],
+                                      slot_off[pj.first + 1] - slot_off[pj.first], stream), "rk_upload_async");
+            gpu.check(rk_stream_sync(gpu.ctx, stream), "rk_stream_sync");
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            free_slots.push_back(pj.second);
+        }
+        cv.notify_all();
+    }
+    for (auto &th : pool) th.join();
+    const double t1 = get_sec();
+    bool ok = !bad;
+    if (ok) {
+        const uint64_t gbeg = 0, gend = dev_bytes;
+        gpu.check(rk_sketch_packed_dev_ex(gpu.ctx, flt, (const uint8_t *)d_buf, dev_bytes, &gbeg, &gend, 1, min_count, stream, sk_out),
+                  "rk_sketch_packed_dev_ex");
+    }
+    if (timing) fprintf(stderr, "[timing] big file: parse + upload of %.1f MB (overlapped, %d thread(s)): %.3f s, sketch kernels: %.3f s\n",
+                        sz / 1e6, nt, t1 - t0, get_sec() - t1);
+    for (int j = 0; j < n_ring; j++) rk_pinned_free(ring[(size_t)j]);
+    rk_dev_free(d_buf);
+    return ok;
+}
+
 
 // HIP runtime start-up (hipInit: 150-190 ms on an MI355X box) is the largest single item of a short alldist/dist run:
 // it starts on a thread of its own while the main thread reads the .sketch files
@@ -189,6 +361,7 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
         size_t first = 0, last = 0;  // files [first, last)
         uint64_t bytes = 0;          // staging bytes used
         bool pageable = false;       // one oversized file: staged in ordinary memory
+        bool streamed = false;       // ... or, a plain FASTA file, streamed piece by piece (sketch_big_fasta_streamed)
         vector<Slot> slots;
     };
     // upper bound of a file's packed size: a plain file cannot expand; a .gz member stores its
@@ -320,6 +493,20 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
             }
             rk_sketches *sk = nullptr;
             const double t_gpu = get_sec();
+            if (bt.streamed) {
+                if (!sketch_big_fasta_streamed(gpu, flt, files[bt.first], 2 * shuf.k, threads, (uint32_t)std::max(1, fq.least_num), stream,
+                                               &sk, timing))
+                    slow_path(bt.first, &sk);   // not a file this path takes (FASTQ-like lines, '\r' line ends): the serial reader
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    consumed = k + 1;
+                }
+                cv.notify_all();
+                append_sketches(sk, 1);
+                rk_sketches_free(sk);
+                cerr << "finshed sketching: " << bt.last << " genomes" << endl;
+                continue;
+            }
             gpu.check(rk_upload_async(gpu.ctx, dev[bi], bt.pageable ? big_stage.data() : stage[bi], bt.bytes, stream),
                       "rk_upload_async");
             gpu.check(rk_sketch_packed_dev_ex(gpu.ctx, flt, (const uint8_t *)dev[bi], bt.bytes, gbeg.data(), gend.data(),
@@ -364,6 +551,16 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
             cv.wait(lk, [&] { return k < (size_t)n_buf || consumed + (size_t)n_buf > k; });
         }
         Batch &bt = batches[k];
+        if (bt.pageable && !fq.fastq && !ends_with(files[bt.first], ".gz") && !getenv("RK_BIG_WHOLE")) {
+            // a big plain FASTA file: the GPU thread streams it piece by piece (parse, upload and kernels overlap)
+            bt.streamed = true;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                filled = k + 1;
+            }
+            cv.notify_all();
+            continue;
+        }
         if (bt.pageable) {  // its own buffer; the previous oversized batch must be uploaded first
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return consumed == k; });

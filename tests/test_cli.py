@@ -246,6 +246,62 @@ def test_cli_sketch_streaming_pipeline_many_batches_and_a_big_file(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("piece_kb", [0, 193, 1021])
+def test_cli_big_fasta_streamed_in_pieces_equals_the_whole_file_path(tmp_path, piece_kb):
+    """One big plain FASTA file is streamed: cut into pieces at line starts, parsed piece by piece into page-locked
+    buffers while earlier pieces are uploaded; a piece starts with the last k-1 bases in front of it, so that every
+    window is seen exactly once.  Tiny pieces (RK_BIG_PIECE_KB) put piece boundaries everywhere: next to headers, inside
+    records shorter than k, around empty lines and N runs, in lines of every width.  The hash set must be the oracle's
+    and the whole-file path's (RK_BIG_WHOLE=1)."""
+    k, s, l = 8, 5, 2
+    shuf = tmp_path / "L2K8.shuf"
+    run(["shuffle", "-k", k, "-s", s, "-l", l, "-o", shuf])
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    rng = np.random.default_rng(2026 + piece_kb)
+    lut = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    recs, text = [], []
+    total = 0
+    while total < (66 << 20):
+        n = int(rng.choice([1, 7, 15, 16, 17, 40, 5000, 200_000, 3_000_000]))
+        codes = rng.integers(0, 8, n, dtype=np.uint8)
+        if n > 1000 and rng.random() < 0.5:
+            a = int(rng.integers(0, n - 100))
+            codes[a:a + int(rng.integers(1, 90))] = 8               # an N run
+        bases = lut[codes]
+        recs.append(bases)
+        width = int(rng.choice([60, 61, 80, 200, 100000]))
+        body = bases.tobytes()
+        lines = [body[i:i + width] for i in range(0, n, width)]
+        if rng.random() < 0.2:
+            lines.insert(len(lines) // 2, b"")                       # an empty line inside the record
+        text.append(b">r%d some comment\n" % len(recs) + b"\n".join(lines) + b"\n")
+        total += n
+    big = tmp_path / "big.fa"
+    big.write_bytes(b"".join(text))
+    small = tmp_path / "small.fa"
+    small.write_bytes(b">s\nACGTACGTACGTACGTACGTAAAACCCCGGGGTTTT\n")
+    lst = tmp_path / "g.list"
+    lst.write_text("%s\n%s\n" % (small, big))
+    env = dict(os.environ)
+    if piece_kb:
+        env["RK_BIG_PIECE_KB"] = str(piece_kb)
+    p = subprocess.run([TOOL, "sketch", "-i", str(lst), "-L", str(shuf), "-o", str(tmp_path / "st"), "-t", "6", "-q"], cwd=tmp_path,
+                       env=dict(env, RK_TIMING="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    assert b"big file:" in p.stderr                                   # the streamed path ran
+    _, names, h, off = ok.read_sketches32(str(tmp_path / "st.sketch"))
+    seq = np.concatenate(recs)
+    rec_off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+    want = ok.sketch_records(param, table, seq, rec_off)
+    assert np.array_equal(h[int(off[1]):int(off[2])].astype(np.uint64), want)
+    if piece_kb == 0:
+        p = subprocess.run([TOOL, "sketch", "-i", str(lst), "-L", str(shuf), "-o", str(tmp_path / "wh"), "-t", "6", "-q"], cwd=tmp_path,
+                           env=dict(os.environ, RK_BIG_WHOLE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        assert (tmp_path / "wh.sketch").read_bytes() == (tmp_path / "st.sketch").read_bytes()
+
+
+@pytest.mark.gpu
 def test_cli_sketch_gzip_inputs_incl_multi_member(tmp_path):
     """.gz genomes in the streaming pipeline: a single-member file (its trailer gives the slot size) and a
     three-member file whose trailer understates the size -- the slot overflows and the genome takes the
