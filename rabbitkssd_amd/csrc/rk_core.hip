@@ -213,7 +213,7 @@ int rk_ctx_create(int device, rk_ctx **out)
     if (getenv("RK_DIST_NEAR_MIN")) ctx->sw_dist_near_min = std::max(1, atoi(getenv("RK_DIST_NEAR_MIN")));
     ctx->sw_dist_debug = getenv("RK_DIST_DEBUG") ? atoi(getenv("RK_DIST_DEBUG")) : 0;
     if (getenv("RK_DIST_LDS_KB")) ctx->sw_dist_lds_kb = std::max(0, atoi(getenv("RK_DIST_LDS_KB")));
-    ctx->sw_sketch_img = getenv("RK_SKETCH_IMG") ? atoi(getenv("RK_SKETCH_IMG")) != 0 : 1;
+    ctx->sw_sketch_img = getenv("RK_SKETCH_IMG") ? std::min(2, std::max(0, atoi(getenv("RK_SKETCH_IMG")))) : 2;
     ctx->sw_index_fast = getenv("RK_INDEX_FAST") ? atoi(getenv("RK_INDEX_FAST")) != 0 : 1;
     ctx->sw_index_relabel = getenv("RK_INDEX_RELABEL") ? atoi(getenv("RK_INDEX_RELABEL")) != 0 : 1;
     *out = ctx;

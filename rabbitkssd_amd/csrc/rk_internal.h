@@ -49,7 +49,9 @@ struct rk_ctx {
     int sw_dist_near_min = 16;  // RK_DIST_NEAR_MIN: the near-window kernel is used when a reportable pair of the smallest sketch needs at least this count
     int sw_dist_debug = 0;  // RK_DIST_DEBUG=1: the bands of every self join on stderr
     int sw_dist_lds_kb = 0;  // RK_DIST_LDS_KB: plan as if a CU had this much LDS (tests: tiled bands at small sizes)
-    int sw_sketch_img = 1;  // RK_SKETCH_IMG=0: the 144 KiB LDS image with the exact table, one workgroup per CU
+    // RK_SKETCH_IMG: 2 = the two-stage scan (rk_sketch_scan2.inc; parameter sets without a compile-time variant fall
+    // back to 1), 1 = rk_sketch_kernel with the 64 KiB LDS image, 0 = with the 144 KiB image and the exact table
+    int sw_sketch_img = 2;
     int sw_index_fast = 1;     // RK_INDEX_FAST=0: always the general (device-wide radix sort) build
     int sw_index_relabel = 1;  // RK_INDEX_RELABEL=0: keep the caller's genome order inside the index
 };

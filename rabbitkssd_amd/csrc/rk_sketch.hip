@@ -103,7 +103,20 @@ struct SketchArgs {
     unsigned long long *cand;
     uint32_t *gcount;
     unsigned long long *n_windows;
+    // chunks are handed out in order within `n_groups` equal ranges, one ticket counter each (128 B apart, zeroed
+    // per pass); workgroup b works in range b % n_groups
+    uint32_t *tickets;
+    uint32_t n_groups;
+    const struct ChunkDesc *chunks;  // one per chunk, written by k_chunk_table
 };
+// where a chunk lies: the waves read this instead of searching the genome rows (seven dependent loads per chunk)
+struct ChunkDesc {
+    uint64_t beg;       // byte offset of its first block in the packed buffer
+    uint32_t nb_first;  // its blocks; bit 31: the first chunk of its genome
+    uint32_t gid;
+};
+static_assert(sizeof(ChunkDesc) == 16, "read as one uint4");
+constexpr uint32_t kTicketGroups = 64, kTicketStride = 32;  // counters, dwords between them
 
 // low 32 bits of the 96-bit string w2:w1:w0 shifted right by sh (0 <= sh < 96); with a compile-time sh this is one
 // v_alignbit_b32
@@ -169,6 +182,23 @@ __device__ inline uint32_t wave_shr1(uint32_t v, uint32_t lane0_val)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_val, (int)v, 0x138, 0xF, 0xF, false);
 }
 
+// the range of chunks workgroup blockIdx.x draws from (gridDim.x is a multiple of n_groups)
+struct ChunkRange {
+    uint32_t first, next, hi;  // this wave's first chunk; ticket t stands for chunk next + t; end of the range
+    uint32_t *counter;
+};
+__device__ inline ChunkRange chunk_range(const SketchArgs &a, uint32_t wave)
+{
+    const uint32_t g = blockIdx.x % a.n_groups, waves = gridDim.x / a.n_groups * kWavesPerBlock;
+    const uint32_t lo = (uint32_t)((uint64_t)a.n_chunks * g / a.n_groups), hi = (uint32_t)((uint64_t)a.n_chunks * (g + 1) / a.n_groups);
+    ChunkRange r;
+    r.first = min(hi, lo + blockIdx.x / a.n_groups * kWavesPerBlock + wave);
+    r.next = lo + waves;
+    r.hi = hi;
+    r.counter = a.tickets + (size_t)g * kTicketStride;
+    return r;
+}
+
 // KS/OUT2: compile-time kmer_size and 2*half_outctx_len (0/-1: taken from the arguments)
 template <int KS, int OUT2, bool EXACT, int IMG>
 __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sketch_kernel(SketchArgs a)
@@ -204,7 +234,7 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
     const int hi_shift = KS ? (2 * KS - 2 * OUT2 > Img<IMG>::kBitsB ? 2 * KS - 2 * OUT2 - Img<IMG>::kBitsB : 0) : a.hi_shift;
     const uint32_t dim_mask = (1u << dim_bits) - 1;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long windows = 0;
     uint32_t staged = 0;  // wave-uniform: windows in this wave's queue
 
@@ -261,17 +291,19 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
         }
     };
 
-    for (uint32_t c = blockIdx.x * kWavesPerBlock + wave; c < a.n_chunks; c += gridDim.x * kWavesPerBlock) {
-        // the genome of chunk c: largest g with first_chunk[g] <= c (wave-uniform binary search, scalar loads)
-        uint32_t gid = 0;
-        for (uint32_t hi = a.n_genomes; hi - gid > 1;) {
-            const uint32_t mid = (gid + hi) >> 1;
-            if (a.rows[mid].first_chunk <= c) gid = mid; else hi = mid;
-        }
+    // Chunks are handed out in order, not by striding (16,512 chunks on 8,192 striding waves ran for three rounds, not
+    // 2.02).  One counter for the whole grid would serialise 10^4..10^5 same-address atomics (13 ns each, measured):
+    // the chunks are cut into n_groups equal ranges with a counter each; a wave's first chunk is its index in its group.
+    const ChunkRange cr = chunk_range(a, wave);
+    for (uint32_t c = cr.first; c < cr.hi;) {
+        uint32_t ticket = 0;
+        if (lane == 0) ticket = atomicAdd(cr.counter, 1u);  // consumed at the end of this chunk
+        const ChunkDesc cd = a.chunks[c];
+        const uint32_t gid = cd.gid;
         const GenomeRow row = a.rows[gid];
         const uint32_t b0 = (c - row.first_chunk) * a.chunk_blocks;
-        const uint32_t nb = min(a.chunk_blocks, row.nblk - b0);
-        const uint32_t nbf = b0 == 0 ? 0x80000000u : 0u;  // bit 31: first chunk of its genome
+        const uint32_t nb = cd.nb_first & 0x7FFFFFFFu;
+        const uint32_t nbf = cd.nb_first & 0x80000000u;  // bit 31: first chunk of its genome
         const uint8_t *base = a.packed + row.beg + (size_t)b0 * 1024;
         unsigned long long *region = a.cand + row.reg_off;
         const uint32_t region_cap = row.reg_cap;
@@ -432,10 +464,13 @@ __global__ __launch_bounds__(kSketchThreads, Img<IMG>::kWavesPerEu) void rk_sket
         }
         drain(gid, region, region_cap);
         staged = 0;
+        c = cr.next + __builtin_amdgcn_readfirstlane(ticket);
     }
     for (int o = 32; o > 0; o >>= 1) windows += __shfl_down(windows, o);
     if (lane == 0 && windows) atomicAdd(a.n_windows, windows);
 }
+
+#include "rk_sketch_scan2.inc"
 
 // ---- per-genome dedup (the reference's unordered_set, src/sketch.cpp:470,526-529,537-550) -------------------
 // One workgroup per genome: its candidate region (~1,250 dr_tuples for a 5 Mb genome at L3) is sorted in LDS
@@ -596,9 +631,34 @@ template <class K> __global__ void k_check_sets(const K *hashes, uint64_t total,
 
 inline unsigned blocks_for(uint64_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 
+// the chunk table of a pass: chunk c belongs to the largest g with first_chunk[g] <= c
+__global__ void k_chunk_table(const GenomeRow *rows, uint32_t n_genomes, uint32_t n_chunks, uint32_t chunk_blocks, ChunkDesc *out)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    uint32_t g = 0;
+    for (uint32_t hi = n_genomes; hi - g > 1;) {
+        const uint32_t mid = (g + hi) >> 1;
+        if (rows[mid].first_chunk <= c) g = mid; else hi = mid;
+    }
+    const uint32_t b0 = (c - rows[g].first_chunk) * chunk_blocks;
+    ChunkDesc d;
+    d.beg = rows[g].beg + (uint64_t)b0 * 1024;
+    d.nb_first = min(chunk_blocks, rows[g].nblk - b0) | (b0 == 0 ? 0x80000000u : 0u);
+    d.gid = g;
+    out[c] = d;
+}
+
 typedef void (*sketch_kernel_t)(SketchArgs);
 sketch_kernel_t pick_kernel(int kmer, int out2, bool exact, int img)
 {
+    if (img == 2) {  // the two-stage scan (rk_sketch_scan2.inc): compile-time parameter sets only
+        static const bool u2 = !getenv("RK_SCAN2_U2") || atoi(getenv("RK_SCAN2_U2")) != 0;
+        if (kmer == 20 && out2 == 8) return u2 ? rk_scan2_kernel<20, 8, true> : rk_scan2_kernel<20, 8, false>;  // K10 S6
+        if (kmer == 20 && out2 == 6) return rk_scan2_kernel<20, 6, true>;  // K10 S7
+        if (kmer == 16 && out2 == 6) return rk_scan2_kernel<16, 6, true>;  // K8 S5
+        return nullptr;
+    }
 #define RK_SK(K, O) (img ? rk_sketch_kernel<K, O, false, 1> : (exact ? rk_sketch_kernel<K, O, true, 0> : rk_sketch_kernel<K, O, false, 0>))
     if (kmer == 20 && out2 == 8) return RK_SK(20, 8);   // K10 S6
     if (kmer == 20 && out2 == 6) return RK_SK(20, 6);   // K10 S7
@@ -628,11 +688,13 @@ int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_di
             sel_val.push_back((uint32_t)(v - p->dim_start));
         }
     }
-    const int img = ctx->sw_sketch_img;
-    const int kBitsA = img ? Img<1>::kBitsA : Img<0>::kBitsA, kBitsB = img ? Img<1>::kBitsB : Img<0>::kBitsB;
-    const uint32_t kWordsA = (1u << kBitsA) / 32, kWordsB = (1u << kBitsB) / 32;
-    const size_t kFilterLdsBytes = img ? Img<1>::kFilterLdsBytes : Img<0>::kFilterLdsBytes;
-    const bool exact = !img && sel_key.size() <= kExactSlots / 2 && (p->dim_end - p->dim_start) <= 65536;
+    int img = ctx->sw_sketch_img;
+    if (img == 2 && !pick_kernel(2 * p->half_k, 2 * p->half_outctx_len, false, 2)) img = 1;  // no compile-time variant
+    const int kBitsA = img == 2 ? 18 : (img ? Img<1>::kBitsA : Img<0>::kBitsA);
+    const int kBitsB = img == 2 ? Scan2::kBitsB : (img ? Img<1>::kBitsB : Img<0>::kBitsB);
+    const uint32_t kWordsA = (1u << kBitsA) / 32;
+    const size_t kFilterLdsBytes = img == 2 ? Scan2::kFilterLdsBytes : (img ? Img<1>::kFilterLdsBytes : Img<0>::kFilterLdsBytes);
+    const bool exact = img == 0 && sel_key.size() <= kExactSlots / 2 && (p->dim_end - p->dim_start) <= 65536;
     std::vector<uint32_t> image(kFilterLdsBytes / 4, 0);
     const int dim_bits = 4 * p->half_subk;
     const int hi_shift = std::max(0, dim_bits - kBitsB);
@@ -648,7 +710,8 @@ int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_di
         // ... and in scan code (pack16), hence to_base_code(), which maps either code to the other
         const uint32_t d = to_base_code(~dd & dmask) & dmask;
         const uint32_t ia = d & ((1u << kBitsA) - 1), ib = d >> hi_shift;
-        image[ia >> 5] |= 1u << (ia & 31);
+        if (img == 2) image[Scan2::word_a(d)] |= 1u << Scan2::bit_a(d);
+        else image[ia >> 5] |= 1u << (ia & 31);
         image[kWordsA + (ib >> 5)] |= 1u << (ib & 31);
     };
     for (uint32_t key : sel_key) {
@@ -656,7 +719,7 @@ int rk_filter_create(rk_ctx *ctx, const rk_params *p, const int32_t *shuffled_di
         set_bits(revcomp_dim(key));
     }
     if (exact) {
-        uint32_t *keys = image.data() + kWordsA + kWordsB;
+        uint32_t *keys = image.data() + kWordsA + (1u << kBitsB) / 32;
         uint16_t *vals = reinterpret_cast<uint16_t *>(keys + kExactSlots);
         for (uint32_t i = 0; i < kExactSlots; i++) keys[i] = kEmptyKey;
         for (size_t i = 0; i < sel_key.size(); i++) {
@@ -905,9 +968,29 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
         if (((gend[g] - gbeg[g] + 1023) >> 10) > 0x7FFFFFFFULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "genome %u is too long", g);
         total_blocks += (gend[g] - gbeg[g] + 1023) >> 10;
     }
-    // aim for >= 4 rounds of 16 chunks per CU (256 CUs x 16 waves), 16..256 blocks each
-    uint64_t cb = total_blocks / ((uint64_t)ctx->num_cu * 16 * 4 + 1);
-    cb = std::min<uint64_t>(256, std::max<uint64_t>(16, cb));
+    // Chunk length: the smallest for which there are at most two chunks per wave (2 workgroups of 16 waves per CU).
+    // The waves run at the same speed, so the kernel lasts ceil(chunks / waves) chunks whatever the order they are
+    // handed out in: 2.4 chunks per wave cost three rounds (measured: 32 blocks 0.242 ms, 38 blocks 0.211 ms on
+    // 128 x 5 Mb); and a chunk has a fixed cost (its genome's row, the 32 bases before it, the last partial rounds
+    // of its queues), so more and shorter chunks are slower too (20 blocks: 0.245 ms).
+    auto chunks_for = [&](uint64_t len) {
+        uint64_t n = 0;
+        for (uint32_t g = 0; g < n_genomes; g++) n += ((gend[g] - gbeg[g] + 1023) / 1024 + len - 1) / len;
+        return n;
+    };
+    const uint64_t wave_slots = (uint64_t)ctx->num_cu * 2 * kWavesPerBlock;
+    uint64_t cb = 16;
+    if (chunks_for(cb) > 2 * wave_slots) {
+        uint64_t hi = std::max<uint64_t>(32, total_blocks);  // one chunk per genome at most: <= n_genomes... grows until it fits
+        while (chunks_for(hi) > 2 * wave_slots && hi < (1ULL << 31)) hi *= 2;
+        uint64_t lo = cb;  // chunks_for(lo) > limit >= chunks_for(hi)
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (chunks_for(mid) > 2 * wave_slots) lo = mid; else hi = mid;
+        }
+        cb = hi;
+    }
+    if (getenv("RK_SKETCH_CB")) cb = std::min<uint64_t>(1u << 20, std::max<uint64_t>(1, strtoull(getenv("RK_SKETCH_CB"), nullptr, 10)));
     std::vector<GenomeRow> rows((size_t)n_genomes + 1);
     uint64_t n_chunks64 = 0;
     for (uint32_t g = 0; g < n_genomes; g++) {
@@ -931,8 +1014,10 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
     char *pinned = static_cast<char *>(rk_pinned_scratch(ctx, std::max(rows_bytes, res_bytes)));
     if (!pinned) return rk_fail(ctx, RK_ERR_NOMEM, "cannot pin %llu bytes", (unsigned long long)std::max(rows_bytes, res_bytes));
     DevBuf<GenomeRow> d_rows(ctx);
+    DevBuf<ChunkDesc> d_chunks(ctx);
     DevBuf<char> d_res(ctx);  // tail | off | gcount (read back) | per-genome sketch sizes: cleared with ONE fill per pass
-    const size_t work_bytes = (res_bytes + (size_t)n_genomes * 4 + 15) & ~(size_t)15;
+    const size_t tickets_off = (res_bytes + (size_t)n_genomes * 4 + 127) & ~(size_t)127;
+    const size_t work_bytes = tickets_off + kTicketGroups * kTicketStride * 4;  // ... | the scan kernel's ticket counters
     RK_HIP(ctx, d_rows.alloc(rows.size()));
     RK_HIP(ctx, d_res.alloc(work_bytes));
     SketchTail *d_tail = reinterpret_cast<SketchTail *>(d_res.p);
@@ -988,7 +1073,7 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             a.table = f->d_table;
             a.tupmask = P.tupmask;
             a.dim_bits = 4 * P.half_subk;
-            a.hi_shift = std::max(0, 4 * P.half_subk - (f->img ? Img<1>::kBitsB : Img<0>::kBitsB));
+            a.hi_shift = std::max(0, 4 * P.half_subk - (f->img ? Img<1>::kBitsB : Img<0>::kBitsB));  // unused by the two-stage scan
             a.undomask0 = P.undomask0;
             a.undomask1 = P.undomask1;
             a.kmer = (int32_t)P.kmer_size;
@@ -1003,7 +1088,14 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             const uint32_t want = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
             // persistent: one workgroup per CU (the 156 KiB LDS image admits only one), each
             // striding over the chunks, so the filter image is staged once per CU
-            const uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu * (f->img ? 2u : 1u));
+            uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu * (f->img ? 2u : 1u));
+            RK_HIP(ctx, d_chunks.alloc(n_chunks));
+            hipLaunchKernelGGL(k_chunk_table, dim3(blocks_for(n_chunks)), dim3(256), 0, stream, d_rows.p, n_genomes, n_chunks, (uint32_t)cb, d_chunks.p);
+            a.chunks = d_chunks.p;
+            a.n_groups = std::min(grid, kTicketGroups);
+            grid -= grid % a.n_groups;
+            a.tickets = reinterpret_cast<uint32_t *>(d_res.p + tickets_off);
+            if (!kern) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "no scan kernel for this parameter set");
             if (ctx->timing) RK_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kSketchThreads), 0, stream, a);
             if (ctx->timing) RK_HIP(ctx, hipEventRecord(ctx->ev[1], stream));

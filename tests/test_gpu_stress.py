@@ -75,16 +75,17 @@ def test_query_path_shapes():
     ctx.close()
 
 
-@pytest.mark.parametrize("img", [1, 0])
+@pytest.mark.parametrize("img", [2, 1, 0])
 def test_sketch_shapes(monkeypatch, img):
     """random genomes (IUPAC codes, lower case, N runs, empty and tiny records, many records) under several parameter
-    sets, with the default 64 KiB LDS image and with the 144 KiB one (RK_SKETCH_IMG=0): hash sets == oracle"""
+    sets, with the two-stage scan kernel (default; K10S6 and K8S5 have a compile-time variant, the rest falls back), with
+    rk_sketch_kernel's 64 KiB LDS image (RK_SKETCH_IMG=1) and with its 144 KiB one (RK_SKETCH_IMG=0): hash sets == oracle"""
     from test_gpu_parity import sketch_case
     monkeypatch.setenv("RK_SKETCH_IMG", str(img))
     ctx = capi.Context(0)
     rng = np.random.default_rng(900 + img)
     alphabet = np.frombuffer(b"ACGTACGTACGTACGTacgtNnRYKMSWBDHV-", dtype=np.uint8)
-    for k, s, l in [(10, 6, 3), (8, 5, 2), (7, 4, 1), (11, 6, 2), (12, 6, 3), (16, 6, 3)]:
+    for k, s, l in [(10, 6, 3), (8, 5, 2), (10, 7, 4), (7, 4, 1), (11, 6, 2), (12, 6, 3), (16, 6, 3)]:
         genomes = []
         for g in range(9):
             n = int([0, 1, 2 * k - 1, 2 * k, 2 * k + 1, 1023, 1024 + 2 * k, 33333, 150001][g])
@@ -94,4 +95,36 @@ def test_sketch_shapes(monkeypatch, img):
             cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=int(rng.integers(0, 6)))]))
             genomes.append((b, np.array(cuts, dtype=np.uint64)))
         sketch_case(ctx, k, s, l, genomes)
+    ctx.close()
+
+
+def test_sketch_packed_offsets_beyond_2_and_4_gib():
+    """rk_sketch_packed_dev on a 4.6 GB packed buffer: genomes whose byte offsets need bit 31 and bit 32 (the chunk
+    table carries 64-bit offsets; a sign-extended low word once sent a wave 16 EB away) -- hash sets == oracle"""
+    import torch
+    k, s, l = 10, 6, 3
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    ctx = capi.Context(0)
+    flt = ctx.filter(capi.params_init(k, s, l), table)
+    rng = np.random.default_rng(4321)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    total = 4_600_000_000 // 1024 * 1024
+    packed = torch.full((total,), ord("N"), dtype=torch.uint8, device="cuda")
+    mib = 1 << 20  # 2.5 MB each: two genomes straddle the 2 GiB and the 4 GiB offset, two start just beyond them
+    places = [0, (1 << 31) - mib, (1 << 31) + 8 * mib + 1024, (1 << 32) - mib, (1 << 32) + 8 * mib + 5 * 1024, total - 3 * mib]
+    genomes, gbeg, gend = [], [], []
+    for i, at in enumerate(places):
+        n = 2_500_000 + 1000 * i + 7
+        g = lut[rng.integers(0, 4, n)]
+        packed[at:at + n] = torch.from_numpy(g).cuda()
+        genomes.append(g)
+        gbeg.append(at)
+        gend.append(at + n)
+    torch.cuda.synchronize()
+    sk = ctx.sketch_packed_dev(flt, packed.data_ptr(), packed.numel(), np.array(gbeg, dtype=np.uint64), np.array(gend, dtype=np.uint64))
+    gh, goff = sk.download()
+    for i, g in enumerate(genomes):
+        want = ok.sketch_records(param, table, g, np.array([0, len(g)], dtype=np.uint64))
+        assert np.array_equal(gh[int(goff[i]):int(goff[i + 1])].astype(np.uint64), want), "genome %d" % i
+    del sk, packed
     ctx.close()
