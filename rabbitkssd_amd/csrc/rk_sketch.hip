@@ -108,6 +108,8 @@ struct SketchArgs {
     uint32_t *tickets;
     uint32_t n_groups;
     const struct ChunkDesc *chunks;  // one per chunk, written by k_chunk_table
+    uint32_t prio_turns;             // RK_SCAN2_PRIO (default 1): the workgroups of a CU alternate at issue priority
+    unsigned long long *trace;       // developer aid (RK_SCAN2_TRACE=file): eight words per wave, see tools/trace_scan.py
 };
 // where a chunk lies: the waves read this instead of searching the genome rows (seven dependent loads per chunk)
 struct ChunkDesc {
@@ -116,7 +118,7 @@ struct ChunkDesc {
     uint32_t gid;
 };
 static_assert(sizeof(ChunkDesc) == 16, "read as one uint4");
-constexpr uint32_t kTicketGroups = 64, kTicketStride = 32;  // counters, dwords between them
+constexpr uint32_t kTicketGroups = 32, kTicketStride = 32;  // counters, dwords between them
 
 // low 32 bits of the 96-bit string w2:w1:w0 shifted right by sh (0 <= sh < 96); with a compile-time sh this is one
 // v_alignbit_b32
@@ -182,18 +184,23 @@ __device__ inline uint32_t wave_shr1(uint32_t v, uint32_t lane0_val)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_val, (int)v, 0x138, 0xF, 0xF, false);
 }
 
-// the range of chunks workgroup blockIdx.x draws from (gridDim.x is a multiple of n_groups)
+// The range of chunks workgroup blockIdx.x draws from.  Workgroups 8q .. 8q+7 (one per XCD, in dispatch order) share
+// group q % n_groups, and with 512 workgroups on 32 groups so do both workgroups of a CU: neither the XCDs nor the two
+// workgroups of a CU advance at the same pace (per-wave trace, RK_SCAN2_TRACE), and a counter shared across them lets
+// the faster ones take more chunks.  gridDim.x is a multiple of 8 * n_groups, or n_groups is 1.
 struct ChunkRange {
     uint32_t first, next, hi;  // this wave's first chunk; ticket t stands for chunk next + t; end of the range
     uint32_t *counter;
 };
 __device__ inline ChunkRange chunk_range(const SketchArgs &a, uint32_t wave)
 {
-    const uint32_t g = blockIdx.x % a.n_groups, waves = gridDim.x / a.n_groups * kWavesPerBlock;
+    const uint32_t oct = blockIdx.x >> 3, g = oct % a.n_groups;
+    const uint32_t wgs = a.n_groups == 1 ? gridDim.x : gridDim.x / a.n_groups;                    // workgroups of a group
+    const uint32_t idx = a.n_groups == 1 ? blockIdx.x : oct / a.n_groups * 8 + (blockIdx.x & 7);  // mine among them
     const uint32_t lo = (uint32_t)((uint64_t)a.n_chunks * g / a.n_groups), hi = (uint32_t)((uint64_t)a.n_chunks * (g + 1) / a.n_groups);
     ChunkRange r;
-    r.first = min(hi, lo + blockIdx.x / a.n_groups * kWavesPerBlock + wave);
-    r.next = lo + waves;
+    r.first = min(hi, lo + idx * kWavesPerBlock + wave);
+    r.next = min(hi, lo + wgs * kWavesPerBlock);
     r.hi = hi;
     r.counter = a.tickets + (size_t)g * kTicketStride;
     return r;
@@ -653,10 +660,9 @@ typedef void (*sketch_kernel_t)(SketchArgs);
 sketch_kernel_t pick_kernel(int kmer, int out2, bool exact, int img)
 {
     if (img == 2) {  // the two-stage scan (rk_sketch_scan2.inc): compile-time parameter sets only
-        static const bool u2 = !getenv("RK_SCAN2_U2") || atoi(getenv("RK_SCAN2_U2")) != 0;
-        if (kmer == 20 && out2 == 8) return u2 ? rk_scan2_kernel<20, 8, true> : rk_scan2_kernel<20, 8, false>;  // K10 S6
-        if (kmer == 20 && out2 == 6) return rk_scan2_kernel<20, 6, true>;  // K10 S7
-        if (kmer == 16 && out2 == 6) return rk_scan2_kernel<16, 6, true>;  // K8 S5
+        if (kmer == 20 && out2 == 8) return rk_scan2_kernel<20, 8>;  // K10 S6
+        if (kmer == 20 && out2 == 6) return rk_scan2_kernel<20, 6>;  // K10 S7
+        if (kmer == 16 && out2 == 6) return rk_scan2_kernel<16, 6>;  // K8 S5
         return nullptr;
     }
 #define RK_SK(K, O) (img ? rk_sketch_kernel<K, O, false, 1> : (exact ? rk_sketch_kernel<K, O, true, 0> : rk_sketch_kernel<K, O, false, 0>))
@@ -1092,14 +1098,29 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             RK_HIP(ctx, d_chunks.alloc(n_chunks));
             hipLaunchKernelGGL(k_chunk_table, dim3(blocks_for(n_chunks)), dim3(256), 0, stream, d_rows.p, n_genomes, n_chunks, (uint32_t)cb, d_chunks.p);
             a.chunks = d_chunks.p;
-            a.n_groups = std::min(grid, kTicketGroups);
-            grid -= grid % a.n_groups;
+            a.n_groups = std::max(1u, std::min(grid / 16, kTicketGroups));
+            if (a.n_groups > 1) grid -= grid % (8 * a.n_groups);
             a.tickets = reinterpret_cast<uint32_t *>(d_res.p + tickets_off);
+            a.prio_turns = getenv("RK_SCAN2_PRIO") ? (uint32_t)atoi(getenv("RK_SCAN2_PRIO")) : 1u;
+            a.trace = nullptr;
+            DevBuf<unsigned long long> d_trace(ctx);
+            const char *trace_path = getenv("RK_SCAN2_TRACE");
+            if (trace_path && f->img == 2) {
+                RK_HIP(ctx, d_trace.alloc((size_t)grid * kWavesPerBlock * 8));
+                RK_HIP(ctx, hipMemsetAsync(d_trace.p, 0, (size_t)grid * kWavesPerBlock * 64, stream));
+                a.trace = d_trace.p;
+            }
             if (!kern) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "no scan kernel for this parameter set");
             if (ctx->timing) RK_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kSketchThreads), 0, stream, a);
             if (ctx->timing) RK_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
             RK_HIP(ctx, hipGetLastError());
+            if (a.trace) {
+                std::vector<unsigned long long> h((size_t)grid * kWavesPerBlock * 8);
+                RK_HIP(ctx, hipMemcpyAsync(h.data(), a.trace, h.size() * 8, hipMemcpyDeviceToHost, stream));
+                RK_HIP(ctx, hipStreamSynchronize(stream));
+                if (FILE *fp = fopen(trace_path, "wb")) { fwrite(h.data(), 8, h.size(), fp); fclose(fp); }
+            }
         }
         if (n_genomes) {
             // ---- per-genome dedup in LDS, sizes -> offsets, CSR placement: three launches, no host round trip
