@@ -405,8 +405,9 @@ def sketch_block(env, n_genomes, length, steps=5):
     dt = (time.time() - t0) / steps
     ctx.set_timing(False)
     kernel_ms = sum(kms) / len(kms)
-    # L3K10 variant of the scan kernel: the default 64 KiB LDS image, or the 144 KiB one behind RK_SKETCH_IMG=0
-    sk_kernel = "rk_sketch_kernel<20, 8, true, 0>" if os.environ.get("RK_SKETCH_IMG") == "0" else "rk_sketch_kernel<20, 8, false, 1>"
+    # L3K10 variant of the scan kernel: the two-stage scan (default), or rk_sketch_kernel with its 64 KiB / 144 KiB LDS image
+    sk_kernel = {"0": "rk_sketch_kernel<20, 8, true, 0>", "1": "rk_sketch_kernel<20, 8, false, 1>"}.get(
+        os.environ.get("RK_SKETCH_IMG", "2"), "rk_scan2_kernel<20, 8>")
     b_alg = windows * 1.001  # 1 B per k-mer window + 4 B per emitted hash
     achieved = b_alg / (kernel_ms * 1e-3) / 1e9
     out = {"kmers_per_s": windows / dt, "genomes": n_genomes, "genome_length": length, "kmers": int(windows),
@@ -416,8 +417,9 @@ def sketch_block(env, n_genomes, length, steps=5):
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": sk_kernel,
                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg,
-                        "limiter": "VALU issue (integer): 192 vector instructions per wave and 1,024 bases; 73 % of the SIMD cycles issue one, at 8 waves per SIMD "
-                                   "(profiles/r02_pmc_summary.csv, DESIGN.md 4.1)"}}
+                        "limiter": "vector issue and LDS together: 146 vector instructions and 16 random LDS reads (8 cycles each with bank "
+                                   "conflicts) per wave and 1,024 bases, 8 waves per SIMD; the waves are alive 75 % of the kernel's time "
+                                   "(uneven pace of the XCDs in the second half of a pass; profiles/r03_pmc_summary.csv, DESIGN.md 4.1)"}}
     pmc = load_pmc(sk_kernel, "pmc_traffic_sketch.json")
     if pmc and pmc.get("hbm_bytes_per_launch"):
         out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]

@@ -211,6 +211,7 @@ int rk_ctx_create(int device, rk_ctx **out)
     ctx->sw_dist_near = getenv("RK_DIST_NEAR") ? atoi(getenv("RK_DIST_NEAR")) != 0 : 1;
     if (getenv("RK_DIST_NEAR_UW")) ctx->sw_dist_near_uw = atoi(getenv("RK_DIST_NEAR_UW"));
     if (getenv("RK_DIST_NEAR_MIN")) ctx->sw_dist_near_min = std::max(1, atoi(getenv("RK_DIST_NEAR_MIN")));
+    if (getenv("RK_DIST_FB_SKIP")) ctx->sw_dist_fb_skip = atoi(getenv("RK_DIST_FB_SKIP")) != 0;
     ctx->sw_dist_debug = getenv("RK_DIST_DEBUG") ? atoi(getenv("RK_DIST_DEBUG")) : 0;
     if (getenv("RK_DIST_LDS_KB")) ctx->sw_dist_lds_kb = std::max(0, atoi(getenv("RK_DIST_LDS_KB")));
     ctx->sw_sketch_img = getenv("RK_SKETCH_IMG") ? std::min(2, std::max(0, atoi(getenv("RK_SKETCH_IMG")))) : 2;

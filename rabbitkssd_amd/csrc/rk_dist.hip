@@ -1165,15 +1165,50 @@ int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool de
 #undef RK_NEAR
             RK_HIP(ctx, hipGetLastError());
         }
-        // the rows whose far cells could be reportable (usually none): full counter rows, single rows, all columns
+        // the rows whose far cells could be reportable (usually none): full counter rows, single rows, all columns --
+        // unless a completed launch with these very options has shown the list to be empty (rk_internal.h, fb_state)
+        rk_index *mut = const_cast<rk_index *>(idx);
+        unsigned char key[sizeof mut->fb_key] = {0};
+        static_assert(sizeof(rk_dist_opts) + 1 <= sizeof key, "key holds the options and the report mode");
+        memcpy(key, o, sizeof(rk_dist_opts));
+        key[sizeof(rk_dist_opts)] = dense_mode ? 1 : 0;
+        bool skip = false, arm = false;
+        if (ctx->sw_dist_fb_skip && idx->h_fb_seen) {
+            std::lock_guard<std::mutex> lk(mut->lazy_mu);
+            if (memcmp(key, mut->fb_key, sizeof key) != 0) {
+                memcpy(mut->fb_key, key, sizeof key);
+                mut->fb_state = 0;
+            }
+            if (mut->fb_state == 1) {
+                const hipError_t qe = hipEventQuery((hipEvent_t)mut->fb_event);
+                if (qe == hipSuccess) mut->fb_state = *(volatile uint32_t *)idx->h_fb_seen == 0 ? 2 : 3;
+                else (void)hipGetLastError();  // hipErrorNotReady is sticky for hipGetLastError
+            }
+            skip = mut->fb_state == 2;
+            if (mut->fb_state == 0) {
+                if (!mut->fb_event) {
+                    hipEvent_t ev;
+                    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) mut->fb_event = ev;
+                    else (void)hipGetLastError();
+                }
+                arm = mut->fb_event != nullptr;
+            }
+        }
+        if (skip) return RK_OK;
         Plan fp;
         rk_dist_opts all = *o;
         all.row_first = 0;
         all.row_step = 1;
         rc = make_plan(ctx, idx, idx->n_ref, idx->max_src_size, &all, false, true, idx->n_ref, &fp, false);
         if (rc) return rc;
-        return launch_dist(ctx, idx, idx->d_selfrange, idx->d_self_off, idx->d_src_off, idx->n_ref, o, fp, hits_dev, cap, n_hits_dev,
-                           nullptr, stream, idx->d_fb);
+        rc = launch_dist(ctx, idx, idx->d_selfrange, idx->d_self_off, idx->d_src_off, idx->n_ref, o, fp, hits_dev, cap, n_hits_dev,
+                         nullptr, stream, idx->d_fb);
+        if (!rc && arm) {
+            std::lock_guard<std::mutex> lk(mut->lazy_mu);
+            if (mut->fb_state == 0 && memcmp(key, mut->fb_key, sizeof key) == 0 &&
+                hipEventRecord((hipEvent_t)mut->fb_event, stream) == hipSuccess) mut->fb_state = 1;
+        }
+        return rc;
     }
     std::vector<Plan> bands;
     int rc = plan_bands(ctx, idx, o, dense_mode, &bands);

@@ -655,6 +655,7 @@ void rk_index_free(rk_index *idx)
     rk_pool_free(ctx, idx->d_orig);
     rk_pool_free(ctx, idx->d_fb);
     if (idx->h_fb_seen) (void)hipHostFree(idx->h_fb_seen);
+    if (idx->fb_event) (void)hipEventDestroy((hipEvent_t)idx->fb_event);
     delete idx;
 }
 

@@ -46,6 +46,7 @@ struct rk_ctx {
     int sw_dist_band_min_rows = 3072;  // RK_DIST_BAND_MIN_ROWS: no band with fewer rows of the shard than this (tests: small collections in several bands)
     int sw_dist_near = 1;   // RK_DIST_NEAR=0: the self join always with full counter rows (rk_dist_kernel)
     int sw_dist_near_uw = 0;    // RK_DIST_NEAR_UW=1|2|4: waves that share a unit of the near-window kernel (default: by the launch's size)
+    int sw_dist_fb_skip = 1;   // RK_DIST_FB_SKIP=0: always launch the fallback pass of the near-window self join
     int sw_dist_near_min = 16;  // RK_DIST_NEAR_MIN: the near-window kernel is used when a reportable pair of the smallest sketch needs at least this count
     int sw_dist_debug = 0;  // RK_DIST_DEBUG=1: the bands of every self join on stderr
     int sw_dist_lds_kb = 0;  // RK_DIST_LDS_KB: plan as if a CU had this much LDS (tests: tiled bands at small sizes)
@@ -174,6 +175,13 @@ struct rk_index {
                                      // allocated on first use; one self join per index in flight at a time
     uint32_t *h_fb_seen = nullptr;   // page-locked host word: rows the last fallback launch found in the list (a hint for the next
                                      // launch's grid: an empty list is the rule, and an empty launch should be a small one)
+    // The fallback list of a self join is a function of the index and the options alone (the kernels are deterministic): once
+    // a launch with these options has COMPLETED (fb_event) with an empty list, later launches with the same options skip the
+    // empty fallback launch (3 us of a 15 us row shard).  fb_state: 0 nothing known for fb_key, 1 a launch is in flight,
+    // 2 known empty, 3 known non-empty.  Guarded by lazy_mu.
+    unsigned char fb_key[40] = {0};
+    int fb_state = 0;
+    void *fb_event = nullptr;        // hipEvent_t
     std::mutex lazy_mu;              // serialises the lazy builders (prefix directory, rank bitmap, list records, sum of
                                      // squares): two host threads may query one index
 };

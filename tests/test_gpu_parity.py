@@ -296,6 +296,13 @@ def test_near_window_self_join_and_its_fallback(monkeypatch, strains, n, m, D, m
         assert cc.dist_kernel_name(idx, None, 1, metric, 20, D).startswith("rk_near_kernel<%s, " % pair)
         assert_hits_equal(cc.dist_rows(idx, None, 1, metric, 20, D)[0], want)
         assert_hits_equal(cc.dist_rows(idx, None, 1, metric, 20, D)[0], want)      # again: the fallback list was reset
+        # and again: once a completed launch with these options has shown the list to be empty, the (empty) fallback launch is
+        # skipped -- and never when it was not empty; other options in between forget what was known
+        assert_hits_equal(cc.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+        other, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D * 0.5, threads=4)
+        assert_hits_equal(cc.dist_rows(idx, None, 1, metric, 20, D * 0.5)[0], other)
+        assert_hits_equal(cc.dist_rows(idx, None, 1, metric, 20, D * 0.5)[0], other)
+        assert_hits_equal(cc.dist_rows(idx, None, 1, metric, 20, D)[0], want)
         parts = [cc.dist_rows(idx, None, 1, metric, 20, D, row_first=r, row_step=3, row_block=16)[0] for r in range(3)]
         for r, p in enumerate(parts):
             assert np.all(idx.shard_of(p, 3, 16) == r)

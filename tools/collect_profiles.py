@@ -89,12 +89,12 @@ def main(tag, traffic_only=False):
               "index": sorted(glob.glob(os.path.join(OUT, "pmcI_*"))),
               "rq": sorted(glob.glob(os.path.join(OUT, "pmcQ_*"))),
               "sketch": sorted(glob.glob(os.path.join(OUT, "pmcSk_*")) + glob.glob(os.path.join(OUT, "pmcS_*"))),
-              "sketch_img0": sorted(glob.glob(os.path.join(OUT, "pmcS0_*")))}
+              "sketch_img1": sorted(glob.glob(os.path.join(OUT, "pmcS1_*")))}
     with open(os.path.join(PROF, tag + "_pmc_summary.csv"), "w") as o:
         o.write("# rocprofv3 --pmc <group> --kernel-include-regex <kernel> --kernel-trace -- python3 tools/prof_driver.py "
                 "{dist 10000 4 | dist_rq_dev 100000 1000 3 | sketch 128 5000000 | index 10000 3}; one group per pass (tools/pmc_pass.sh, "
-                "groups in tools/pmc_groups_*.txt); mean over launches (tools/pmc_summary.py).  Section sketch_img0 = the "
-                "144 KiB LDS image (RK_SKETCH_IMG=0, one workgroup per CU) for comparison with the default 64 KiB image\n"
+                "groups in tools/pmc_groups_*.txt); mean over launches (tools/pmc_summary.py).  Section sketch = the two-stage scan "
+                "kernel (default), sketch_img1 = rk_sketch_kernel with the 64 KiB LDS image (RK_SKETCH_IMG=1, round 2's default)\n"
                 "Section,Kernel,Counter,Launches,MeanValue\n")
         for sec, dirs in groups.items():
             for line in summary(dirs).splitlines():
@@ -124,7 +124,7 @@ def main(tag, traffic_only=False):
     # stream, corrected by the factor calibrated above (check: ~5.4 M uncovered slices x 8 B = 43 MB)
     t_d = traffic(groups["dist"], "rk_near_kernel", "pmc_traffic.json", "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X", 8)
     t_q = traffic(groups["rq"], "rk_distq_kernel", "pmc_traffic_rq.json", "dist 100,000 refs x 1,000 queries (tools/prof_driver.py dist_rq_dev), MI355X", 0)
-    t_s = traffic(groups["sketch"], "rk_sketch_kernel", "pmc_traffic_sketch.json", "sketch 128 x 5 Mb (tools/prof_driver.py sketch 128 5000000), MI355X", 16)
+    t_s = traffic(groups["sketch"], "rk_scan2_kernel", "pmc_traffic_sketch.json", "sketch 128 x 5 Mb (tools/prof_driver.py sketch 128 5000000), MI355X", 16)
     print("traffic dist %s rq %s sketch %s B/launch" % (t_d, t_q, t_s))
     if d:
         print("value %.4g %s, %.4f ms/step, contract frac %.3f, hbm frac %s" % (

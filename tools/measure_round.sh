@@ -11,8 +11,9 @@ for w in 4 8 16; do
 done
 tools/pmc_pass.sh pmcD rk_near_kernel dist 10000 4 < tools/pmc_groups_dist.txt || exit 1
 tools/pmc_pass.sh pmcQ rk_distq_kernel dist_rq_dev 100000 1000 3 < tools/pmc_groups_rq.txt || exit 1
-printf 'FETCH_SIZE\nWRITE_SIZE\nTCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum\n' | tools/pmc_pass.sh pmcSk rk_sketch_kernel sketch 128 5000000 || exit 1
-tools/pmc_pass.sh pmcS rk_sketch_kernel sketch 128 5000000 < tools/pmc_groups_sketch.txt || exit 1
+printf 'FETCH_SIZE\nWRITE_SIZE\nTCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum\n' | tools/pmc_pass.sh pmcSk rk_scan2_kernel sketch 128 5000000 || exit 1
+tools/pmc_pass.sh pmcS rk_scan2_kernel sketch 128 5000000 < tools/pmc_groups_sketch.txt || exit 1
+RK_SKETCH_IMG=1 tools/pmc_pass.sh pmcS1 rk_sketch_kernel sketch 128 5000000 < tools/pmc_groups_sketch.txt || exit 1
 head -3 tools/pmc_groups_sq.txt | tools/pmc_pass.sh pmcI "k_bucket_emit|k_part_scatter|k_part_hist" index 10000 3 || exit 1
 echo "counter passes done"
 python3 tools/collect_profiles.py $tag --traffic-only || exit 1
