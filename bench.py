@@ -313,6 +313,16 @@ def shard_rehearsal(env, index, n_genomes, steps=30):
         if S == 1:
             t1 = per[0]
         out[str(S)] = {"shard_ms": per, "slowest_ms": max(per), "predicted_efficiency": t1 / (S * max(per))}
+    # the floor of any shard: ONE block of 16 rows (8 units, 8 waves) -- a kernel launch plus one unit's chain of dependent loads
+    blocks = (n_genomes + shard.ROW_BLOCK - 1) // shard.ROW_BLOCK
+    counters = torch.zeros(steps + 3, dtype=torch.int64, device=env.dev)
+
+    def launch_one(i):
+        ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i,
+                          row_first=0, row_step=blocks, stream=env.stream.cuda_stream, row_block=shard.ROW_BLOCK)
+    _, ms, _ = timed_steps(env, launch_one, steps, 2)
+    out["floor"] = {"rows": shard.ROW_BLOCK, "ms": ms,
+                    "note": "one block of rows: a kernel launch + one unit's chain of dependent loads; no shard can be faster"}
     return out
 
 
