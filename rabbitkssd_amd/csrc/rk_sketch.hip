@@ -108,7 +108,7 @@ struct SketchArgs {
     uint32_t *tickets;
     uint32_t n_groups;
     const struct ChunkDesc *chunks;  // one per chunk, written by k_chunk_table
-    uint32_t prio_turns;             // RK_SCAN2_PRIO (default 1): the workgroups of a CU alternate at issue priority
+    uint32_t prio_turns;             // RK_SCAN2_PRIO: 2 (default) issue priority by progress within the workgroup, 1 the workgroups of a CU alternate, 0 none
     unsigned long long *trace;       // developer aid (RK_SCAN2_TRACE=file): eight words per wave, see tools/trace_scan.py
 };
 // where a chunk lies: the waves read this instead of searching the genome rows (seven dependent loads per chunk)
@@ -1101,7 +1101,7 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             a.n_groups = std::max(1u, std::min(grid / 16, kTicketGroups));
             if (a.n_groups > 1) grid -= grid % (8 * a.n_groups);
             a.tickets = reinterpret_cast<uint32_t *>(d_res.p + tickets_off);
-            a.prio_turns = getenv("RK_SCAN2_PRIO") ? (uint32_t)atoi(getenv("RK_SCAN2_PRIO")) : 1u;
+            a.prio_turns = getenv("RK_SCAN2_PRIO") ? (uint32_t)atoi(getenv("RK_SCAN2_PRIO")) : 2u;
             a.trace = nullptr;
             DevBuf<unsigned long long> d_trace(ctx);
             const char *trace_path = getenv("RK_SCAN2_TRACE");
