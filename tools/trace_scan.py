@@ -22,7 +22,7 @@ xcd = wg % 8
 print("per XCD end mean:", " ".join("%.0f" % e[xcd == x].mean() for x in range(8)))
 dr, fl, fr, nd = t[:, 4].astype(np.int64) / 100.0, t[:, 5].astype(np.int64) / 100.0, (t[:, 6].astype(np.int64) - base) / 100.0, t[:, 7].astype(np.int64)
 print("time in drains of the second queue: mean %.1f us per wave (%.1f drains, %.2f us each); in the run-end flushes (incl. their drains): mean %.1f us" % (dr.mean(), nd.mean(), dr.sum() / max(1, nd.sum()), fl.mean()))
-print("end of the first run: p10 %.1f p50 %.1f p90 %.1f us" % tuple(np.percentile(fr, [10, 50, 90])))
+print("end of the chunk loop (before the last drain): p10 %.1f p50 %.1f p90 %.1f us; last drain: mean %.1f us, p90 %.1f, max %.1f" % (tuple(np.percentile(fr, [10, 50, 90])) + ((e - fr).mean(), np.percentile(e - fr, 90), (e - fr).max())))
 for x in range(8):
     m = xcd == x
-    print("xcd %d: end p50 %.0f, first run end p50 %.0f, drains %.1f us, flushes %.1f us, blocks %.1f" % (x, np.median(e[m]), np.median(fr[m]), dr[m].mean(), fl[m].mean(), bl[m].mean()))
+    print("xcd %d: end p50 %.0f, loop end p50 %.0f, drains %.1f us, flushes %.1f us, blocks %.1f" % (x, np.median(e[m]), np.median(fr[m]), dr[m].mean(), fl[m].mean(), bl[m].mean()))
