@@ -974,28 +974,15 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
         if (((gend[g] - gbeg[g] + 1023) >> 10) > 0x7FFFFFFFULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "genome %u is too long", g);
         total_blocks += (gend[g] - gbeg[g] + 1023) >> 10;
     }
-    // Chunk length: the smallest for which there are at most two chunks per wave (2 workgroups of 16 waves per CU).
+    // Chunk length: (nearly) the smallest for which there are at most two chunks per wave (2 workgroups of 16 waves per CU).
     // The waves run at the same speed, so the kernel lasts ceil(chunks / waves) chunks whatever the order they are
     // handed out in: 2.4 chunks per wave cost three rounds (measured: 32 blocks 0.242 ms, 38 blocks 0.211 ms on
     // 128 x 5 Mb); and a chunk has a fixed cost (its genome's row, the 32 bases before it, the last partial rounds
     // of its queues), so more and shorter chunks are slower too (20 blocks: 0.245 ms).
-    auto chunks_for = [&](uint64_t len) {
-        uint64_t n = 0;
-        for (uint32_t g = 0; g < n_genomes; g++) n += ((gend[g] - gbeg[g] + 1023) / 1024 + len - 1) / len;
-        return n;
-    };
-    const uint64_t wave_slots = (uint64_t)ctx->num_cu * 2 * kWavesPerBlock;
-    uint64_t cb = 16;
-    if (chunks_for(cb) > 2 * wave_slots) {
-        uint64_t hi = std::max<uint64_t>(32, total_blocks);  // one chunk per genome at most: <= n_genomes... grows until it fits
-        while (chunks_for(hi) > 2 * wave_slots && hi < (1ULL << 31)) hi *= 2;
-        uint64_t lo = cb;  // chunks_for(lo) > limit >= chunks_for(hi)
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) / 2;
-            if (chunks_for(mid) > 2 * wave_slots) lo = mid; else hi = mid;
-        }
-        cb = hi;
-    }
+    // (a genome adds at most one partial chunk: total / len + n_genomes bounds the count from above)
+    const uint64_t wave_slots = (uint64_t)ctx->num_cu * 2 * kWavesPerBlock, limit = 2 * wave_slots;
+    uint64_t cb = n_genomes < limit ? (total_blocks + (limit - n_genomes) - 1) / (limit - n_genomes) : (total_blocks + limit - 1) / limit;
+    cb = std::min<uint64_t>(1u << 20, std::max<uint64_t>(16, cb));
     if (getenv("RK_SKETCH_CB")) cb = std::min<uint64_t>(1u << 20, std::max<uint64_t>(1, strtoull(getenv("RK_SKETCH_CB"), nullptr, 10)));
     std::vector<GenomeRow> rows((size_t)n_genomes + 1);
     uint64_t n_chunks64 = 0;
