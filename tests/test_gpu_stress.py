@@ -128,3 +128,33 @@ def test_sketch_packed_offsets_beyond_2_and_4_gib():
         assert np.array_equal(gh[int(goff[i]):int(goff[i + 1])].astype(np.uint64), want), "genome %d" % i
     del sk, packed
     ctx.close()
+
+
+@pytest.mark.parametrize("k,s,l", [(10, 6, 3), (10, 7, 4), (8, 5, 2)])
+def test_sketch_sequences_dense_in_selected_windows(k, s, l):
+    """genomes built FROM selected k-mers (every 2k-th window passes both bitmaps of the scan kernel, 50x the density of a
+    random genome), poly-A and short tandem repeats: the queues of the scan kernel overflow in every block and its
+    in-place path runs; hash sets and window counts == oracle"""
+    from test_gpu_parity import sketch_case
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    sel = np.nonzero((table >= param.dim_start) & (table < param.dim_end))[0]
+    rng = np.random.default_rng(77 + k + s)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)          # BaseMap codes (src/common.h:27-37)
+    inner, outer = 2 * s, k - s
+    n_kmers = 40_000
+    d = sel[rng.integers(0, len(sel), n_kmers)].astype(np.uint64)
+    shifts = (2 * (inner - 1 - np.arange(inner))).astype(np.uint64)   # first inner base in the high bits
+    inner_codes = ((d[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.uint8)
+    kmers = np.concatenate([rng.integers(0, 4, (n_kmers, outer), dtype=np.uint8), inner_codes,
+                            rng.integers(0, 4, (n_kmers, outer), dtype=np.uint8)], axis=1)
+    dense = lut[kmers.reshape(-1)]
+    genomes = [(dense, np.array([0, len(dense)], dtype=np.uint64)),
+               (np.full(300_000, ord("A"), dtype=np.uint8), np.array([0, 300_000], dtype=np.uint64)),
+               (np.tile(np.frombuffer(b"ACGTTGCAAC", dtype=np.uint8), 40_000), np.array([0, 150_000, 400_000], dtype=np.uint64)),
+               (np.concatenate([dense[:100_000], np.full(50, ord("N"), dtype=np.uint8), dense[100_000:300_000]]),
+                np.array([0, 300_050], dtype=np.uint64))]
+    want = ok.sketch_records(param, table, dense, genomes[0][1])
+    assert len(want) > 200, "the construction must hit selected windows (%d hashes)" % len(want)
+    ctx = capi.Context(0)
+    sketch_case(ctx, k, s, l, genomes)
+    ctx.close()
