@@ -844,6 +844,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         fa.low_bits = low_bits;
         fa.gb = gb;
         fa.rb = rb;
+        fa.xcd_map = getenv("RK_INDEX_XCD") ? atoi(getenv("RK_INDEX_XCD")) : 1;
         fa.nb = 1u << B;
         fa.n_chunks = (uint32_t)((H + kPartChunk - 1) / kPartChunk);
         DevBuf<uint32_t> chunk_first(ctx), matrix(ctx), total(ctx), bstart(ctx), ucount(ctx), ubase(ctx), tmp_uhash(ctx), tmp_upos(ctx), n_open(ctx), n_cov(ctx);
@@ -885,6 +886,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         ea.ucount = ucount.p;
         ea.self_raw = self_raw.p;
         ea.res = res.p;
+        ea.xcd_map = fa.xcd_map;
         ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
         if (ea.debug) {  // developer ablations leave stages out: whatever they do not write must still be harmless downstream
             RK_HIP(ctx, hipMemsetAsync(ucount.p, 0, (size_t)fa.nb * 4, st));
