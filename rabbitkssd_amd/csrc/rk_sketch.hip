@@ -1079,8 +1079,8 @@ int rk_sketch_packed_dev_ex(rk_ctx *ctx, const rk_filter *f, const uint8_t *pack
             a.gcount = d_gcount;
             a.n_windows = &d_tail->windows;
             const uint32_t want = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
-            // persistent: one workgroup per CU (the 156 KiB LDS image admits only one), each
-            // striding over the chunks, so the filter image is staged once per CU
+            // persistent: as many workgroups as the LDS image admits per CU (two; one with the 144 KiB image), the filter
+            // image staged once per workgroup; chunks by table and ticket (chunk_range)
             uint32_t grid = std::min<uint32_t>(want, (uint32_t)ctx->num_cu * (f->img ? 2u : 1u));
             RK_HIP(ctx, d_chunks.alloc(n_chunks));
             hipLaunchKernelGGL(k_chunk_table, dim3(blocks_for(n_chunks)), dim3(256), 0, stream, d_rows.p, n_genomes, n_chunks, (uint32_t)cb, d_chunks.p);
