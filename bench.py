@@ -781,7 +781,11 @@ def main():
                    "postings_streamed_T": head["postings_streamed_T"], "hits": head["hits"], "max_dist": MAX_DIST,
                    "slice_records": head["slice_records"], "compact_share": head["compact_share"],
                    "records_walked_per_launch": head["records_walked"],
-                   "sharding": "query rows in blocks of 16 dealt round-robin to %d rank(s); index broadcast once (RCCL on GPUs)" % world},
+                   "sharding": "query rows in blocks of 16 dealt round-robin to %d rank(s); index broadcast once (RCCL on GPUs)" % world,
+                   "step": "one rk_dist_rows_dev call: rk_near_kernel counts and evaluates every pair of the launch; its exact "
+                           "fallback pass (rows whose far cells could be reportable) is launched until a completed launch with "
+                           "the same options has shown that list to be empty -- here after the warm-up -- and skipped from then on "
+                           "(RK_DIST_FB_SKIP=0 launches it always: +3 us per step)"},
         "roofline": dist_roofline(head, "pmc_traffic.json" if world == 1 else None),
         # second headline: what an alldist costs when the index is NOT there yet -- sketches resident in HBM -> hits in HBM
         "build_plus_dist": {
