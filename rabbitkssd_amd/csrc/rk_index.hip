@@ -871,7 +871,20 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         hipLaunchKernelGGL(k_part_hist, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, res.p);
         hipLaunchKernelGGL(k_part_colscan, dim3((fa.nb + 63) / 64), dim3(1024), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
         hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart.p, res.p);
-        hipLaunchKernelGGL(k_part_scatter, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
+        // the partition itself: two coalescing passes (rk_index_fast.inc), or one scattering pass
+        const bool part2 = (getenv("RK_INDEX_PART2") ? atoi(getenv("RK_INDEX_PART2")) != 0 : true) && B >= 7 && low_bits + gb + rb <= 64 - (int)kFineBits;
+        DevBuf<unsigned long long> mid(ctx);
+        DevBuf<uint32_t> fine_cursor(ctx);
+        if (part2) {
+            RK_HIP(ctx, mid.alloc(H));
+            RK_HIP(ctx, fine_cursor.alloc(fa.nb));
+            RK_HIP(ctx, hipMemsetAsync(fine_cursor.p, 0, (size_t)fa.nb * 4, st));
+            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPart2Lds));
+            hipLaunchKernelGGL(k_part_coarse, dim3(fa.n_chunks), dim3(kPartThreads), kPart2Lds, st, fa, chunk_first.p, matrix.p, bstart.p, mid.p);
+            hipLaunchKernelGGL(k_part_fine, dim3(fa.nb >> kFineBits, 16), dim3(kPartThreads), 0, st, fa, bstart.p, mid.p, keys.p, fine_cursor.p);
+        } else {
+            hipLaunchKernelGGL(k_part_scatter, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
+        }
         EmitArgs ea;
         ea.keys = keys.p;
         ea.bstart = bstart.p;

@@ -257,6 +257,27 @@ def test_genome_order_does_not_matter(ctx, mode):
     assert ctx.dist_rows(idx2, None, 1, 0, 20, 0.05)[0].tobytes() == full.tobytes()
 
 
+@pytest.mark.parametrize("n,m,bits", [(3000, 700, 28), (20000, 90, 26), (150, 60, 24)])
+def test_index_partition_in_one_pass_and_in_two_gives_the_same_index(ctx, monkeypatch, n, m, bits):
+    # the bucket partition of the fast build: two coalescing passes (default; needs >= 128 buckets and six spare key bits)
+    # or one scattering pass (RK_INDEX_PART2=0), with and without the XCD-contiguous workgroup mapping: the exported
+    # .dict/.index payloads must be the oracle's in every combination, and so must the hits
+    names, h, off = synth.clade_sketches(n, m, bits, seed=300 + n)
+    postings, counts = ok.index_build32(h, off, bits)
+    hits = None
+    for part2, xcd in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("RK_INDEX_PART2", part2)
+        monkeypatch.setenv("RK_INDEX_XCD", xcd)
+        idx = ctx.index_build(ctx.sketches_from_host(h, off), bits)
+        assert idx.built_fast
+        p2, c2 = idx.export()
+        assert np.array_equal(p2, postings) and np.array_equal(c2, counts)
+        got = ctx.dist_rows(idx, None, 1, 0, 20, 0.05)[0].tobytes()
+        assert hits is None or got == hits
+        hits = got
+        del idx
+
+
 def test_index_without_renumbering_gives_the_same_results(monkeypatch):
     names, h, off = synth.clade_sketches(900, 150, 24, seed=62)
     names, h, off = synth.permute_genomes(names, h, off, synth.genome_order(900, "shuffled", seed=4))
