@@ -874,13 +874,23 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         // the partition itself: two coalescing passes (rk_index_fast.inc), or one scattering pass
         const bool part2 = (getenv("RK_INDEX_PART2") ? atoi(getenv("RK_INDEX_PART2")) != 0 : true) && B >= 7 && low_bits + gb + rb <= 64 - (int)kFineBits;
         DevBuf<unsigned long long> mid(ctx);
-        DevBuf<uint32_t> fine_cursor(ctx);
+        DevBuf<uint32_t> fine_cursor(ctx), seg_taken(ctx);
         if (part2) {
             RK_HIP(ctx, mid.alloc(H));
             RK_HIP(ctx, fine_cursor.alloc(fa.nb));
             RK_HIP(ctx, hipMemsetAsync(fine_cursor.p, 0, (size_t)fa.nb * 4, st));
-            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_coarse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPart2Lds));
-            hipLaunchKernelGGL(k_part_coarse, dim3(fa.n_chunks), dim3(kPartThreads), kPart2Lds, st, fa, chunk_first.p, matrix.p, bstart.p, mid.p);
+            const bool small_wgs = (fa.nb >> kFineBits) <= 128;   // several workgroups per chunk: they share its stretch through counters
+            RK_HIP(ctx, seg_taken.alloc(small_wgs ? (size_t)fa.n_chunks * (fa.nb >> kFineBits) : 1));
+            if (small_wgs) RK_HIP(ctx, hipMemsetAsync(seg_taken.p, 0, (size_t)fa.n_chunks * (fa.nb >> kFineBits) * 4, st));
+            if (small_wgs) {
+                RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_coarse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds(256)));
+                hipLaunchKernelGGL(k_part_coarse<256>, dim3(fa.n_chunks * 4), dim3(256), part2_lds(256), st, fa, chunk_first.p, matrix.p, bstart.p,
+                                   seg_taken.p, mid.p);
+            } else {
+                RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_coarse<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds(1024)));
+                hipLaunchKernelGGL(k_part_coarse<1024>, dim3(fa.n_chunks), dim3(1024), part2_lds(1024), st, fa, chunk_first.p, matrix.p, bstart.p,
+                                   seg_taken.p, mid.p);
+            }
             hipLaunchKernelGGL(k_part_fine, dim3(fa.nb >> kFineBits, 16), dim3(kPartThreads), 0, st, fa, bstart.p, mid.p, keys.p, fine_cursor.p);
         } else {
             hipLaunchKernelGGL(k_part_scatter, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
