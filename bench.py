@@ -163,6 +163,15 @@ class Env:
         return box[0], box[1]
 
 
+def spread_steps(steps):
+    return min(steps, 50)
+
+
+def counter_slots(steps, warmup):
+    """one zeroed u64 hit counter per launch of timed_steps: warm-up, timed stretch, per-step spread stretch"""
+    return warmup + steps + spread_steps(steps) + 1
+
+
 def timed_steps(env, launch, steps, warmup):
     """W untimed + K timed launches on env.stream, barrier + synchronize on both sides; returns
     (wall seconds max over ranks, mean kernel ms by HIP events on the launch stream, per-step ms [min, median, max]).
@@ -181,11 +190,11 @@ def timed_steps(env, launch, steps, warmup):
         ev1.record(env.stream)
         env.fence()
         elapsed = time.perf_counter() - t0
-        n = min(steps, 50)
+        n = spread_steps(steps)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
         evs[0].record(env.stream)
         for i in range(n):
-            launch(warmup + i)
+            launch(warmup + steps + i)   # (slots of their own: a launch ADDS its hits to its counter slot)
             evs[i + 1].record(env.stream)
         env.fence()
     per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
@@ -240,14 +249,17 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
     H, T = index.total, index.sum_sq
     hits_cap = 1 << 20
     hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=env.dev)
-    counters = torch.zeros(steps + warmup + 1, dtype=torch.int64, device=env.dev)
+    counters = torch.zeros(counter_slots(steps, warmup), dtype=torch.int64, device=env.dev)
 
     def launch(i):
         ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i,
                           row_first=rank, row_step=world, stream=env.stream.cuda_stream, row_block=shard.ROW_BLOCK)
 
     elapsed, kernel_ms, spread = timed_steps(env, launch, steps, warmup)
-    my_hits = int(counters[warmup].item())
+    per_launch = counters[:warmup + steps + spread_steps(steps)].cpu().numpy()
+    my_hits = int(per_launch[warmup + steps - 1])   # the last timed launch
+    if not (per_launch == my_hits).all():
+        sys.exit("bench.py: launches of the same shard reported different hit counts: %s" % sorted(set(per_launch.tolist())))
     tot_hits = env.sum_over_ranks(my_hits)
     kernel = ctx.dist_kernel_name(index, None, 1, 0, KMER, MAX_DIST, row_first=rank, row_step=world, row_block=shard.ROW_BLOCK)
     pairs = None
@@ -303,7 +315,7 @@ def shard_rehearsal(env, index, n_genomes, steps=30):
     for S in (1, 2, 4, 8):
         per = []
         for r in range(S):
-            counters = torch.zeros(steps + 3, dtype=torch.int64, device=env.dev)
+            counters = torch.zeros(counter_slots(steps, 2), dtype=torch.int64, device=env.dev)
 
             def launch(i, r=r, S=S, counters=counters):
                 ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i,
@@ -315,7 +327,7 @@ def shard_rehearsal(env, index, n_genomes, steps=30):
         out[str(S)] = {"shard_ms": per, "slowest_ms": max(per), "predicted_efficiency": t1 / (S * max(per))}
     # the floor of any shard: ONE block of 16 rows (8 units, 8 waves) -- a kernel launch plus one unit's chain of dependent loads
     blocks = (n_genomes + shard.ROW_BLOCK - 1) // shard.ROW_BLOCK
-    counters = torch.zeros(steps + 3, dtype=torch.int64, device=env.dev)
+    counters = torch.zeros(counter_slots(steps, 2), dtype=torch.int64, device=env.dev)
 
     def launch_one(i):
         ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i,
@@ -343,7 +355,7 @@ def dist_rq_block(env, n_ref=100000, n_query=1000, steps=20, warmup=3, keep=None
     qs = ctx.sketches_from_host(qh, qoff)
     hits_cap = 1 << 20
     hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=env.dev)
-    counters = torch.zeros(steps + warmup + 1, dtype=torch.int64, device=env.dev)
+    counters = torch.zeros(counter_slots(steps, warmup), dtype=torch.int64, device=env.dev)
     per_rank = (n_query + world - 1) // world  # contiguous query blocks
 
     def launch(i):
@@ -351,7 +363,7 @@ def dist_rq_block(env, n_ref=100000, n_query=1000, steps=20, warmup=3, keep=None
                           row_first=rank, row_step=world, row_block=per_rank, stream=env.stream.cuda_stream, queries=qs)
 
     elapsed, kernel_ms, spread = timed_steps(env, launch, steps, warmup)
-    tot_hits = env.sum_over_ranks(int(counters[warmup].item()))
+    tot_hits = env.sum_over_ranks(int(counters[warmup + steps - 1].item()))
     if rank != 0:
         return None
     if keep is not None:
@@ -619,7 +631,8 @@ def alldist_cpu_and_cli(keep, n_pairs):
         t = time.time() - t0
         res = {"value": n_pairs / t, "unit": "genome-pairs/s", "cores": cores, "kind": "port",
                "sample": "full workload: %d sketches, %d pairs, -D %g, %d threads; oracle port incl. 2^28 prefix sum %.3f s "
-                         "(index build %.3f s not counted); %d hits" % (n, n_pairs, MAX_DIST, cores, t, t_build, len(hits))}
+                         "(index build %.3f s not counted); %d hits" % (n, n_pairs, MAX_DIST, cores, t, t_build, len(hits)),
+               "hits": int(len(hits))}
     return res, cli
 
 
@@ -830,6 +843,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cb, cli = alldist_cpu_and_cli(keep, n_pairs)
         out["cpu_baseline"] = cb
+        if cb.get("hits") is not None and cb["hits"] != head["hits"]:
+            print(json.dumps(out), flush=True)
+            sys.exit("bench.py: the GPU reports %d hits, the CPU baseline %d" % (head["hits"], cb["hits"]))
         if cb.get("wall_pairs_per_s"):
             cb["gpu_kernel_vs_cpu_distance_loop"] = out["value"] / cb["value"]
             cb["gpu_api_vs_cpu_wall"] = (n_pairs / t_host_inclusive) / cb["wall_pairs_per_s"]

@@ -40,27 +40,58 @@ def clade_genome_set(n_genomes, length, strains_per_clade=10):
     return out
 
 
-def clade_sketches(n_genomes, m, hash_bits, kmer_size=20, strains_per_clade=10, seed=20261003):
+def strain_rates(s):
+    """Per-level substitution rates of strain `s` of a clade (species).  Up to 10 strains: the SURVEY 8d model, strain s
+    differs from the ancestor by 0.002 s.  Wider clades are a tree: s = 100 a + 10 b + c is strain c of sub-lineage b of
+    lineage a; a lineage differs from the ancestor by 0.026, a sub-lineage from its lineage by 0.006, a strain from its
+    sub-lineage by 0.001 c.  Mash distances: inside a sub-lineage <= 0.018, inside a lineage 0.012-0.030 (all reportable
+    at -D 0.05), across lineages >= 0.064 (never reportable, yet such pairs still share ~28 % of their hashes)."""
+    a, b, c = s // 100, (s // 10) % 10, s % 10
+    return a, b, c
+
+
+def clade_sketches(n_genomes, m, hash_bits, kmer_size=20, strains_per_clade=10, seed=20261003, tiny=0, tiny_size=40):
     """Sketch-level generator: per clade draw `m` distinct uniform values in
     [0, 2^hash_bits); strain s keeps each with probability (1-0.002 s)^kmer_size and
     replaces the rest with fresh uniform values; per-genome sets are deduplicated and
-    returned SORTED.  Returns (names, hashes uint32[H], off uint64[N+1])."""
+    returned SORTED.  Returns (names, hashes uint32[H], off uint64[N+1]).
+    strains_per_clade > 10: a species tree of lineages / sub-lineages / strains (strain_rates).
+    tiny: that many extra sketches of `tiny_size` hashes (plasmids, small contigs) are spread over the collection; each is a
+    random subset of one clade ancestor (so it has relatives and reportable pairs under containment)."""
     rng = np.random.default_rng(seed)
     space = 1 << hash_bits
     names, parts = [], []
     anc = None
+    wide = strains_per_clade > 10
+
+    def mutate(src, rate):
+        keep = rng.random(len(src)) < (1.0 - rate) ** kmer_size
+        fresh = rng.integers(0, space, size=len(src), dtype=np.uint64)
+        return np.where(keep, src, fresh)
+
+    lineage = sub = None
     for g in range(n_genomes):
         c, s = divmod(g, strains_per_clade)
         if s == 0:
             anc = np.unique(rng.integers(0, space, size=m + m // 8, dtype=np.uint64))
             rng.shuffle(anc)
             anc = anc[:m]
-        keep = rng.random(len(anc)) < (1.0 - 0.002 * s) ** kmer_size
-        fresh = rng.integers(0, space, size=len(anc), dtype=np.uint64)
-        h = np.unique(np.where(keep, anc, fresh)).astype(np.uint32)
-        parts.append(h)
+        if not wide:
+            h = mutate(anc, 0.002 * s)
+        else:
+            a, b, cc = strain_rates(s)
+            if s % 100 == 0:
+                lineage = mutate(anc, 0.026)
+            if s % 10 == 0:
+                sub = mutate(lineage, 0.006)
+            h = mutate(sub, 0.001 * cc)
+        parts.append(np.unique(h).astype(np.uint32))
         names.append("syn/c%04d_s%d.fna" % (c, s))
-    off = np.zeros(n_genomes + 1, dtype=np.uint64)
+        if tiny and (g + 1) % max(1, n_genomes // tiny) == 0 and len(names) - (g + 1) < tiny:
+            t = np.unique(anc[rng.permutation(len(anc))[:tiny_size]]).astype(np.uint32)
+            parts.append(t)
+            names.append("syn/tiny%04d.fna" % (len(names) - (g + 1)))
+    off = np.zeros(len(parts) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(p) for p in parts])
     hashes = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32)
     return names, hashes, off

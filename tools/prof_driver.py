@@ -37,19 +37,21 @@ def sketch(n_genomes=128, length=5_000_000, steps=3):
         print("sketch pass %.3f ms (scan kernel %.4f ms), %d windows, %d hashes" % ((time.time() - t0) * 1e3, ctx.last_ms(0), sk.windows, sk.total))
 
 
-def dist(n_genomes=10000, steps=5, row_step=1, row_block=0, order=0):
-    """order: 0 as generated (clade members adjacent), 1 random permutation of the genome ids, 2 completion-order jitter"""
+def dist(n_genomes=10000, steps=5, row_step=1, row_block=0, order=0, clade=10, tiny=0, metric=0):
+    """order: 0 as generated (clade members adjacent), 1 random permutation of the genome ids, 2 completion-order jitter;
+    clade: strains per clade (> 10: the species tree of synth.strain_rates); tiny: extra 40-hash sketches"""
     ctx = capi.Context(0)
-    names, hashes, off = synth.clade_sketches(n_genomes, 1220, 28)
+    names, hashes, off = synth.clade_sketches(n_genomes, 1220, 28, strains_per_clade=clade, tiny=tiny)
+    n_genomes = len(names)
     if order:
         names, hashes, off = synth.permute_genomes(names, hashes, off, synth.genome_order(n_genomes, ["sorted", "shuffled", "jitter"][order]))
     index = ctx.index_build(ctx.sketches_from_host(hashes, off), 28)
-    hits = torch.empty((1 << 20) * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    hits = torch.empty((1 << 23) * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
     counters = torch.zeros(steps + 1, dtype=torch.int64, device="cuda")
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         def launch(i):
-            ctx.dist_rows_dev(index, 1, 0, 20, 0.05, hits.data_ptr(), 1 << 20, counters.data_ptr() + 8 * i,
+            ctx.dist_rows_dev(index, 1, metric, 20, 0.05, hits.data_ptr(), 1 << 23, counters.data_ptr() + 8 * i,
                               row_first=0, row_step=row_step, row_block=row_block, stream=stream.cuda_stream)
         launch(steps)  # warm-up
         torch.cuda.synchronize()
@@ -61,9 +63,9 @@ def dist(n_genomes=10000, steps=5, row_step=1, row_block=0, order=0):
         ev1.record(stream)
         t_host = time.time() - t0   # time the host needed to enqueue everything
         torch.cuda.synchronize()
-    print("dist %.4f ms/step (events; host enqueue %.3f ms/step), hits %d (row_step %d, row_block %d, order %d) %s" % (
-        ev0.elapsed_time(ev1) / steps, t_host * 1e3 / steps, int(counters[0].item()), row_step, row_block, order,
-        ctx.dist_kernel_name(index, None, 1, 0, 20, 0.05, row_first=0, row_step=row_step, row_block=row_block)))
+    print("dist %.4f ms/step (events; host enqueue %.3f ms/step), hits %d (row_step %d, row_block %d, order %d, clade %d, tiny %d, metric %d) %s" % (
+        ev0.elapsed_time(ev1) / steps, t_host * 1e3 / steps, int(counters[0].item()), row_step, row_block, order, clade, tiny, metric,
+        ctx.dist_kernel_name(index, None, 1, metric, 20, 0.05, row_first=0, row_step=row_step, row_block=row_block)))
 
 
 def dist_rq(n_ref=100000, n_query=1000, steps=3):
