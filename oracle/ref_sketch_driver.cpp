@@ -25,6 +25,16 @@
 #include "shuffle.h"
 #include "sketch.h"
 
+#ifdef RK_GPU_BINDING
+// oracle/_ref/ref_sketch_driver_gpu: the same driver over integration/gpu_sketch_backend.cpp (the reference-side binding
+// of librabbitkssd.so for sketchFastaFile / transSketches) instead of the reference's CPU loops; saveSketches and
+// readSketches stay the reference's own
+bool sketchFastaFile_gpu(std::string, bool, int, kssd_parameter_t, std::vector<sketch_t> &, sketchInfo_t &, std::string);
+void transSketches_gpu(std::vector<sketch_t> &, sketchInfo_t &, std::string, std::string, int);
+#define sketchFastaFile sketchFastaFile_gpu
+#define transSketches transSketches_gpu
+#endif
+
 static int usage()
 {
     fprintf(stderr,
@@ -87,7 +97,9 @@ int main(int argc, char **argv)
         kssd_parameter_t p = initParameter(sh->dim_shuffle_stat.k, sh->dim_shuffle_stat.subk, sh->dim_shuffle_stat.drlevel,
                                            sh->shuffled_dim);
         const int threads = atoi(argv[5]);
+#ifndef RK_GPU_BINDING
         check_small_files(argv[3], threads);
+#endif
         std::vector<sketch_t> sk;
         sketchInfo_t info;
         bool ok;

@@ -820,6 +820,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 || THREADS == 768) ? 6 : 4
 }
 
 #include "rk_dist_near.inc"
+#include "rk_dist_tile.inc"
 
 struct Plan {
     uint32_t n_units, tile_cols, n_tiles, cnt_words, row_words;
@@ -1108,6 +1109,51 @@ NearPlan plan_near(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool
     return np;
 }
 
+// records of the self join that are posting ranges whose first genome lies within the 32-column window (near flag): the
+// related lists that are wider than a compact record.  A handful per cent in a collection of small clades (a clade hash
+// that also sits in an unrelated genome), most records when species are wider than the window.
+__global__ void k_count_flagged(const uint2 *selfrange, uint64_t n_self, unsigned long long *acc)
+{
+    unsigned long long mine = 0;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_self; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 r = selfrange[e];
+        mine += !(r.x >> 31) && (r.y >> 31);
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(acc, mine);
+}
+
+// Which kernel takes a sparse self join over set sketches: the tile kernel when the collection has clusters wider than
+// the window of rk_near_kernel (decided once per index from its slice records: one pass, one 8-byte read-back), or when
+// RK_DIST_TILES=1 asks for it; RK_DIST_TILES=0 never.
+int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bool dense_mode, hipStream_t stream, bool *use)
+{
+    *use = false;
+    if (!ctx->sw_dist_tiles || dense_mode || !cidx->ref_sets || !cidx->d_postings || !cidx->d_upos || !cidx->d_src_off || !cidx->n_ref ||
+        o->kmer_size <= 0 || o->row_block < 0 || !(o->max_dist > 0.0))
+        return RK_OK;
+    if (ctx->sw_dist_tiles == 1) { *use = true; return RK_OK; }
+    rk_index *idx = const_cast<rk_index *>(cidx);
+    std::lock_guard<std::mutex> lk(idx->lazy_mu);
+    if (!idx->spread_known) {
+        unsigned long long flagged = 0;
+        if (idx->d_selfrange && idx->n_self) {
+            DevBuf<unsigned long long> acc(ctx);
+            RK_HIP(ctx, acc.alloc(1));
+            RK_HIP(ctx, hipMemsetAsync(acc.p, 0, 8, stream));
+            const unsigned grid = (unsigned)std::min<uint64_t>((idx->n_self + 255) / 256, 4096);
+            hipLaunchKernelGGL(k_count_flagged, dim3(grid), dim3(256), 0, stream, idx->d_selfrange, idx->n_self, acc.p);
+            RK_HIP(ctx, hipGetLastError());
+            int rc = rk_read_back(ctx, &flagged, acc.p, 8, stream);
+            if (rc) return rc;
+        }
+        idx->spread = flagged * 8 > idx->n_self;
+        idx->spread_known = 1;
+    }
+    *use = idx->spread;
+    return RK_OK;
+}
+
 // the fallback list of an index (allocated and zeroed once)
 int ensure_fallback(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
 {
@@ -1126,6 +1172,18 @@ int ensure_fallback(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
 int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool dense_mode, rk_hit *hits_dev, uint64_t cap,
                 unsigned long long *n_hits_dev, hipStream_t stream)
 {
+    bool tiles = false;
+    {
+        int rc = self_uses_tiles(ctx, idx, o, dense_mode, stream, &tiles);
+        if (rc) return rc;
+    }
+    if (tiles) {
+        int rc = rk_tiles_build(ctx, const_cast<rk_index *>(idx), stream);
+        if (rc) return rc;
+        const double t = exp(-(double)o->kmer_size * o->max_dist);
+        const double min_jorc = ((o->metric != 0) ? t : t / (2.0 - t)) * (1.0 - 1e-6);
+        return launch_tiles(ctx, idx, o, min_jorc, hits_dev, cap, n_hits_dev, stream);
+    }
     const NearPlan np = plan_near(ctx, idx, o, dense_mode);
     if (np.use) {
         int rc = ensure_fallback(ctx, const_cast<rk_index *>(idx), stream);
@@ -1282,6 +1340,13 @@ int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *que
 {
     if (!ctx || !idx || !opts || !buf || !cap) return RK_ERR_ARG;
     if (queries) return rk_distq_kernel_name(ctx, idx, queries, buf, cap);
+    bool tiles = false;
+    int trc = self_uses_tiles(ctx, idx, opts, rk_dense_mode(opts), ctx->stream, &tiles);
+    if (trc) return trc;
+    if (tiles) {
+        snprintf(buf, cap, "rk_tile_kernel");
+        return RK_OK;
+    }
     const NearPlan np = plan_near(ctx, idx, opts, rk_dense_mode(opts));
     if (np.use) {
         snprintf(buf, cap, "rk_near_kernel<%s, %d>", np.pair ? "true" : "false", np.uw);

@@ -654,6 +654,12 @@ void rk_index_free(rk_index *idx)
     rk_pool_free(ctx, idx->d_src_off);
     rk_pool_free(ctx, idx->d_orig);
     rk_pool_free(ctx, idx->d_fb);
+    rk_pool_free(ctx, idx->d_tile_contrib);
+    rk_pool_free(ctx, idx->d_tile_key);
+    rk_pool_free(ctx, idx->d_tile_start);
+    rk_pool_free(ctx, idx->d_blk_min);
+    rk_pool_free(ctx, idx->d_tile_order[0]);
+    rk_pool_free(ctx, idx->d_tile_order[1]);
     if (idx->h_fb_seen) (void)hipHostFree(idx->h_fb_seen);
     if (idx->fb_event) (void)hipEventDestroy((hipEvent_t)idx->fb_event);
     delete idx;

@@ -47,6 +47,7 @@ struct rk_ctx {
     int sw_dist_near = 1;   // RK_DIST_NEAR=0: the self join always with full counter rows (rk_dist_kernel)
     int sw_dist_near_uw = 0;    // RK_DIST_NEAR_UW=1|2|4: waves that share a unit of the near-window kernel (default: by the launch's size)
     int sw_dist_fb_skip = 1;   // RK_DIST_FB_SKIP=0: always launch the fallback pass of the near-window self join
+    int sw_dist_tiles = 2;      // RK_DIST_TILES: 0 never the tile kernel (rk_dist_tile.inc), 1 for every sparse self join over sets, 2 when the index is wide
     int sw_dist_near_min = 16;  // RK_DIST_NEAR_MIN: the near-window kernel is used when a reportable pair of the smallest sketch needs at least this count
     int sw_dist_debug = 0;  // RK_DIST_DEBUG=1: the bands of every self join on stderr
     int sw_dist_lds_kb = 0;  // RK_DIST_LDS_KB: plan as if a CU had this much LDS (tests: tiled bands at small sizes)
@@ -182,6 +183,18 @@ struct rk_index {
     unsigned char fb_key[40] = {0};
     int fb_state = 0;
     void *fb_event = nullptr;        // hipEvent_t
+    // Tile records of the self join over 32 x 32 tiles (rk_dist_tile.inc), built on first use: per tile (block b of rows,
+    // block w >= b of columns) the (row mask, column mask) pairs of the posting lists that touch both blocks, sorted by tile
+    uint2 *d_tile_contrib = nullptr;            // uint2[n_tile_records]
+    unsigned long long *d_tile_key = nullptr;   // u64[n_tiles]: b << 32 | w, ascending
+    unsigned long long *d_tile_start = nullptr; // u64[n_tiles + 1]
+    uint32_t *d_blk_min = nullptr;              // u32[ceil(n_ref / 32)]: smallest non-empty sketch of the block
+    uint32_t *d_tile_order[2] = {nullptr, nullptr};  // tile numbers by records per smallest sketch, descending: [0] jaccard, [1] containment
+    unsigned long long tile_prefix[2][256] = {};     // [metric][k]: tiles with at least 2^(-k/8) records per smallest sketch
+    uint64_t n_tiles = 0, n_tile_records = 0;
+    bool tiles_ready = false;
+    int spread_known = 0;            // 1: `spread` below is valid (rk_dist.hip self_uses_tiles)
+    bool spread = false;             // many related lists span more than the 32-column window of rk_near_kernel
     std::mutex lazy_mu;              // serialises the lazy builders (prefix directory, rank bitmap, list records, sum of
                                      // squares): two host threads may query one index
 };

@@ -308,10 +308,12 @@ def test_near_window_self_join_and_its_fallback(monkeypatch, strains, n, m, D, m
     sizes = np.diff(off).astype(np.uint32)
     want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=4)
     assert len(want) > n
+    monkeypatch.setenv("RK_DIST_TILES", "0")    # (a collection with wide clusters would take the tile kernel)
     c = capi.Context(0)
     monkeypatch.setenv("RK_DIST_PAIR", "2")
     c1 = capi.Context(0)
     monkeypatch.delenv("RK_DIST_PAIR")
+    monkeypatch.delenv("RK_DIST_TILES")
     for cc, pair in ((c, "true"), (c1, "false")):
         idx = cc.index_build(cc.sketches_from_host(h, off), 26)
         assert cc.dist_kernel_name(idx, None, 1, metric, 20, D).startswith("rk_near_kernel<%s, " % pair)
@@ -331,6 +333,50 @@ def test_near_window_self_join_and_its_fallback(monkeypatch, strains, n, m, D, m
         assert_hits_equal(merged[np.lexsort((merged["col"], merged["row"]))], want)
     c.close()
     c1.close()
+
+
+@pytest.mark.parametrize("strains,n,m,D,metric,tiny", [(10, 2000, 400, 0.05, 0, 0), (70, 1500, 300, 0.05, 0, 3), (100, 2100, 300, 0.05, 1, 2),
+                                                       (300, 1801, 200, 0.05, 0, 0), (1000, 3000, 150, 0.03, 0, 5), (10, 777, 60, 0.2, 0, 4)])
+def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
+    # rk_tile_kernel counts 32 x 32 tiles of the pair matrix from (row mask, column mask) records, one per posting list and
+    # pair of blocks it touches; tiles with fewer records than a reportable cell needs are skipped, every other tile is
+    # counted exactly: species of any width, tiny sketches, loose thresholds, both metrics, row shards -- no fallback.
+    names, h, off = synth.clade_sketches(n, m, 26, strains_per_clade=strains, seed=200 + strains, tiny=tiny)
+    n = len(names)
+    order = synth.genome_order(n, "shuffled", seed=strains)
+    names, h, off = synth.permute_genomes(names, h, off, order)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=4)
+    assert len(want) > n
+    monkeypatch.setenv("RK_DIST_TILES", "1")
+    c = capi.Context(0)
+    monkeypatch.delenv("RK_DIST_TILES")
+    auto = capi.Context(0)
+    idx = c.index_build(c.sketches_from_host(h, off), 26)
+    assert c.dist_kernel_name(idx, None, 1, metric, 20, D) == "rk_tile_kernel"
+    assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+    assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+    other, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 1 - metric, 20, D * 0.5, threads=4)
+    assert_hits_equal(c.dist_rows(idx, None, 1, 1 - metric, 20, D * 0.5)[0], other)
+    for step, block in ((3, 16), (2, 64), (5, 1)):
+        parts = [c.dist_rows(idx, None, 1, metric, 20, D, row_first=r, row_step=step, row_block=block)[0] for r in range(step)]
+        for r, p in enumerate(parts):
+            assert np.all(idx.shard_of(p, step, block) == r)
+        merged = np.concatenate(parts)
+        assert_hits_equal(merged[np.lexsort((merged["col"], merged["row"]))], want)
+    # a dense report (-D 1.0 under `dist` semantics is not a self join; alldist with D > 1) stays with the counter rows
+    assert c.dist_kernel_name(idx, None, 1, metric, 20, 1.5).startswith("rk_dist_kernel")
+    # the default: the tile kernel for collections with clusters wider than the window of rk_near_kernel
+    idx2 = auto.index_build(auto.sketches_from_host(h, off), 26)
+    name = auto.dist_kernel_name(idx2, None, 1, metric, 20, D)
+    assert name == ("rk_tile_kernel" if strains >= 70 else name)
+    if strains == 10 and D < 0.1:
+        assert name.startswith("rk_near_kernel")
+    assert_hits_equal(auto.dist_rows(idx2, None, 1, metric, 20, D)[0], want)
+    del idx, idx2
+    c.close()
+    auto.close()
 
 
 def test_pair_kernel_equals_single_row_kernel(ctx, monkeypatch):
