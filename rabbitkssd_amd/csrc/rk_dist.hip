@@ -19,6 +19,7 @@
 // RK_DIST_PERSIST=2 (one run per workgroup), RK_DIST_CAND_CAP, RK_DIST_STAGE_HITS, RK_DIST_XCD_ROWS, RK_DIST_BANDS=0 (one
 // launch), RK_DIST_BAND_MIN_ROWS, RK_DIST_LDS_KB (plan as if a CU had less LDS: tiles and bands at test sizes).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1124,8 +1125,9 @@ __global__ void k_count_flagged(const uint2 *selfrange, uint64_t n_self, unsigne
 }
 
 // Which kernel takes a sparse self join over set sketches: the tile kernel when the collection has clusters wider than
-// the window of rk_near_kernel (decided once per index from its slice records: one pass, one 8-byte read-back), or when
-// RK_DIST_TILES=1 asks for it; RK_DIST_TILES=0 never.
+// the window of rk_near_kernel (decided once per index from its slice records: one pass, one 8-byte read-back), when a
+// sketch is so small -- or the threshold so loose -- that rk_near_kernel's bound on the cells beyond its window cannot hold,
+// or when RK_DIST_TILES=1 asks for it; RK_DIST_TILES=0 never.
 int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bool dense_mode, hipStream_t stream, bool *use)
 {
     *use = false;
@@ -1133,6 +1135,12 @@ int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bo
         o->kmer_size <= 0 || o->row_block < 0 || !(o->max_dist > 0.0))
         return RK_OK;
     if (ctx->sw_dist_tiles == 1) { *use = true; return RK_OK; }
+    if (!ctx->sw_dist_near) return RK_OK;   // (RK_DIST_NEAR=0 asks for the kernels with counter rows)
+    {   // a sketch so small that the chance hashes of a row reach its threshold: rk_near_kernel would send every row to its fallback
+        const double t = exp(-(double)o->kmer_size * o->max_dist);
+        const double min_jorc = ((o->metric != 0) ? t : t / (2.0 - t)) * (1.0 - 1e-6);
+        if (floor(min_jorc * (double)cidx->min_ref_size) < (double)ctx->sw_dist_near_min) { *use = true; return RK_OK; }
+    }
     rk_index *idx = const_cast<rk_index *>(cidx);
     std::lock_guard<std::mutex> lk(idx->lazy_mu);
     if (!idx->spread_known) {
