@@ -64,11 +64,13 @@ def parse_args():
                     "rehearse the N>1 plumbing with all ranks on ONE GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-sketch", action="store_true")
+    ap.add_argument("--no-sketch-big", action="store_true", help="skip the one-1-Gb-genome leg (K10 S7 L4)")
     ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--no-dist-rq", action="store_true")
     ap.add_argument("--no-orders", action="store_true", help="skip the shuffled / jitter order legs")
     ap.add_argument("--no-rehearsal", action="store_true", help="skip the 1/2/4/8 row-shard rehearsal")
-    ap.add_argument("--sketch-genomes", type=int, default=128)
+    ap.add_argument("--no-variants", action="store_true", help="skip the wide-species / tiny-sketch legs")
+    ap.add_argument("--sketch-genomes", type=int, default=1000, help="BASELINE configs[1]: 1,000 x 5 Mb")
     ap.add_argument("--sketch-length", type=int, default=5_000_000)
     ap.add_argument("--config3-genomes", type=int, default=50000)
     return ap.parse_args()
@@ -215,9 +217,10 @@ def canonical_pairs(hits_tensor, n, capi, order=None):
     return np.stack([lo[key], hi[key], h["common"][key].astype(np.int64)])
 
 
-def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted", build_reps=0):
+def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted", build_reps=0, strains=10, tiny=0):
     """alldist over n_genomes synthetic sketches, this rank's block-cyclic row shard; rank 0 returns the report.
-    order_mode: the order the collection is listed in ("sorted" as generated, "shuffled", "jitter": synth.genome_order)"""
+    order_mode: the order the collection is listed in ("sorted" as generated, "shuffled", "jitter": synth.genome_order);
+    strains: genomes per clade (> 10: a species tree, synth.strain_rates); tiny: extra 40-hash sketches"""
     from rabbitkssd_amd import capi, shard, synth
     torch, ctx, rank, world = env.torch, env.ctx, env.rank, env.world
     n_pairs = n_genomes * (n_genomes - 1) // 2
@@ -226,7 +229,10 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
     names = hashes = off = order = None
     sk = None
     if rank == 0:
-        names, hashes, off = synth.clade_sketches(n_genomes, HASHES_PER_GENOME, HASH_BITS, kmer_size=KMER)
+        names, hashes, off = synth.clade_sketches(n_genomes, HASHES_PER_GENOME, HASH_BITS, kmer_size=KMER, strains_per_clade=strains,
+                                                  tiny=tiny)
+        n_genomes = len(names)
+        n_pairs = n_genomes * (n_genomes - 1) // 2
         if order_mode != "sorted":
             order = synth.genome_order(n_genomes, order_mode)
             names, hashes, off = synth.permute_genomes(names, hashes, off, order)
@@ -255,7 +261,30 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
         ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i,
                           row_first=rank, row_step=world, stream=env.stream.cuda_stream, row_block=shard.ROW_BLOCK)
 
+    # the first call over a fresh index (whatever the kernel builds lazily -- fallback list, tile records -- is in it)
+    first = torch.zeros(1, dtype=torch.int64, device=env.dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, first.data_ptr(), row_first=rank, row_step=world,
+                      stream=env.stream.cuda_stream, row_block=shard.ROW_BLOCK)
+    env.stream.synchronize()
+    t_first = time.perf_counter() - t0
     elapsed, kernel_ms, spread = timed_steps(env, launch, steps, warmup)
+    # cold steps: other options in between make the library forget what it learned about this (index, options) pair -- here
+    # that rk_near_kernel's fallback list is empty --, so every launch of this stretch is a first one (two option sets taking turns)
+    n_cold = min(steps, 20)
+    cold_cnt = torch.zeros(2 * n_cold, dtype=torch.int64, device=env.dev)
+    with torch.cuda.stream(env.stream):
+        env.fence()
+        evc0, evc1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        evc0.record(env.stream)
+        for i in range(2 * n_cold):
+            ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST * (1.0 if i % 2 == 0 else 1.0 - 1e-9), hits.data_ptr(), hits_cap,
+                              cold_cnt.data_ptr() + 8 * i, row_first=rank, row_step=world, stream=env.stream.cuda_stream,
+                              row_block=shard.ROW_BLOCK)
+        evc1.record(env.stream)
+        env.fence()
+    kernel_ms_cold = evc0.elapsed_time(evc1) / (2 * n_cold)
     per_launch = counters[:warmup + steps + spread_steps(steps)].cpu().numpy()
     my_hits = int(per_launch[warmup + steps - 1])   # the last timed launch
     if not (per_launch == my_hits).all():
@@ -299,6 +328,7 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
         "index_blob_bytes": int(nbytes), "rccl_broadcast_ms": t_bcast * 1e3,
         "slice_records": stats[0], "compact_share": (stats[1] / stats[0]) if stats[0] else None, "records_walked": stats[2],
         "build_plus_dist_ms": t_bd * 1e3 if t_bd else None, "pairs_canonical": pairs, "order": order_mode,
+        "first_call_ms": t_first * 1e3, "kernel_ms_cold": kernel_ms_cold,
     }
 
 
@@ -396,8 +426,8 @@ def dist_rq_block(env, n_ref=100000, n_query=1000, steps=20, warmup=3, keep=None
     }
 
 
-def sketch_block(env, n_genomes, length, steps=5):
-    """secondary metric: sketch k-mers/s, sequence bytes resident in HBM"""
+def sketch_block(env, n_genomes, length, steps=5, pmc_file=None, cpu=True):
+    """secondary metric: sketch k-mers/s, sequence bytes resident in HBM (BASELINE configs[1]: 1,000 x 5 Mb)"""
     from rabbitkssd_amd import capi, synth
     torch, ctx = env.torch, env.ctx
     params = capi.params_init(10, 6, 3)
@@ -442,19 +472,79 @@ def sketch_block(env, n_genomes, length, steps=5):
                         "limiter": "vector issue and LDS together: 146 vector instructions and 16 random LDS reads (8 cycles each with bank "
                                    "conflicts) per wave and 1,024 bases, 8 waves per SIMD; the waves are alive 75 % of the kernel's time "
                                    "(uneven pace of the XCDs in the second half of a pass; profiles/r03_pmc_summary.csv, DESIGN.md 4.1)"}}
-    pmc = load_pmc(sk_kernel, "pmc_traffic_sketch.json")
+    pmc = load_pmc(sk_kernel, pmc_file) if pmc_file else None
     if pmc and pmc.get("hbm_bytes_per_launch"):
         out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
         out["roofline"]["hbm_frac"] = pmc["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if pmc.get("SQ_ACTIVE_INST_VALU"):
             out["roofline"]["issue_frac"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / ENGINE_CLOCK_HZ / (kernel_ms * 1e-3)
-    if not env.args.no_cpu_baseline:
+    if cpu and not env.args.no_cpu_baseline:
         out["cpu_baseline"] = sketch_cpu_reference(packed, stride, length, n_genomes) or \
             sketch_cpu_baseline(packed, stride, length, n_genomes, table)
+    del packed, view
+    torch.cuda.empty_cache()
     return out
 
 
 REF_SKETCH = os.path.join(ROOT, "oracle", "_ref", "ref_sketch_driver")
+
+
+def sketch_big_block(env, length=1_000_000_000, sample=200_000_000):
+    """BASELINE configs[4]'s query side: ONE 1 Gb genome at K10 S7 L4 (24-bit hashes), resident in HBM -- the genome is cut
+    into chunks over the whole chip, its ~15,000 hashes are deduplicated per genome.  Beside it the reference's own
+    sketchFastaFile arithmetic (src/sketch.cpp:487-530, small-file loop, one thread: a single file is one task there) on the
+    first `sample` bases of the same genome."""
+    from rabbitkssd_amd import capi, synth
+    torch, ctx = env.torch, env.ctx
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
+        shuf = os.path.join(tmp, "L4K10.shuf")
+        if subprocess.run([TOOL, "shuffle", "-k", "10", "-s", "7", "-l", "4", "-o", shuf], stdout=subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL).returncode != 0:
+            return None
+        table = np.fromfile(shuf, dtype=np.int32)[4:].copy()
+        flt = ctx.filter(capi.params_init(10, 7, 4), table)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(4321)
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+        pad = (length + 1023) // 1024 * 1024
+        packed = torch.zeros(pad, dtype=torch.uint8, device="cuda")
+        packed[:length] = lut[torch.randint(0, 4, (length,), generator=g, device="cuda")]
+        gbeg, gend = np.array([0], dtype=np.uint64), np.array([length], dtype=np.uint64)
+        stream = env.stream.cuda_stream
+        torch.cuda.synchronize()
+        ctx.set_timing(True)
+        sk = ctx.sketch_packed_dev(flt, packed.data_ptr(), packed.numel(), gbeg, gend, stream)   # warm-up
+        kms, t0 = [], time.time()
+        for _ in range(3):
+            sk = ctx.sketch_packed_dev(flt, packed.data_ptr(), packed.numel(), gbeg, gend, stream)
+            kms.append(ctx.last_ms(0))
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / 3
+        ctx.set_timing(False)
+        kernel_ms = sum(kms) / len(kms)
+        b_alg = sk.windows * 1.001
+        out = {"workload": "one %d-base genome, K10 S7 L4 (24-bit hashes), resident in HBM" % length, "kmers": int(sk.windows),
+               "hashes": int(sk.total), "ms_per_pass": dt * 1e3, "kmers_per_s": sk.windows / dt,
+               "roofline": {"bound": "hbm", "achieved": b_alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": b_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "rk_scan2_kernel<20, 8>",
+                            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg}}
+        if not env.args.no_cpu_baseline and os.path.exists(REF_SKETCH):
+            n = min(sample, length)
+            fa = os.path.join(tmp, "big.fa")
+            open(fa, "wb").write(synth.fasta_text("big", packed[:n].cpu().numpy()))
+            open(os.path.join(tmp, "l"), "w").write(fa + "\n")
+            t0 = time.time()
+            p = subprocess.run([REF_SKETCH, "sketch", shuf, os.path.join(tmp, "l"), os.path.join(tmp, "o"), "1", "1"],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            t_ref = time.time() - t0
+            if p.returncode == 0:
+                out["cpu_baseline"] = {"value": (n - 19) / t_ref, "unit": "k-mers/s", "cores": 1, "kind": "reference",
+                                       "sample": "the first %d bases of the genome as one FASTA file, the reference's sketchFastaFile -t 1 (a "
+                                                 "single file is one task of its small-file loop; its big-file branch needs RabbitFX), process "
+                                                 "wall %.2f s incl. reading the 1 GiB .shuf" % (n, t_ref), "wall_s": t_ref}
+        del packed
+        torch.cuda.empty_cache()
+        return out
 
 
 def sketch_cpu_reference(packed, stride, length, n_genomes):
@@ -464,16 +554,18 @@ def sketch_cpu_reference(packed, stride, length, n_genomes):
     from rabbitkssd_amd import synth
     if not os.path.exists(REF_SKETCH) or not os.path.exists(TOOL):
         return None
+    from concurrent.futures import ThreadPoolExecutor
     cores = host_cores()
-    sample = min(n_genomes, 128)
+    sample = min(n_genomes, 1000 if cores >= 32 else 128)   # (all of configs[1] where the host has the cores for it)
     threads = max(1, min(cores, sample))
-    host = packed.view(n_genomes, stride)[:sample, :length].cpu().numpy()
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
-        names = []
-        for g in range(sample):
-            name = os.path.join(tmp, "g%03d.fna" % g)
-            open(name, "wb").write(synth.fasta_text("g%03d" % g, host[g]))
-            names.append(name)
+        names = [os.path.join(tmp, "g%04d.fna" % g) for g in range(sample)]
+        rows = packed.view(n_genomes, stride)
+
+        def write(g):
+            open(names[g], "wb").write(synth.fasta_text("g%04d" % g, rows[g, :length].cpu().numpy()))
+        with ThreadPoolExecutor(max_workers=min(16, cores)) as ex:
+            list(ex.map(write, range(sample)))
         open(os.path.join(tmp, "g.list"), "w").write("\n".join(names) + "\n")
         shuf = os.path.join(tmp, "L3K10.shuf")
         if subprocess.run([TOOL, "shuffle", "-k", "10", "-s", "6", "-l", "3", "-o", shuf], stdout=subprocess.DEVNULL,
@@ -496,7 +588,7 @@ def sketch_cpu_reference(packed, stride, length, n_genomes):
                 break
         kmers = sample * (length - 19)
         res = {"value": kmers / t_ref, "unit": "k-mers/s", "cores": threads, "kind": "reference",
-               "sample": "%d synthetic 5 Mb genomes as FASTA files (page cache), reference sketchFastaFile -t %d, process wall %.3f s "
+               "sample": "%d synthetic 5 Mb genomes as FASTA files (page cache), the reference's sketchFastaFile -t %d, process wall %.3f s "
                          "(reads the 64 MiB .shuf + %d MB of FASTA, sketches, writes the .sketch)" % (sample, threads, t_ref, sample * length // 1000000),
                "wall_s": t_ref}
         if walls:
@@ -636,6 +728,80 @@ def alldist_cpu_and_cli(keep, n_pairs):
     return res, cli
 
 
+def reference_alldist_pairs(names, hashes, off):
+    """the reference's index_tridist (oracle/_ref/ref_driver) on these sketches: (distance-loop seconds, process wall seconds,
+    sorted (lo, hi, common) of every reported pair) -- or None when the reference build is not there"""
+    from oracle import oracle as ok
+    from rabbitkssd_amd import synth
+    if not os.path.exists(REF):
+        return None
+    cores = host_cores()
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
+        sk = os.path.join(tmp, "v.sketch")
+        synth.write_sketch_file(sk, 10, 6, 3, names, hashes, off)
+        postings, counts = ok.index_build32(hashes, off, HASH_BITS)
+        ok.write_index32(sk + ".dict", sk + ".index", postings, counts, HASH_BITS)
+        del counts, postings
+        t0 = time.time()
+        p = subprocess.run([REF, "alldist", tmp, sk, "ref.out", str(MAX_DIST), "0", str(cores)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall = time.time() - t0
+        m = re.search(r"time of multiple threads distance computing and save the subFile is: ([0-9.eE+-]+)", p.stderr.decode(errors="replace"))
+        if p.returncode != 0 or not m:
+            return None
+        where = {n: i for i, n in enumerate(names)}
+        lo, hi, cm = [], [], []
+        with open(os.path.join(tmp, "ref.out")) as f:
+            next(f)
+            for line in f:
+                a, b, c = line.split("\t")[:3]
+                i, j = where[a], where[b]
+                lo.append(min(i, j))
+                hi.append(max(i, j))
+                cm.append(int(c.split("|")[0]))
+        lo, hi, cm = np.array(lo, dtype=np.int64), np.array(hi, dtype=np.int64), np.array(cm, dtype=np.int64)
+        key = np.lexsort((cm, hi, lo))
+        return float(m.group(1)), wall, np.stack([lo[key], hi[key], cm[key]])
+
+
+def alldist_variant(env, head, n_genomes, steps, strains, tiny, what):
+    """the headline workload on a collection that does NOT look like the clade-of-ten generator: species of 100 / 1,000
+    strains, a 40-hash sketch among the bacteria.  Kernel time, pairs per second against the headline's, and whether the
+    reported pairs and counts are the reference's."""
+    k = {}
+    b = alldist_block(env, n_genomes, steps, 3, k, strains=strains, tiny=tiny)
+    if env.rank != 0:
+        return None
+    res = {"workload": what, "genomes": b["genomes"], "pairs": b["pairs"], "hits": b["hits"], "kernel": b["kernel"],
+           "kernel_ms": b["kernel_ms"], "kernel_ms_min_median_max": b["kernel_ms_min_median_max"],
+           "pairs_per_s": b["pairs"] / (b["kernel_ms"] * 1e-3),
+           "pairs_per_s_vs_headline": (b["pairs"] / (b["kernel_ms"] * 1e-3)) / (head["pairs"] / (head["kernel_ms"] * 1e-3)),
+           "index_build_ms": b["index_build_ms"], "first_call_ms": b.get("first_call_ms")}
+    stats = k["index"].self_stats
+    if b["kernel"].startswith("rk_tile_kernel"):
+        # the tile kernel's stream: the 8-byte tile records (one per posting list and pair of 32-genome blocks) + 40 B per hit
+        stream = 8.0 * stats[3] + 40.0 * b["hits"]
+        secs = b["kernel_ms"] * 1e-3
+        roof = {"bound": "hbm", "achieved": stream / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stream / secs / 1e9 / HBM_PEAK_GBS,
+                "traffic": None, "achieved_from": "the kernel's own stream: 8 B per tile record + 40 B per hit written",
+                "stream_bytes_per_launch": stream, "tile_records": int(stats[3]), "kernel": b["kernel"], "kernel_ms": b["kernel_ms"],
+                "issue_frac": None,
+                "limited_by": "vector issue (bit-sliced adds: ~4 vector instructions per tile record) and the length of a tile's chain of "
+                              "records per wave; HBM traffic is a few per cent of the roof by construction (a record stands for up to "
+                              "1,024 cell increments)"}
+        apply_pmc(roof, load_pmc(b["kernel"], "pmc_traffic_tile_clade%d.json" % strains) if strains > 10 else None)
+        res["roofline"] = roof
+    if not env.args.no_cpu_baseline and env.world == 1:
+        ref = reference_alldist_pairs(k["names"], k["hashes"], k["off"])
+        if ref:
+            res["reference"] = {"distance_loop_s": ref[0], "wall_s": ref[1], "hits": int(ref[2].shape[1]), "cores": host_cores()}
+            res["same_hits_as_reference"] = bool(b["pairs_canonical"] is not None and np.array_equal(b["pairs_canonical"], ref[2]))
+            if not res["same_hits_as_reference"]:
+                print(json.dumps(res), flush=True)
+                sys.exit("bench.py: %s: the GPU's pairs differ from the reference's" % what)
+    k.clear()
+    return res
+
+
 def dist_rq_cpu_baseline(keep, n_pairs):
     """the reference's index_dist (src/dist.cpp:429-776) on a bounded sample of the same queries"""
     from oracle import oracle as ok
@@ -684,6 +850,9 @@ def dist_roofline(block, pmc_file=None):
             "issue_frac": None,
             "kernel": block["kernel"], "kernel_ms": block["kernel_ms"],
             "kernel_ms_min_median_max": block["kernel_ms_min_median_max"],
+            "kernel_ms_cold": block["kernel_ms_cold"],
+            "cold_note": "kernel_ms: launches that repeat one (index, options) pair (after the first completed one the empty fallback "
+                         "launch of rk_near_kernel is skipped); kernel_ms_cold: every launch a first one (two option sets taking turns)",
             "limited_by": "the dependent memory round trips of a unit (row bounds -> slice records -> sizes and ids of the "
                           "reportable cells) with one short unit per wave, and vector issue; not HBM bandwidth: the kernel's whole "
                           "stream is the 8-byte slice records (a compact record is its own posting list; the window counts stay in "
@@ -730,6 +899,17 @@ def main():
                 "vs_sorted": o["kernel_ms"] / head["kernel_ms"],
                 "same_pairs_and_counts_as_sorted": bool(o["pairs_canonical"] is not None and head["pairs_canonical"] is not None and
                                                         np.array_equal(o["pairs_canonical"], head["pairs_canonical"]))}
+    # collections that do not look like the generator of the headline: wide species, a tiny sketch
+    variants = None
+    if world == 1 and not args.no_variants:
+        vs = max(10, args.steps // 2)
+        variants = {
+            "clade100": alldist_variant(env, head, n_genomes, vs, 100, 0, "alldist over %d sketches in species of 100 strains (10 sub-lineages "
+                                        "of 10; every pair of a species within -D %g)" % (n_genomes, MAX_DIST)),
+            "clade1000": alldist_variant(env, head, n_genomes, vs, 1000, 0, "alldist over %d sketches in species of 1,000 strains (10 lineages "
+                                         "of 100: pairs across lineages share ~28 %% of their hashes and are NOT within -D %g)" % (n_genomes, MAX_DIST)),
+            "tiny": alldist_variant(env, head, n_genomes, vs, 10, 1, "the headline collection plus one 40-hash sketch (a plasmid)"),
+        }
     if world == 1 and not args.no_rehearsal:
         rehearsal = {"10000": shard_rehearsal(env, keep["index"], n_genomes)}
     distinct = int(keep["index"].distinct) if rank == 0 else 0
@@ -807,6 +987,7 @@ def main():
                     "build's 32-byte read-back); `value` above times the distance kernel alone, as BASELINE configs[2] words it",
             "index_build": build_roofline(head)},
         "alldist_order": orders or None,
+        "alldist_variants": variants,
         "scaling_rehearsal": rehearsal,
         "setup": {"index_build_ms": head["index_build_ms"], "index_build_cold_ms": head["index_build_cold_ms"],
                   "index_built_fast": head["index_built_fast"],
@@ -824,7 +1005,7 @@ def main():
             "index_build_ms": config3["index_build_ms"], "index_built_fast": config3["index_built_fast"],
             "build_plus_dist_ms": config3["build_plus_dist_ms"], "compact_share": config3["compact_share"],
             "index_blob_bytes": config3["index_blob_bytes"], "rccl_broadcast_ms": config3["rccl_broadcast_ms"],
-            "roofline": dist_roofline(config3), "index_build": build_roofline(config3)}
+            "roofline": dist_roofline(config3, "pmc_traffic_50k.json" if world == 1 else None), "index_build": build_roofline(config3)}
     if rq:
         if world == 1:
             apply_pmc(rq["roofline"], load_pmc(rq["roofline"]["kernel"], "pmc_traffic_rq.json"))
@@ -839,7 +1020,12 @@ def main():
                     rq["cpu_baseline"] = cb
         out["dist_rq"] = rq
     if world == 1 and not args.no_sketch:
-        out["sketch"] = sketch_block(env, args.sketch_genomes, args.sketch_length)
+        out["sketch"] = sketch_block(env, args.sketch_genomes, args.sketch_length,
+                                     pmc_file="pmc_traffic_sketch%d.json" % args.sketch_genomes)
+        if args.sketch_genomes != 128:   # round 1-3's batch, kept as a second figure (kernel and pass only)
+            out["sketch_128"] = sketch_block(env, 128, args.sketch_length, pmc_file="pmc_traffic_sketch.json", cpu=False)
+        if not args.no_sketch_big:
+            out["sketch_big"] = sketch_big_block(env)
     if world == 1 and not args.no_cpu_baseline:
         cb, cli = alldist_cpu_and_cli(keep, n_pairs)
         out["cpu_baseline"] = cb

@@ -221,8 +221,9 @@ int rk_index_built_fast(const rk_index *idx);
 uint64_t rk_index_sum_sq(const rk_index *idx);
 /* The all-vs-all join reads one 8-byte slice record per (genome, hash) pair with later sharers.  out[0] = records,
  * out[1] = of which in compact form (first genome + bitmask: the record IS the posting list, no posting is gathered),
- * out[2] = records the row-pair kernel walks (the rest are covered by the pair partner), out[3] = 0.  Computed on first
- * request (one small kernel) and cached; 0s for an imported index. */
+ * out[2] = records the row-pair kernel walks (the rest are covered by the pair partner), out[3] = the 8-byte tile records of
+ * the tile kernel (one per posting list and pair of 32-genome blocks it touches; 0 until a self join has built them).
+ * Computed on first request (one small kernel) and cached; 0s for an imported index. */
 int rk_index_self_stats(const rk_index *idx, uint64_t out[4]);
 /* Multi-GPU: the whole index as ONE contiguous device blob, so that the owner can hand it
  * to an RCCL broadcast (one collective, no reduction: query rows are independent) and every
@@ -271,7 +272,13 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
 /* Asynchronous all-in-HBM variant: hits are appended (unordered) to hits_dev
  * (capacity hits_cap records); *n_hits_dev (uint64, zeroed by the caller) counts every
  * hit, including those beyond the capacity, so an overflow is detectable.  Distances here are the
- * device's own FP64 evaluation (its log may differ from the C library's in the last bit: <= 1e-12). */
+ * device's own FP64 evaluation (its log may differ from the C library's in the last bit: <= 1e-12).
+ * Concurrency: calls with explicit queries and self joins that run on the tile kernel (collections with wide clusters or
+ * tiny sketches, RK_DIST_TILES=1) keep no per-launch state in the index and may overlap freely on different streams.  A
+ * self join that runs on the near-window kernel keeps its fallback list IN the index: at most one such self join per index
+ * may be in flight at a time (serialise them on one stream, or use one index object per stream).
+ * Limits: an index holds fewer than 2^31-1 postings and genomes (rk_index_build returns RK_ERR_UNSUPPORTED beyond: bit 31 of
+ * a slice record tags its compact form). */
 int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
                      const rk_dist_opts *opts, rk_hit *hits_dev, uint64_t hits_cap,
                      uint64_t *n_hits_dev, void *stream);

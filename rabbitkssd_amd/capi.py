@@ -376,10 +376,11 @@ class Index(_Obj):
 
     @property
     def self_stats(self):
-        """(slice records of the self join, of which compact, records the row-pair kernel walks)"""
+        """(slice records of the self join, of which compact, records the row-pair kernel walks, tile records of the tile
+        kernel -- 0 until a self join has built them)"""
         out = (C.c_uint64 * 4)()
         self.ctx.check(lib().rk_index_self_stats(self._h, out))
-        return int(out[0]), int(out[1]), int(out[2])
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
 
     @property
     def order(self):

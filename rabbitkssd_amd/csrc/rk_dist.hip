@@ -1171,7 +1171,8 @@ int ensure_fallback(rk_ctx *ctx, rk_index *idx, hipStream_t stream)
     if (fb.alloc((size_t)idx->n_ref + 8) != hipSuccess) return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate the fallback list");
     RK_HIP(ctx, hipMemsetAsync(fb.p, 0, 16, stream));
     RK_HIP(ctx, hipStreamSynchronize(stream));  // once per index: a later call may come on another stream
-    if (hipHostMalloc((void **)&idx->h_fb_seen, 64, hipHostMallocDefault) == hipSuccess) *idx->h_fb_seen = 0xFFFFFFFFu;  // unknown: first launch at full size
+    // (coherent: the host reads the word after hipEventQuery on an event without release-to-system semantics of its own)
+    if (hipHostMalloc((void **)&idx->h_fb_seen, 64, hipHostMallocCoherent) == hipSuccess) *idx->h_fb_seen = 0xFFFFFFFFu;  // unknown: first launch at full size
     else { (void)hipGetLastError(); idx->h_fb_seen = nullptr; }
     idx->d_fb = fb.release();
     return RK_OK;
@@ -1254,7 +1255,7 @@ int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool de
             if (mut->fb_state == 0) {
                 if (!mut->fb_event) {
                     hipEvent_t ev;
-                    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) mut->fb_event = ev;
+                    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventReleaseToSystem) == hipSuccess) mut->fb_event = ev;
                     else (void)hipGetLastError();
                 }
                 arm = mut->fb_event != nullptr;
@@ -1351,8 +1352,14 @@ int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *que
     bool tiles = false;
     int trc = self_uses_tiles(ctx, idx, opts, rk_dense_mode(opts), ctx->stream, &tiles);
     if (trc) return trc;
-    if (tiles) {
-        snprintf(buf, cap, "rk_tile_kernel");
+    if (tiles) {   // (the variant follows the launch size, which needs the tile directory: built here if it is not there yet)
+        trc = rk_tiles_build(ctx, const_cast<rk_index *>(idx), ctx->stream);
+        if (trc) return trc;
+        const double t = exp(-(double)opts->kmer_size * opts->max_dist);
+        unsigned long long grid = 0;
+        int threads = 256;
+        tile_launch_shape(idx, opts, ((opts->metric != 0) ? t : t / (2.0 - t)) * (1.0 - 1e-6), &grid, &threads);
+        snprintf(buf, cap, "rk_tile_kernel<%du>", threads);
         return RK_OK;
     }
     const NearPlan np = plan_near(ctx, idx, opts, rk_dense_mode(opts));

@@ -35,6 +35,7 @@ inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + kThreads - 1) / 
 
 struct BuildResult {  // written by the kernels, read back once
     unsigned long long U, n_self, dups, flags;
+    unsigned long long flagged;   // slice records that are near-flagged posting ranges (fast path only): related lists wider than a compact record
 };
 
 // Single-workgroup exclusive scan in two sweeps over contiguous per-thread stretches (one block-wide exchange instead
@@ -725,6 +726,7 @@ int rk_index_self_stats(const rk_index *cidx, uint64_t out[4])
         idx->self_stats[2] = v[1];
         idx->self_stats_known = true;
     }
+    idx->self_stats[3] = idx->tiles_ready ? idx->n_tile_records : 0;
     for (int i = 0; i < 4; i++) out[i] = idx->self_stats[i];
     return RK_OK;
 }
@@ -826,7 +828,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     DevBuf<BuildResult> res(ctx);
     RK_HIP(ctx, res.alloc(1));
     RK_HIP(ctx, hipMemsetAsync(res.p, 0, sizeof(BuildResult), st));
-    BuildResult r{0, 0, 0, 0};
+    BuildResult r{0, 0, 0, 0, 0};
     bool built = false;
 
     // ---- fast path: two-level bucket sort, second level and all emission in LDS (rk_index_fast.inc) -----------------
@@ -944,7 +946,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         if (r.flags == 0) built = true;
         else {  // a bucket beyond the LDS sort, or a hash outside the hash space: the general path decides
             RK_HIP(ctx, hipMemsetAsync(res.p, 0, sizeof(BuildResult), st));
-            r = BuildResult{0, 0, 0, 0};
+            r = BuildResult{0, 0, 0, 0, 0};
         }
     }
 
@@ -1034,6 +1036,10 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     idx->n_self = r.n_self;
     idx->ref_sets = s->is_set || r.dups == 0;
     idx->built_fast = built;
+    if (built) {   // (the same rule as rk_dist.hip self_uses_tiles, which counts the records itself for an index built the general way)
+        idx->spread = r.flagged * 8 > r.n_self;
+        idx->spread_known = 1;
+    }
     set_dir_shape(idx);
     guard.p = nullptr;
     *out = idx;

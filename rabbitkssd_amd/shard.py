@@ -39,17 +39,21 @@ def broadcast_blob(blob, src, device, dist):
     and the byte count instead of a bare backend error."""
     import torch
     rank = dist.get_rank()
+    # (the byte count of the message is fixed on the host BEFORE anything can fail: the handler must not touch the device)
+    n_known = "%d bytes" % blob.numel() if rank == src else "size not yet received"
     size = torch.tensor([blob.numel() if rank == src else 0], dtype=torch.int64, device=device)
     try:
         dist.broadcast(size, src)
+        n = int(size.item())
+        n_known = "%d bytes" % n
         if rank != src:
-            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
+            blob = torch.empty(n, dtype=torch.uint8, device=device)
         dist.broadcast(blob, src)
         if device.type == "cuda":
             torch.cuda.synchronize(device)   # RCCL errors surface at the synchronisation
     except Exception as e:  # noqa: BLE001 -- every backend raises its own type
-        raise RuntimeError("rank %d/%d: index broadcast from rank %d (%d bytes) failed: %s"
-                           % (rank, dist.get_world_size(), src, int(size.item()), e)) from e
+        raise RuntimeError("rank %d/%d: index broadcast from rank %d (%s) failed: %s"
+                           % (rank, dist.get_world_size(), src, n_known, e)) from e
     return blob
 
 

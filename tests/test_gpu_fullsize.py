@@ -358,3 +358,67 @@ def test_config4_ref_vs_query_all_1000_queries(ctx):
     _, wdense = ok.index_dist32(counts, 24, postings, sizes, np.concatenate([parts[q] for q in three]), t_off, 0, 0, 20, 0.05,
                                 want_dense=True)
     assert np.array_equal(dense, wdense)
+
+
+def test_one_gigabase_genome_k10s7l4(ctx, tmp_path):
+    """configs[4]'s queries are mammalian genomes at K10 S7 L4 (24-bit hashes, 1 / 65,536 of the windows).  One 1.1 Gb
+    genome -- more distinct hashes (~16,800) than the per-genome LDS sort holds (16,384): the device-wide sort, the
+    run-length pass and the select of rk_sketch.hip take over -- as ONE record, and 400 Mb of it as 61 records with N runs, through
+    rk_sketch_packed_dev (resident in HBM) and through `rabbit_kssd sketch` (one big plain FASTA file, streamed in pieces):
+    every hash set equals the oracle's restatement of src/sketch.cpp:487-530 on the same bytes."""
+    import subprocess
+    import torch
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rabbitkssd_amd", "rabbit_kssd")
+    k, s, l = 10, 7, 4
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    n = 1_100_000_000
+    rng = np.random.default_rng(20261004)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n, dtype=np.uint8)]
+    one = np.array([0, n], dtype=np.uint64)
+    want_one = ok.sketch_records(param, table, bases, one)
+    assert len(want_one) > 16384
+    # the first 400 Mb as 61 records of uneven length, with an N run inside every fifth
+    nm = 400_000_000
+    cuts = np.unique(np.concatenate([[0, nm], rng.integers(1, nm, 60)])).astype(np.uint64)
+    multi = bases[:nm].copy()
+    for i in range(0, len(cuts) - 1, 5):
+        a = int(cuts[i]) + 1000
+        multi[a:a + 50 + 7 * i] = ord("N")
+    want_multi = ok.sketch_records(param, table, multi, cuts)
+    assert len(want_multi) > 5000
+
+    # ---- resident in HBM: rk_sketch_packed_dev (records of a genome separated by one 0x00, start at a multiple of 1,024)
+    flt = ctx.filter(capi.params_init(k, s, l), table)
+    pad = (n + 1023) // 1024 * 1024
+    packed = torch.zeros(pad, dtype=torch.uint8, device="cuda")
+    packed[:n] = torch.from_numpy(bases).cuda()
+    sk = ctx.sketch_packed_dev(flt, packed.data_ptr(), packed.numel(), np.array([0], dtype=np.uint64), np.array([n], dtype=np.uint64))
+    gh, goff = sk.download()
+    assert np.array_equal(gh.astype(np.uint64), want_one)
+    del sk
+    # the multi-record genome through the record API (rk_sketch_batch packs it: one separator per record boundary)
+    sk = ctx.sketch_batch(flt, multi, cuts, np.array([0, len(cuts) - 1], dtype=np.uint64))
+    gh, goff = sk.download()
+    assert np.array_equal(gh.astype(np.uint64), want_multi)
+    del sk, packed
+    torch.cuda.empty_cache()
+
+    # ---- the command line: each genome as one big FASTA file next to a tiny one (size rule of src/sketch.cpp:366-374:
+    # the big one takes the streamed path), 80-column lines / 61 records with lines of 70
+    shuf = tmp_path / "L4K10.shuf"
+    assert subprocess.run([tool, "shuffle", "-k", str(k), "-s", str(s), "-l", str(l), "-o", str(shuf)], stdout=subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL).returncode == 0
+    (tmp_path / "one.fa").write_bytes(synth.fasta_text("chr_one", bases))
+    with open(tmp_path / "multi.fa", "wb") as f:
+        for i in range(len(cuts) - 1):
+            f.write(synth.fasta_text("scaffold_%d extra words" % i, multi[int(cuts[i]):int(cuts[i + 1])], width=70))
+    (tmp_path / "small.fa").write_bytes(b">s\nACGTACGTACGTACGTACGTAAAACCCCGGGGTTTTACGATCGATCGAT\n")
+    for name, want in (("one", want_one), ("multi", want_multi)):
+        lst = tmp_path / (name + ".list")
+        lst.write_text("%s\n%s\n" % (tmp_path / "small.fa", tmp_path / (name + ".fa")))
+        p = subprocess.run([tool, "sketch", "-i", str(lst), "-L", str(shuf), "-o", str(tmp_path / name), "-t", "8", "-q"], cwd=tmp_path,
+                           env=dict(os.environ, RK_TIMING="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        assert b"big file:" in p.stderr                               # the streamed path ran
+        _, names, h, off = ok.read_sketches32(str(tmp_path / (name + ".sketch")))
+        assert np.array_equal(h[int(off[1]):int(off[2])].astype(np.uint64), want), name

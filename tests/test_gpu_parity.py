@@ -354,7 +354,7 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     monkeypatch.delenv("RK_DIST_TILES")
     auto = capi.Context(0)
     idx = c.index_build(c.sketches_from_host(h, off), 26)
-    assert c.dist_kernel_name(idx, None, 1, metric, 20, D) == "rk_tile_kernel"
+    assert c.dist_kernel_name(idx, None, 1, metric, 20, D) .startswith("rk_tile_kernel<")
     assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
     assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
     other, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 1 - metric, 20, D * 0.5, threads=4)
@@ -370,7 +370,7 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     # the default: the tile kernel for collections with clusters wider than the window of rk_near_kernel
     idx2 = auto.index_build(auto.sketches_from_host(h, off), 26)
     name = auto.dist_kernel_name(idx2, None, 1, metric, 20, D)
-    assert name == ("rk_tile_kernel" if strains >= 70 else name)
+    assert strains < 70 or name.startswith("rk_tile_kernel<")
     if strains == 10 and D < 0.1:
         assert name.startswith("rk_near_kernel")
     assert_hits_equal(auto.dist_rows(idx2, None, 1, metric, 20, D)[0], want)

@@ -86,6 +86,10 @@ def main(tag, traffic_only=False):
             for w, fct in sorted(calib.items()):
                 o.write("%2d B/lane: factor %.3f\n" % (w, fct))
     groups = {"dist": sorted(glob.glob(os.path.join(OUT, "pmcD_*"))),
+              "dist_50k": sorted(glob.glob(os.path.join(OUT, "pmcD50_*"))),
+              "tile_clade100": sorted(glob.glob(os.path.join(OUT, "pmcT100_*"))),
+              "tile_clade1000": sorted(glob.glob(os.path.join(OUT, "pmcT1000_*"))),
+              "sketch_1000": sorted(glob.glob(os.path.join(OUT, "pmcSk1000_*"))),
               "index": sorted(glob.glob(os.path.join(OUT, "pmcI_*"))),
               "rq": sorted(glob.glob(os.path.join(OUT, "pmcQ_*"))),
               "sketch": sorted(glob.glob(os.path.join(OUT, "pmcSk_*")) + glob.glob(os.path.join(OUT, "pmcS_*"))),
@@ -100,7 +104,11 @@ def main(tag, traffic_only=False):
             for line in summary(dirs).splitlines():
                 o.write(sec + "," + line + "\n")
     # counter-measured HBM bytes per launch, keyed by the exact kernel variant (bench.py refuses a mismatch)
-    def traffic(dirs, base, fname, workload, width):
+    def traffic(dirs, base, fname, workload, width, coalesced_bytes=0):
+        """coalesced_bytes: a known coalesced stream inside an otherwise scattered read pattern (the query hashes of the rq kernel):
+        FETCH_SIZE saw half of it, so the estimate is FETCH + coalesced/2, between the bounds FETCH x 1 and FETCH x 2"""
+        if not dirs:
+            return None
         v = values(summary(dirs))
         fetch, write = v.get((base, "FETCH_SIZE")), v.get((base, "WRITE_SIZE"))
         if fetch is None or write is None:
@@ -112,7 +120,13 @@ def main(tag, traffic_only=False):
         # 64-B requests and need no correction (cross-check: TCC_MISS x 64 B)
         factor = round(calib.get(width, 2.0 if width == 16 else 1.0), 2) if width else 1.0
         hbm = int(round((fetch * factor + write) * 1024))
-        json.dump({"kernel": variant_of(dirs, base), "workload": workload, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+        extra = {}
+        if coalesced_bytes:
+            hbm = int(round((fetch + write) * 1024 + coalesced_bytes / 2))
+            extra = {"hbm_bytes_lower": int(round((fetch + write) * 1024)), "hbm_bytes_upper": int(round((2 * fetch + write) * 1024)),
+                     "coalesced_stream_bytes": coalesced_bytes,
+                     "estimate": "FETCH_SIZE reports half of a coalesced stream: FETCH + WRITE + coalesced stream / 2"}
+        json.dump({**extra, "kernel": variant_of(dirs, base), "workload": workload, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
                    "SQ_ACTIVE_INST_VALU": v.get((base, "SQ_ACTIVE_INST_VALU")), "SQ_INSTS_VALU": v.get((base, "SQ_INSTS_VALU")),
                    "GRBM_GUI_ACTIVE": v.get((base, "GRBM_GUI_ACTIVE")),
                    "fetch_correction": factor, "TCC_MISS_sum": miss, "TCC_MISS_x64B": miss * 64,
@@ -123,7 +137,12 @@ def main(tag, traffic_only=False):
     # the self join streams its 8-byte slice records (compact slices carry their posting list): a coalesced 8 B/lane
     # stream, corrected by the factor calibrated above (check: ~5.4 M uncovered slices x 8 B = 43 MB)
     t_d = traffic(groups["dist"], "rk_near_kernel", "pmc_traffic.json", "alldist 10,000 sketches (tools/prof_driver.py dist 10000 4), MI355X", 8)
-    t_q = traffic(groups["rq"], "rk_distq_kernel", "pmc_traffic_rq.json", "dist 100,000 refs x 1,000 queries (tools/prof_driver.py dist_rq_dev), MI355X", 0)
+    t_q = traffic(groups["rq"], "rk_distq_kernel", "pmc_traffic_rq.json", "dist 100,000 refs x 1,000 queries (tools/prof_driver.py dist_rq_dev), MI355X", 0,
+                  coalesced_bytes=4 * 45776 * 1000)   # the query hashes, read once, 4 B per lane
+    traffic(groups["dist_50k"], "rk_near_kernel", "pmc_traffic_50k.json", "alldist 50,000 sketches (tools/prof_driver.py dist 50000 3), MI355X", 8)
+    traffic(groups["tile_clade100"], "rk_tile_kernel", "pmc_traffic_tile_clade100.json", "alldist 10,000 sketches in species of 100 (tools/prof_driver.py dist 10000 4 1 0 0 100), MI355X", 8)
+    traffic(groups["tile_clade1000"], "rk_tile_kernel", "pmc_traffic_tile_clade1000.json", "alldist 10,000 sketches in species of 1,000 (tools/prof_driver.py dist 10000 4 1 0 0 1000), MI355X", 8)
+    traffic(groups["sketch_1000"], "rk_scan2_kernel", "pmc_traffic_sketch1000.json", "sketch 1,000 x 5 Mb (tools/prof_driver.py sketch 1000 5000000 2), MI355X", 16)
     t_s = traffic(groups["sketch"], "rk_scan2_kernel", "pmc_traffic_sketch.json", "sketch 128 x 5 Mb (tools/prof_driver.py sketch 128 5000000), MI355X", 16)
     print("traffic dist %s rq %s sketch %s B/launch" % (t_d, t_q, t_s))
     if d:
@@ -133,4 +152,4 @@ def main(tag, traffic_only=False):
 
 if __name__ == "__main__":
     args = [x for x in sys.argv[1:] if not x.startswith("--")]
-    main(args[0] if args else "r03", "--traffic-only" in sys.argv)
+    main(args[0] if args else "r04", "--traffic-only" in sys.argv)

@@ -3,13 +3,18 @@
 # bench.py reports the HBM traffic measured in this very call; the kernel trace of the index build; then bench.py and the
 # rocprofv3 kernel trace of the same command.  Outputs under gpurun_out/; tools/collect_profiles.py <tag> turns the
 # summaries into profiles/<tag>_*.
-tag=${1:-r03}
+tag=${1:-r04}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for w in 4 8 16; do
   printf 'FETCH_SIZE\n' | tools/pmc_pass.sh pmcC$w k_calib_read calib 1024 $w || exit 1
 done
 tools/pmc_pass.sh pmcD rk_near_kernel dist 10000 4 < tools/pmc_groups_dist.txt || exit 1
+printf 'FETCH_SIZE\nWRITE_SIZE\nSQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY\nSQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA\nSQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD\n' > /tmp/groups_short.txt
+tools/pmc_pass.sh pmcD50 rk_near_kernel dist 50000 3 < /tmp/groups_short.txt || exit 1
+tools/pmc_pass.sh pmcT100 rk_tile_kernel dist 10000 4 1 0 0 100 < /tmp/groups_short.txt || exit 1
+tools/pmc_pass.sh pmcT1000 rk_tile_kernel dist 10000 4 1 0 0 1000 < /tmp/groups_short.txt || exit 1
+printf 'FETCH_SIZE\nWRITE_SIZE\nSQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES\n' | tools/pmc_pass.sh pmcSk1000 rk_scan2_kernel sketch 1000 5000000 2 || exit 1
 tools/pmc_pass.sh pmcQ rk_distq_kernel dist_rq_dev 100000 1000 3 < tools/pmc_groups_rq.txt || exit 1
 printf 'FETCH_SIZE\nWRITE_SIZE\nTCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum\n' | tools/pmc_pass.sh pmcSk rk_scan2_kernel sketch 128 5000000 || exit 1
 tools/pmc_pass.sh pmcS rk_scan2_kernel sketch 128 5000000 < tools/pmc_groups_sketch.txt || exit 1
