@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--genomes", type=int, default=10000)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicate", choices=["sketches", "blob"], default="sketches",
+                    help="N > 1: how every rank gets the index -- broadcast of the CSR sketches + a build per rank (default), or "
+                         "broadcast of rank 0's packed index")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the N>1 plumbing with all ranks on ONE GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -135,26 +138,69 @@ class Env:
         self.dist.all_reduce(t)
         return int(t.item())
 
-    def share_index(self, index):
-        """rank 0's index to every rank: ONE broadcast of one blob; returns (index, blob bytes, seconds)"""
+    def share_index(self, index, hashes=None, off=None, hash_bits=HASH_BITS):
+        """every rank gets the index of rank 0's collection; returns (index, bytes moved per rank, seconds, mode).
+        mode "sketches" (default): ONE broadcast of the CSR sketches (4 B per hash), then every rank runs rk_index_build --
+        a third of the bytes of the index blob, and the builds run at the same time (10,000 genomes: 49 MB + 0.5 ms against a
+        147 MB blob; 50,000: 244 MB + 2.6 ms against 733 MB).  mode "blob" (--replicate blob): rank 0 packs its index,
+        one broadcast, every peer unpacks.  The clock runs barrier to barrier, from "rank 0 holds sketches and index in
+        HBM" to "every rank holds the index"."""
         from rabbitkssd_amd import shard
         if self.world == 1:
-            return index, index.blob_bytes, 0.0
+            return index, index.blob_bytes, 0.0, "none"
         torch = self.torch
+        mode = self.args.replicate if hashes is not None or self.rank != 0 else "blob"
+        if mode == "sketches":
+            dh = doff = None
+            if self.rank == 0:
+                dh = torch.from_numpy(np.ascontiguousarray(hashes).view(np.uint8)).to(self.dev)
+                doff = torch.from_numpy(np.ascontiguousarray(off, dtype=np.uint64).view(np.uint8)).to(self.dev)
+            torch.cuda.synchronize()
+            self.dist.barrier()
+            t0 = time.time()
+            dh = shard.broadcast_blob(dh, 0, self.dev, self.dist)
+            doff = shard.broadcast_blob(doff, 0, self.dev, self.dist)
+            if self.rank != 0:
+                sk = self.ctx.sketches_from_dev(dh.data_ptr(), doff.data_ptr(), doff.numel() // 8 - 1)
+                index = self.ctx.index_build(sk, hash_bits)
+                del sk
+            torch.cuda.synchronize()
+            self.dist.barrier()
+            return index, dh.numel() + doff.numel(), time.time() - t0, mode
         blob, nbytes = None, 0
         if self.rank == 0:
             nbytes = index.blob_bytes
             blob = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-            index.pack_dev(blob.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         self.dist.barrier()
         t0 = time.time()
+        if self.rank == 0:
+            index.pack_dev(blob.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
         blob = shard.broadcast_blob(blob, 0, self.dev, self.dist)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
         if self.rank != 0:
             index = self.ctx.index_unpack_dev(blob.data_ptr(), blob.numel(), torch.cuda.current_stream().cuda_stream)
-        return index, blob.numel(), dt
+        torch.cuda.synchronize()
+        self.dist.barrier()
+        return index, blob.numel(), time.time() - t0, mode
+
+    def gather_hits_ms(self, hits_tensor, n_hits, itemsize):
+        """this rank's first n_hits device hit records to rank 0 (what a user of N GPUs waits for after the kernels): counts
+        first, then one gather of equal-sized padded buffers; returns milliseconds, barrier to barrier"""
+        if self.world == 1:
+            return 0.0
+        torch = self.torch
+        self.fence()
+        t0 = time.time()
+        on = self.dev if self.args.backend == "nccl" else torch.device("cpu")   # (gloo gathers host tensors: rehearsals only)
+        cnt = torch.tensor([n_hits], dtype=torch.int64, device=on)
+        all_cnt = [torch.zeros_like(cnt) for _ in range(self.world)]
+        self.dist.all_gather(all_cnt, cnt)
+        most = int(max(int(c.item()) for c in all_cnt))
+        mine = hits_tensor[: most * itemsize].to(on)
+        got = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(mine, got, dst=0)
+        self.fence()
+        return (time.time() - t0) * 1e3
 
     def share_sketches(self, hashes, off):
         """rank 0's host sketches to every rank (queries of the dist path are scattered by the host)"""
@@ -251,7 +297,7 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
         t_steady = sorted(ts)[len(ts) // 2]
     fast = bool(index.built_fast) if rank == 0 else False
     stats = index.self_stats if rank == 0 else (0, 0, 0)
-    index, nbytes, t_bcast = env.share_index(index)
+    index, nbytes, t_bcast, repl_mode = env.share_index(index, hashes, off)
     H, T = index.total, index.sum_sq
     hits_cap = 1 << 20
     hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=env.dev)
@@ -290,6 +336,7 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
     if not (per_launch == my_hits).all():
         sys.exit("bench.py: launches of the same shard reported different hit counts: %s" % sorted(set(per_launch.tolist())))
     tot_hits = env.sum_over_ranks(my_hits)
+    gather_ms = env.max_over_ranks(env.gather_hits_ms(hits, min(my_hits, hits_cap), capi.HIT_DTYPE.itemsize))
     kernel = ctx.dist_kernel_name(index, None, 1, 0, KMER, MAX_DIST, row_first=rank, row_step=world, row_block=shard.ROW_BLOCK)
     pairs = None
     if rank == 0 and world == 1 and my_hits <= hits_cap:
@@ -325,7 +372,9 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
         "kernel": kernel, "kernel_ms": kernel_ms, "kernel_ms_min_median_max": spread,
         "contract_bytes_per_launch": b_contract, "stream_bytes_per_launch": b_stream,
         "index_build_cold_ms": t_cold * 1e3, "index_build_ms": t_steady * 1e3, "index_built_fast": fast,
-        "index_blob_bytes": int(nbytes), "rccl_broadcast_ms": t_bcast * 1e3,
+        "index_blob_bytes": int(index.blob_bytes), "replicate_mode": repl_mode, "replicate_bytes": int(nbytes),
+        "replicate_ms": t_bcast * 1e3, "gather_ms": gather_ms,
+        "e2e_ms": t_bcast * 1e3 + elapsed / steps * 1e3 + gather_ms,
         "slice_records": stats[0], "compact_share": (stats[1] / stats[0]) if stats[0] else None, "records_walked": stats[2],
         "build_plus_dist_ms": t_bd * 1e3 if t_bd else None, "pairs_canonical": pairs, "order": order_mode,
         "first_call_ms": t_first * 1e3, "kernel_ms_cold": kernel_ms_cold,
@@ -380,7 +429,7 @@ def dist_rq_block(env, n_ref=100000, n_query=1000, steps=20, warmup=3, keep=None
         _, rh, roff = synth.clade_sketches(n_ref, 76, bits, seed=31)
         _, qh, qoff = synth.clade_sketches(n_query, 45776, bits, seed=32)
         index = ctx.index_build(ctx.sketches_from_host(rh, roff), bits)
-    index, _, t_bcast = env.share_index(index)
+    index, _, t_bcast, _ = env.share_index(index, rh, roff, bits)
     qh, qoff = env.share_sketches(qh, qoff)
     qs = ctx.sketches_from_host(qh, qoff)
     hits_cap = 1 << 20
@@ -412,7 +461,7 @@ def dist_rq_block(env, n_ref=100000, n_query=1000, steps=20, warmup=3, keep=None
                     "-D %g; one fused kernel per rank, queries in %d contiguous block(s)" % (n_ref, n_query, MAX_DIST, world),
         "value": n_pairs * steps / elapsed, "unit": "genome-pairs/s", "ms_per_step": elapsed / steps * 1e3,
         "pairs": n_pairs, "query_hashes": int(len(qh)), "postings_streamed_T": T_all, "hits": int(tot_hits),
-        "steps": steps, "warmup": warmup, "rccl_broadcast_ms": t_bcast * 1e3,
+        "steps": steps, "warmup": warmup, "replicate_ms": t_bcast * 1e3,
         "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                      "contract_achieved": achieved, "contract_frac": achieved / HBM_PEAK_GBS,
                      "kernel": ctx.dist_kernel_name(index, qs, 0, 0, kmer, MAX_DIST), "kernel_ms": kernel_ms,
@@ -833,6 +882,18 @@ def dist_rq_cpu_baseline(keep, n_pairs):
                 "wall_pairs_per_s": sample * n_ref / wall}
 
 
+def multi_gpu_block(block, world):
+    """what a user of N GPUs waits for: replication of the index, the slowest rank's step, the gather of the hits"""
+    if world == 1:
+        return None
+    return {"replicate_mode": block["replicate_mode"], "replicate_bytes_per_rank": block["replicate_bytes"],
+            "replicate_ms": block["replicate_ms"], "step_ms": block["ms_per_step"], "gather_ms": block["gather_ms"],
+            "e2e_ms": block["e2e_ms"],
+            "note": "e2e = replicate + slowest rank's step + gather of the hit records on rank 0, each barrier to barrier; `value` "
+                    "times the steps alone (the index is resident, BASELINE configs[2]).  replicate: one RCCL broadcast of the CSR "
+                    "sketches + rk_index_build on every rank (--replicate blob: rank 0's packed index instead)"}
+
+
 def dist_roofline(block, pmc_file=None):
     """roofline block of a self-join launch.  `achieved`/`frac`: HBM bytes per second the launch really moved -- from the
     HBM counters when profiles/ holds them for this very kernel variant, else from the kernel's own stream (8 B per slice
@@ -986,12 +1047,13 @@ def main():
             "note": "rk_index_build + rk_dist_rows_dev from device-resident sketches, median of 15, one synchronisation (the "
                     "build's 32-byte read-back); `value` above times the distance kernel alone, as BASELINE configs[2] words it",
             "index_build": build_roofline(head)},
+        "multi_gpu": multi_gpu_block(head, world),
         "alldist_order": orders or None,
         "alldist_variants": variants,
         "scaling_rehearsal": rehearsal,
         "setup": {"index_build_ms": head["index_build_ms"], "index_build_cold_ms": head["index_build_cold_ms"],
                   "index_built_fast": head["index_built_fast"],
-                  "index_blob_bytes": head["index_blob_bytes"], "rccl_broadcast_ms": head["rccl_broadcast_ms"],
+                  "index_blob_bytes": head["index_blob_bytes"],
                   "host_inclusive_ms": t_host_inclusive * 1e3,
                   "host_inclusive_note": "host sketches -> H2D -> rk_index_build -> rk_dist_rows -> %d hits on the host "
                                          "(PCIe-inclusive, whole dataset, one pass, steady state; not `value`)" % n_host_hits},
@@ -1004,7 +1066,7 @@ def main():
             "pairs": config3["pairs"], "hits": config3["hits"], "steps": config3["steps"], "warmup": config3["warmup"],
             "index_build_ms": config3["index_build_ms"], "index_built_fast": config3["index_built_fast"],
             "build_plus_dist_ms": config3["build_plus_dist_ms"], "compact_share": config3["compact_share"],
-            "index_blob_bytes": config3["index_blob_bytes"], "rccl_broadcast_ms": config3["rccl_broadcast_ms"],
+            "index_blob_bytes": config3["index_blob_bytes"], "multi_gpu": multi_gpu_block(config3, world),
             "roofline": dist_roofline(config3, "pmc_traffic_50k.json" if world == 1 else None), "index_build": build_roofline(config3)}
     if rq:
         if world == 1:

@@ -454,8 +454,9 @@ def test_distance_text_single_file_and_subfile_layout(tmp_path, parts, threads):
 
 @pytest.mark.gpu
 def test_cli_multi_gpu_row_shards_reproduce_the_reference_text(tmp_path):
-    """`--gpus N --same-device`: N contexts and host threads in one process (all on the one card of the GPU box), index
-    replicated with rk_index_broadcast, block-cyclic rows (alldist) / contiguous query blocks (dist); the text must be
+    """`--gpus N --same-device`: N contexts and host threads in one process (all on the one card of the GPU box), every
+    context building its own index from the host's sketches (2 GPUs) or the first one's replicated with rk_index_broadcast
+    (RK_MULTI_BROADCAST=1, 3 GPUs), block-cyclic rows (alldist) / contiguous query blocks (dist); the text must be
     the real reference's, also when the output is kept as sub-files"""
     d = os.path.join(GOLDEN, "dist")
     man = json.load(open(os.path.join(d, "manifest.json")))
@@ -464,6 +465,7 @@ def test_cli_multi_gpu_row_shards_reproduce_the_reference_text(tmp_path):
     for case in man["cases"]:
         want = open(os.path.join(d, case["file"])).read().split("\n")[:-1]
         for gpus in (2, 3):
+            os.environ["RK_MULTI_BROADCAST"] = "1" if gpus == 3 else "0"
             if case["cmd"] == "alldist":
                 run(["alldist", "-i", "ref.sketch", "-D", case["max_dist"], "-M", case["metric"], "-o", "o.txt", "--gpus", gpus,
                      "--same-device"], cwd=tmp_path)
@@ -477,6 +479,7 @@ def test_cli_multi_gpu_row_shards_reproduce_the_reference_text(tmp_path):
                 run(args, cwd=tmp_path)
                 lines = (tmp_path / "o.txt").read_text().split("\n")[:-1]
                 assert lines[1:] == want, (case["file"], gpus)     # queries in order, -N heap order per query
+    os.environ.pop("RK_MULTI_BROADCAST", None)
     # the same through the sub-file layout (src/dist.cpp:311-335)
     case = [c for c in man["cases"] if c["cmd"] == "alldist" and c["max_dist"] == 1.5 and c["metric"] == 0][0]
     want = open(os.path.join(d, case["file"])).read().split("\n")[:-1]
