@@ -195,6 +195,10 @@ int rk_index_import(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const
                     int hash_bits, const uint32_t *ref_sizes, uint32_t n_ref, rk_index **out);
 /* To the on-disk pair: postings[total] and (optional) dense counts[2^hash_bits]. */
 int rk_index_export(const rk_index *idx, uint32_t *postings, uint32_t *counts);
+/* The same content without the dense array: the distinct hashes (ascending, rk_index_distinct() of them) and the length of
+ * each one's posting list -- 8 bytes per distinct hash instead of 4 * 2^hash_bits; a host that writes the dense .index
+ * file (src/sketch.cpp:1008-1011) scatters the counts into the zero-filled file itself.  32-bit hash layout only. */
+int rk_index_export_lists(const rk_index *idx, uint32_t *postings, uint32_t *hashes, uint32_t *counts);
 /* 64-bit hash layout: the sparse .index variant {u64 n; u64 hash[n]; u32 count[n]} with the .dict
  * posting blocks in the same order (src/sketch.cpp:942-963, read at src/dist.cpp:36-82).  Export
  * lists the hashes ascending; import accepts any block order (the reference writes hash-map order). */

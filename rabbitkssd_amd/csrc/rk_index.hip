@@ -1451,6 +1451,32 @@ __global__ void k_counts_from_upos(const uint32_t *upos, uint64_t U, uint32_t *c
 
 extern "C" {
 
+int rk_index_export_lists(const rk_index *idx, uint32_t *postings, uint32_t *hashes, uint32_t *counts)
+{
+    if (!idx) return RK_ERR_ARG;
+    rk_ctx *ctx = idx->ctx;
+    if (idx->wide) return rk_fail(ctx, RK_ERR_ARG, "64-bit index: use rk_index_export64");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (postings && idx->H) {
+        uint32_t *mapped = nullptr;
+        RK_TRY(postings_in_caller_ids(ctx, idx, st, &mapped));
+        struct Free { rk_ctx *c; uint32_t *p; ~Free() { rk_pool_free(c, p); } } guard{ctx, mapped};
+        RK_HIP(ctx, hipMemcpyAsync(postings, mapped ? mapped : idx->d_postings, idx->H * 4, hipMemcpyDeviceToHost, st));
+        RK_HIP(ctx, hipStreamSynchronize(st));
+    }
+    if (hashes && idx->U) RK_HIP(ctx, hipMemcpyAsync(hashes, idx->d_uhash, idx->U * 4, hipMemcpyDeviceToHost, st));
+    DevBuf<uint32_t> c(ctx);
+    if (counts && idx->U) {
+        RK_HIP(ctx, c.alloc(idx->U));
+        hipLaunchKernelGGL(k_counts_from_upos, dim3(blocks_for(idx->U)), dim3(kThreads), 0, st, idx->d_upos, idx->U, c.p);
+        RK_HIP(ctx, hipGetLastError());
+        RK_HIP(ctx, hipMemcpyAsync(counts, c.p, idx->U * 4, hipMemcpyDeviceToHost, st));
+    }
+    RK_HIP(ctx, hipStreamSynchronize(st));
+    return RK_OK;
+}
+
 int rk_index_export64(const rk_index *idx, uint32_t *postings, uint64_t *hashes, uint32_t *counts)
 {
     if (!idx) return RK_ERR_ARG;

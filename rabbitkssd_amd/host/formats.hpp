@@ -4,6 +4,7 @@
 // the reference tree.  Host code only: no arithmetic of the hot path lives here.
 #pragma once
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -214,6 +215,51 @@ inline bool write_index(const std::string &dict, const std::string &index, const
     if (!good) { err = "write error on " + index; return false; }
     return true;
 }
+// The dense .index from the index's own sparse form (distinct hashes ascending + list lengths): no 4 * 2^bits byte array
+// crosses PCIe (1 GiB at 28 hash bits for 3 M distinct hashes).  Every thread owns a stretch of the hash space: it
+// scatters that stretch's counts into an anonymous zero mapping and writes the stretch to its place in the file.
+// (Scattering into a mapping of the file itself measured slower: 0.36-0.59 s against 0.28 s for the dense export.)
+inline bool write_index_lists(const std::string &dict, const std::string &index, const uint32_t *postings, uint64_t total,
+                              const uint32_t *hashes, const uint32_t *counts, uint64_t n_lists, uint64_t hash_size, std::string &err,
+                              int threads = 8)
+{
+    FILE *fd = fopen(dict.c_str(), "wb");
+    if (!fd) { err = "cannot write " + dict; return false; }
+    fwrite(postings, 4, total, fd);
+    if (fclose(fd)) { err = "write error on " + dict; return false; }
+    // no O_TRUNC: an existing .index of the same parameters has the same size, and overwriting its pages in place is
+    // twice as fast as freeing 1 GiB of page cache first
+    const int fi = open(index.c_str(), O_WRONLY | O_CREAT, 0644);
+    if (fi < 0) { err = "cannot write " + index; return false; }
+    void *m = mmap(nullptr, hash_size * 4, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) { close(fi); err = "out of memory writing " + index; return false; }
+    uint32_t *dense = (uint32_t *)m;
+    const uint64_t T = (uint64_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads, (hash_size >> 22) + 1));
+    std::vector<int> ok(T, 1);
+    std::vector<std::thread> pool;
+    for (uint64_t t = 0; t < T; t++)
+        pool.emplace_back([&, t]() {
+            const uint64_t lo = hash_size * t / T, hi = hash_size * (t + 1) / T;
+            const uint32_t *a = std::lower_bound(hashes, hashes + n_lists, lo, [](uint32_t h, uint64_t v) { return (uint64_t)h < v; });
+            const uint32_t *b = std::lower_bound(hashes, hashes + n_lists, hi, [](uint32_t h, uint64_t v) { return (uint64_t)h < v; });
+            for (const uint32_t *p = a; p < b; p++) dense[*p] = counts[p - hashes];
+            uint64_t pos = lo * 4;
+            while (pos < hi * 4) {
+                const ssize_t r = pwrite(fi, (const char *)dense + pos, (size_t)std::min<uint64_t>(hi * 4 - pos, 1u << 30), (off_t)(16 + pos));
+                if (r <= 0) { ok[t] = 0; break; }
+                pos += (uint64_t)r;
+            }
+        });
+    for (auto &th : pool) th.join();
+    const uint64_t head[2] = {hash_size, total};
+    bool good = pwrite(fi, head, 16, 0) == 16 && ftruncate(fi, (off_t)(16 + hash_size * 4)) == 0;
+    for (uint64_t t = 0; t < T; t++) good = good && ok[t];
+    munmap(m, hash_size * 4);
+    if (close(fi)) good = false;
+    if (!good) { err = "write error on " + index; return false; }
+    return true;
+}
+
 inline bool write_index(const std::string &dict, const std::string &index, const std::vector<uint32_t> &postings,
                         const std::vector<uint32_t> &counts, std::string &err)
 {

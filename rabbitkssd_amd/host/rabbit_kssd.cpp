@@ -389,11 +389,14 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
         total_bound += bound[i];
         max_bound = std::max(max_bound, bound[i]);
     }
-    // staging buffers: a quarter of the input each (so that uploads and kernels overlap the
-    // parsing of the next batch), between 64 MiB and 1 GiB, never below the largest file
-    // A file bigger than the staging buffer (a 3 Gb genome) gets a batch of its own and is parsed into
-    // ordinary memory: page-locking and releasing 3 GB costs 0.9 s, the slower upload 0.2 s.
-    uint64_t stage_bytes = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(64ull << 20, total_bound / 4));
+    // staging buffers: two, an eighth of the input each (uploads and kernels overlap the parsing of the next batch), between
+    // 64 and 256 MiB -- page-locking costs 0.2 s per GB and releasing 0.13 s per GB (measured: 2 x 1 GiB for 1,000 x 5 Mb
+    // were 0.42 + 0.27 s of a 1.4 s run whose parsing, uploads and kernels take 0.2 s).  A file bigger than the staging
+    // buffer gets a batch of its own: a plain FASTA file is streamed in pieces through a ring of small page-locked buffers
+    // (sketch_big_fasta_streamed), anything else is parsed into ordinary memory (page-locking and releasing 3 GB costs 0.9 s,
+    // the slower upload 0.2 s).
+    uint64_t stage_bytes = std::min<uint64_t>(256ull << 20, std::max<uint64_t>(64ull << 20, total_bound / 8));
+    if (getenv("RK_STAGE_MB")) stage_bytes = std::max<uint64_t>(1, (uint64_t)atoll(getenv("RK_STAGE_MB"))) << 20;
     stage_bytes = (stage_bytes + 1023) & ~1023ULL;
     const uint64_t dev_bytes = std::max(stage_bytes, max_bound);
     vector<Batch> batches;
@@ -607,13 +610,17 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
         cv.notify_all();
     }
     gpu_thread.join();
+    // the page-locked buffers go back to the system while the sketches are saved and the index is built (unpinning is
+    // kernel work that needs nothing from this thread)
     const double t_free = get_sec();
-    for (int k = 0; k < n_buf; k++) {
-        rk_pinned_free(stage[k]);
-        rk_dev_free(dev[k]);
-    }
+    for (int k = 0; k < n_buf; k++) rk_dev_free(dev[k]);
     rk_stream_destroy(stream);
-    if (timing) fprintf(stderr, "[timing] releasing the staging buffers: %.3f s\n", get_sec() - t_free);
+    // (detached: the GPU subcommands leave through _exit once their output is on disk)
+    std::thread([st0 = stage[0], st1 = stage[1], timing, t_free] {
+        rk_pinned_free(st0);
+        rk_pinned_free(st1);
+        if (timing) fprintf(stderr, "[timing] staging buffers released (in the background): %.3f s\n", get_sec() - t_free);
+    }).detach();
     rk_filter_free(flt);
 
     string out_path = out_path_in;
@@ -656,6 +663,14 @@ static rk_index *build_index(Gpu &gpu, const SketchSet &s, const string &sketch_
             vector<uint32_t> counts(rk_index_distinct(idx));
             gpu.check(rk_index_export64(idx, postings.data(), hashes.data(), counts.data()), "rk_index_export64");
             if (!write_index64(sketch_path + ".dict", sketch_path + ".index", postings, hashes, counts, err)) die("%s", err.c_str());
+        } else if (getenv("RK_INDEX_WRITE_LISTS")) {   // dense layout from the sparse form, scattered on the host (measured slower:
+                                                          // 0.52-0.62 s against 0.28 s for 1,000 genomes at 28 hash bits)
+            vector<uint32_t> hashes(rk_index_distinct(idx)), counts(rk_index_distinct(idx));
+            gpu.check(rk_index_export_lists(idx, postings.data(), hashes.data(), counts.data()), "rk_index_export_lists");
+            if (!write_index_lists(sketch_path + ".dict", sketch_path + ".index", postings.data(), postings.size(), hashes.data(),
+                                   counts.data(), hashes.size(), (uint64_t)1 << bits, err,
+                                   (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()))))
+                die("%s", err.c_str());
         } else {         // dense layout, src/sketch.cpp:991-1011
             RawBuf counts;  // 4 * 2^bits bytes, every one of them written by the export: no zero-fill
             counts.resize((size_t)4 << bits);

@@ -54,7 +54,7 @@ def main(n=200, length=5_000_000, threads=16):
         dt, err = run(["sketch", "-L", "L3K10.shuf", "-i", lst, "-o", "out", "-t", str(threads)])
         print("sketch pass %d: %.2f s wall -> %.2f GB/s of FASTA, %.2f genomes/s" % (rep, dt, total / dt / 1e9, n / dt))
         print("   " + " | ".join(l for l in err.splitlines() if "time" in l or "timing" in l))
-    dt, err = run(["alldist", "-i", "out.sketch", "-o", "out.dist", "-d", "0.05", "-t", str(threads)])
+    dt, err = run(["alldist", "-i", "out.sketch", "-o", "out.dist", "-D", "0.05", "-t", str(threads)])
     print("alldist %.2f s wall, %d output lines" % (dt, sum(1 for _ in open(os.path.join(tmp, "out.dist")))))
     print("   " + " | ".join(l for l in err.splitlines() if "time" in l or "timing" in l))
 
