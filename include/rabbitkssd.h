@@ -281,8 +281,11 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
  * tiny sketches, RK_DIST_TILES=1) keep no per-launch state in the index and may overlap freely on different streams.  A
  * self join that runs on the near-window kernel keeps its fallback list IN the index: at most one such self join per index
  * may be in flight at a time (serialise them on one stream, or use one index object per stream).
- * Limits: an index holds fewer than 2^31-1 postings and genomes (rk_index_build returns RK_ERR_UNSUPPORTED beyond: bit 31 of
- * a slice record tags its compact form). */
+ * Limits: fewer than 2^31-1 genomes and 2^32-1 postings per index.  From 2^31-1 postings on (all of GenBank's bacteria at
+ * ~1,200 hashes each) rk_index_build leaves out the slice records of the row kernels (their posting offsets would collide
+ * with the tag bit of the compact form): export, explicit queries below 2^31 postings and SPARSE self joins (the tile
+ * kernel reads the posting lists themselves) work on such an index; a dense self join (a threshold that admits distance
+ * 1.0) and sketches that repeat a hash return RK_ERR_UNSUPPORTED. */
 int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
                      const rk_dist_opts *opts, rk_hit *hits_dev, uint64_t hits_cap,
                      uint64_t *n_hits_dev, void *stream);

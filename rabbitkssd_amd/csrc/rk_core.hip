@@ -218,6 +218,7 @@ int rk_ctx_create(int device, rk_ctx **out)
     ctx->sw_sketch_img = getenv("RK_SKETCH_IMG") ? std::min(2, std::max(0, atoi(getenv("RK_SKETCH_IMG")))) : 2;
     ctx->sw_index_fast = getenv("RK_INDEX_FAST") ? atoi(getenv("RK_INDEX_FAST")) != 0 : 1;
     ctx->sw_index_relabel = getenv("RK_INDEX_RELABEL") ? atoi(getenv("RK_INDEX_RELABEL")) != 0 : 1;
+    ctx->sw_index_no_self = getenv("RK_INDEX_NO_SELF") ? atoi(getenv("RK_INDEX_NO_SELF")) != 0 : 0;
     *out = ctx;
     return RK_OK;
 }

@@ -1131,10 +1131,10 @@ __global__ void k_count_flagged(const uint2 *selfrange, uint64_t n_self, unsigne
 int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bool dense_mode, hipStream_t stream, bool *use)
 {
     *use = false;
-    if (!ctx->sw_dist_tiles || dense_mode || !cidx->ref_sets || !cidx->d_postings || !cidx->d_upos || !cidx->d_src_off || !cidx->n_ref ||
+    if ((!ctx->sw_dist_tiles && cidx->d_selfrange) || dense_mode || !cidx->ref_sets || !cidx->d_postings || !cidx->d_upos || !cidx->d_src_off || !cidx->n_ref ||
         o->kmer_size <= 0 || o->row_block < 0 || !(o->max_dist > 0.0))
         return RK_OK;
-    if (ctx->sw_dist_tiles == 1) { *use = true; return RK_OK; }
+    if (ctx->sw_dist_tiles == 1 || !cidx->d_selfrange) { *use = true; return RK_OK; }   // (no slice records: an index of 2^31 postings and more)
     if (!ctx->sw_dist_near) return RK_OK;   // (RK_DIST_NEAR=0 asks for the kernels with counter rows)
     {   // a sketch so small that the chance hashes of a row reach its threshold: rk_near_kernel would send every row to its fallback
         const double t = exp(-(double)o->kmer_size * o->max_dist);
@@ -1186,6 +1186,9 @@ int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool de
         int rc = self_uses_tiles(ctx, idx, o, dense_mode, stream, &tiles);
         if (rc) return rc;
     }
+    if (!tiles && !idx->d_selfrange)
+        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "this index has no slice records (2^31 postings or more, or RK_INDEX_NO_SELF): only sparse self "
+                                                "joins (a threshold below distance 1.0) run on it");
     if (tiles) {
         int rc = rk_tiles_build(ctx, const_cast<rk_index *>(idx), stream);
         if (rc) return rc;
@@ -1391,7 +1394,7 @@ int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *querie
         return rk_distq_launch(ctx, idx, queries, opts, rk_dense_mode(opts), hits_dev, hits_cap, (unsigned long long *)n_hits_dev,
                                nullptr, (hipStream_t)stream);
     }
-    if (!opts->triangle || !idx->d_selfrange)
+    if (!opts->triangle || !idx->d_src_off)
         return rk_fail(ctx, RK_ERR_ARG, "queries == NULL needs triangle=1 and an index built by rk_index_build");
     return launch_self(ctx, idx, opts, rk_dense_mode(opts), hits_dev, hits_cap, (unsigned long long *)n_hits_dev, (hipStream_t)stream);
 }
@@ -1404,7 +1407,7 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
     *n_hits = 0;
     RK_HIP(ctx, hipSetDevice(ctx->device));
     const bool self = (queries == nullptr);
-    if (self && (!opts->triangle || !idx->d_selfrange))
+    if (self && (!opts->triangle || !idx->d_src_off))
         return rk_fail(ctx, RK_ERR_ARG, "queries == NULL needs triangle=1 and an index built by rk_index_build");
     if (self && common_dense) return rk_fail(ctx, RK_ERR_ARG, "common_dense needs explicit query sketches");
     const uint32_t n_query = self ? idx->n_ref : queries->n;

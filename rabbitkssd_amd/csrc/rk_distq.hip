@@ -566,6 +566,8 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     if (o->row_block < 0) return rk_fail(ctx, RK_ERR_ARG, "row_block must be >= 0");
     if (qs->wide != idx->wide) return rk_fail(ctx, RK_ERR_ARG, "query sketches and index use different hash widths");
     if (!qs->n || !idx->n_ref) return RK_OK;
+    if (idx->H >= 0x7FFFFFFFULL)   // (bit 31 of a list record tags its compact form: posting offsets stay below it)
+        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "explicit queries against an index of 2^31-1 postings or more");
     PlanQ p;
     p.cbits = counter_bits(idx, qs);
     int rc = ensure_rankbm(ctx, const_cast<rk_index *>(idx), stream);  // lazily built, cached in the index

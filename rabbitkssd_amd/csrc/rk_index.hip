@@ -121,7 +121,7 @@ __device__ inline uint2 slice_range(uint2 r) { return r.x <= r.y ? r : make_uint
 // list is its pair partner.  Walking the partner's slice then serves both rows (the slice of 2p starts with 2p+1 and
 // continues with exactly the slice of 2p+1), so the pair kernel skips the covered slices of the odd row.
 // CHECK_DUPS (sketches not known to be sets): a genome that repeats a hash sits next to itself in the group.
-template <bool CHECK_DUPS>
+template <bool CHECK_DUPS, bool NO_SELF = false>
 __global__ void k_postings_selfrange(const uint32_t *sorted_e, const uint32_t *gidx, const uint32_t *upos,
                                      const uint32_t *gid, uint64_t n, uint32_t *postings, uint2 *self_raw,
                                      BuildResult *res)
@@ -131,6 +131,7 @@ __global__ void k_postings_selfrange(const uint32_t *sorted_e, const uint32_t *g
     const uint32_t e = sorted_e[k];
     const uint32_t me = gid[e];
     postings[k] = me;
+    if (NO_SELF) return;   // (an index without slice records: set sketches, nothing to check)
     const uint32_t g = gidx[k] - 1;
     const uint32_t end = upos[g + 1];
     const bool has_prev = k > upos[g];
@@ -742,8 +743,15 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
                        s->wide ? "64" : "32");
     const uint64_t H = s->total;
     const uint32_t N = s->n;
-    // (bit 31 of a slice / list record tags the compact form: posting offsets and genome ids stay below it)
-    if (H >= 0x7FFFFFFFULL || N >= 0x7FFFFFFFu) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "more than 2^31-1 postings or genomes");
+    // Bit 31 of a slice record tags its compact form, so posting offsets inside slice records stay below 2^31.  An index of
+    // 2^31-1 .. 2^32-2 postings (all of GenBank's bacteria at ~1,200 hashes each) is built WITHOUT slice records: its
+    // postings, list offsets and distinct hashes are complete (.dict / .index export, sparse self joins through the tile
+    // kernel, which reads the posting lists themselves); what needs slice records -- a dense report, sketches that repeat
+    // a hash -- is refused for it.  RK_INDEX_NO_SELF=1 builds any index that way (tests).
+    if (H >= 0xFFFFFFFFULL || N >= 0x7FFFFFFFu) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "more than 2^32-2 postings or 2^31-1 genomes");
+    const bool no_self = H >= 0x7FFFFFFFULL || ctx->sw_index_no_self;
+    if (no_self && !s->is_set)
+        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "an index of more than 2^31-1 postings needs set sketches (no hash twice in a genome)");
     RK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     rk_index *idx = new (std::nothrow) rk_index;
@@ -768,9 +776,11 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     if (idx->wide) RK_TRY(pool_array(ctx, &idx->d_uhash64, Ucap + 1));
     else RK_TRY(pool_array(ctx, &idx->d_uhash, Ucap + 1));
     RK_TRY(pool_array(ctx, &idx->d_upos, Ucap + 2));
-    RK_TRY(pool_array(ctx, &idx->d_selfrange, H + 1));
-    RK_TRY(pool_array(ctx, &idx->d_self_off, (size_t)N + 1));
-    RK_TRY(pool_array(ctx, &idx->d_self_split, (size_t)N + 1));
+    if (!no_self) {
+        RK_TRY(pool_array(ctx, &idx->d_selfrange, H + 1));
+        RK_TRY(pool_array(ctx, &idx->d_self_off, (size_t)N + 1));
+        RK_TRY(pool_array(ctx, &idx->d_self_split, (size_t)N + 1));
+    }
     RK_TRY(pool_array(ctx, &idx->d_orig, (size_t)N + 1));
     const unsigned wave_blocks = (N + 3) / 4;  // 4 waves (genomes) per 256-thread workgroup
 
@@ -838,7 +848,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     while ((1ULL << gb) < N) gb++;
     while ((1ULL << rb) < s->max_size) rb++;
     const int low_bits = hash_bits - B;
-    const bool fast_ok = ctx->sw_index_fast && H && H < (1ULL << 30) && !idx->wide && s->is_set && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 &&
+    const bool fast_ok = ctx->sw_index_fast && !no_self && H && H < (1ULL << 30) && !idx->wide && s->is_set && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 &&
                          low_bits + gb + rb <= 63 && gb <= 31 && rb <= 31;
     if (fast_ok) {
         FastArgs fa;
@@ -979,7 +989,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         RK_HIP(ctx, sorted_e.alloc(H));
         RK_HIP(ctx, flags.alloc(H));
         RK_HIP(ctx, gid.alloc(H));
-        RK_HIP(ctx, self_raw.alloc(H));
+        RK_HIP(ctx, self_raw.alloc(no_self ? 1 : H));
         RK_HIP(ctx, n_open.alloc((size_t)N + 1));
         RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
         if (idx->wide) RK_HIP(ctx, keys_sorted64.alloc(H));
@@ -1013,23 +1023,30 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         else
             hipLaunchKernelGGL(k_scatter_heads<uint32_t>, dim3(blocks_for(H)), dim3(kThreads), 0, st, keys_sorted.p, gidx, H,
                                idx->d_uhash, idx->d_upos, res.p);
-        if (s->is_set)
+        if (no_self)
+            hipLaunchKernelGGL((k_postings_selfrange<false, true>), dim3(blocks_for(H)), dim3(kThreads), 0, st, sorted_e.p, gidx,
+                               idx->d_upos, gid.p, H, idx->d_postings, self_raw.p, res.p);
+        else if (s->is_set)
             hipLaunchKernelGGL(k_postings_selfrange<false>, dim3(blocks_for(H)), dim3(kThreads), 0, st, sorted_e.p, gidx,
                                idx->d_upos, gid.p, H, idx->d_postings, self_raw.p, res.p);
         else
             hipLaunchKernelGGL(k_postings_selfrange<true>, dim3(blocks_for(H)), dim3(kThreads), 0, st, sorted_e.p, gidx,
                                idx->d_upos, gid.p, H, idx->d_postings, self_raw.p, res.p);
-        // drop the empty slices (26 % of the elements at 10,000 genomes), covered slices last in their row
-        hipLaunchKernelGGL(k_row_counts, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, self_raw.p, n_open.p, n_cov.p);
-        hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, res.p);
-        hipLaunchKernelGGL(k_row_place, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, self_raw.p,
-                           idx->d_self_off, idx->d_self_split, idx->d_postings, s->is_set, idx->d_selfrange);
+        if (!no_self) {
+            // drop the empty slices (26 % of the elements at 10,000 genomes), covered slices last in their row
+            hipLaunchKernelGGL(k_row_counts, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, self_raw.p, n_open.p, n_cov.p);
+            hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, res.p);
+            hipLaunchKernelGGL(k_row_place, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, self_raw.p,
+                               idx->d_self_off, idx->d_self_split, idx->d_postings, s->is_set, idx->d_selfrange);
+        }
         RK_HIP(ctx, hipGetLastError());
         RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));  // the one synchronisation of the build
     } else if (!H) {
         RK_HIP(ctx, hipMemsetAsync(idx->d_upos, 0, 8, st));
-        RK_HIP(ctx, hipMemsetAsync(idx->d_self_off, 0, ((size_t)N + 1) * 8, st));
-        RK_HIP(ctx, hipMemsetAsync(idx->d_self_split, 0, ((size_t)N + 1) * 8, st));
+        if (!no_self) {
+            RK_HIP(ctx, hipMemsetAsync(idx->d_self_off, 0, ((size_t)N + 1) * 8, st));
+            RK_HIP(ctx, hipMemsetAsync(idx->d_self_split, 0, ((size_t)N + 1) * 8, st));
+        }
         RK_HIP(ctx, hipStreamSynchronize(st));
     }
     idx->U = r.U;

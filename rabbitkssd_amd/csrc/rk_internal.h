@@ -56,6 +56,7 @@ struct rk_ctx {
     int sw_sketch_img = 2;
     int sw_index_fast = 1;     // RK_INDEX_FAST=0: always the general (device-wide radix sort) build
     int sw_index_relabel = 1;  // RK_INDEX_RELABEL=0: keep the caller's genome order inside the index
+    int sw_index_no_self = 0;  // RK_INDEX_NO_SELF=1: build every index without slice records (as one of 2^31 postings and more is)
 };
 constexpr size_t kPinnedBytes = 1 << 16;
 

@@ -379,6 +379,33 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     auto.close()
 
 
+def test_index_without_slice_records(monkeypatch):
+    # an index of 2^31 postings and more is built without slice records (their posting offsets would collide with the tag bit
+    # of the compact form); RK_INDEX_NO_SELF=1 builds a small one that way: .dict / .index content, explicit queries and the
+    # sparse self join (tile kernel: it reads the posting lists themselves) are the oracle's, a dense self join is refused
+    names, h, off = synth.clade_sketches(1500, 200, 26, strains_per_clade=40, seed=77, tiny=2)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    monkeypatch.setenv("RK_INDEX_NO_SELF", "1")
+    c = capi.Context(0)
+    monkeypatch.delenv("RK_INDEX_NO_SELF")
+    idx = c.index_build(c.sketches_from_host(h, off), 26)
+    p2, c2 = idx.export()
+    assert np.array_equal(p2, postings) and np.array_equal(c2, counts)
+    assert idx.self_stats[0] == 0
+    for metric, D in ((0, 0.05), (1, 0.08)):
+        want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=4)
+        assert c.dist_kernel_name(idx, None, 1, metric, 20, D).startswith("rk_tile_kernel<")
+        assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+    with pytest.raises(Exception, match="no slice records"):
+        c.dist_rows(idx, None, 1, 0, 20, 1.5)
+    q = c.sketches_from_host(h[: int(off[100])], off[:101])
+    want, _ = ok.index_dist32(counts, 26, postings, sizes, h[: int(off[100])], off[:101], 0, 0, 20, 0.1, threads=4)
+    assert_hits_equal(c.dist_rows(idx, q, 0, 0, 20, 0.1)[0], want)
+    del idx, q
+    c.close()
+
+
 def test_pair_kernel_equals_single_row_kernel(ctx, monkeypatch):
     # the same self join through the pair kernel (default) and the single-row kernel (RK_DIST_PAIR=2; the developer
     # switches are read when a context is created)
