@@ -109,6 +109,8 @@ int rk_stream_create(rk_ctx *ctx, void **out);
 void rk_stream_destroy(void *stream);
 int rk_stream_sync(rk_ctx *ctx, void *stream);
 int rk_upload_async(rk_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes, void *stream);
+/* device-to-device copy on `stream` (a host that streams a file of unknown inflated size grows its device buffer) */
+int rk_dev_copy_async(rk_ctx *ctx, void *dst_dev, const void *src_dev, uint64_t bytes, void *stream);
 
 /* ---- parameters (host arithmetic only) -------------------------------------------- */
 /* RK_ERR_ARG when half_subk - drlevel < 3 (src/common.cpp:37), half_k < half_subk or

@@ -335,6 +335,14 @@ int rk_upload_async(rk_ctx *ctx, void *dst_dev, const void *src_host, uint64_t b
     return RK_OK;
 }
 
+int rk_dev_copy_async(rk_ctx *ctx, void *dst_dev, const void *src_dev, uint64_t bytes, void *stream)
+{
+    if (!ctx || (bytes && (!dst_dev || !src_dev))) return RK_ERR_ARG;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes) RK_HIP(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return RK_OK;
+}
+
 // src/common.cpp:35-78 (initParameter); argument checks of src/shuffle.cpp:26,30 folded in.
 int rk_params_init(int half_k, int half_subk, int drlevel, rk_params *p)
 {

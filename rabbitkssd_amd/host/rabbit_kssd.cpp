@@ -250,6 +250,269 @@ static bool sketch_big_fasta_streamed(Gpu &gpu, const rk_filter *flt, const stri
 }
 
 
+// ---- one big gzip'ed file, or one big FASTQ file, streamed (the role of src/sketch.cpp:380-450 and :658-737: the
+// RabbitFX producer hands chunks of FA / FQ_SE records to the consumers while it is still reading) -------------------
+// Such a file used to be inflated and parsed completely before its upload.  Now a reader thread (gzread: plain, gzip'ed
+// and multi-member files alike) fills text pieces of ~32 MB, each cut where the parser of a piece needs no context: a
+// FASTQ piece ends in front of a record (an '@' line whose next line but one starts with '+'; RecordReader::parse_packed
+// -- kseq semantics, quality gate -- parses it like a file of its own), a FASTA piece at a line start and carries the
+// last k-1 bases of the text in front of it unless a header line lies between (as sketch_big_fasta_streamed).  Parser
+// threads turn pieces into the packed layout in a ring of page-locked buffers, the calling thread uploads them to
+// consecutive slots of a device buffer that doubles when the inflated size outgrows it, and ONE sketch call over the
+// whole buffer follows (so -n, the minimum number of occurrences, counts over the whole file).
+// Returns false -- nothing done -- for inputs this path does not take ('\r' line ends in FASTA, multi-line FASTQ records
+// longer than a piece, a file that starts without a header): the caller falls back to the whole-file path.
+static bool sketch_big_sequential(Gpu &gpu, const rk_filter *flt, const string &path, bool fastq, int least_qual, int kmer, int threads,
+                                  uint32_t min_count, void *stream, rk_sketches **sk_out, bool timing)
+{
+    const double t0 = get_sec();
+    gzFile fp = gzopen(path.c_str(), "r");
+    if (!fp) return false;
+    gzbuffer(fp, 1 << 20);
+    size_t piece = (size_t)(getenv("RK_BIG_PIECE_MB") ? std::max(1, atoi(getenv("RK_BIG_PIECE_MB"))) : 32) << 20;
+    if (getenv("RK_BIG_PIECE_KB")) piece = (size_t)std::max(1, atoi(getenv("RK_BIG_PIECE_KB"))) << 10;   // tests
+    const size_t need = (size_t)std::min(63, kmer - 1);
+    struct Piece {
+        RawBuf text;
+        size_t len = 0;
+        uint8_t prefix[64];
+        size_t n_prefix = 0;
+        bool first = false;
+        uint64_t dev_off = 0, cap = 0;
+    };
+    const int n_ring = std::max(2, std::min(threads, 4));
+    const uint64_t slot_cap = ((uint64_t)piece * 2 + (uint64_t)kmer + 2 + 1024 + 1023) & ~1023ULL;   // (a piece holds at most 2 x `piece` text bytes)
+    vector<uint8_t *> ring((size_t)n_ring, nullptr);
+    for (int j = 0; j < n_ring; j++) gpu.check(rk_pinned_alloc(gpu.ctx, slot_cap, (void **)&ring[(size_t)j]), "rk_pinned_alloc");
+    struct stat st;
+    uint64_t dev_cap = 256ull << 20;
+    if (stat(path.c_str(), &st) == 0) dev_cap = std::max<uint64_t>(dev_cap, (uint64_t)st.st_size * (ends_with(path, ".gz") ? 4 : 1) + (64ull << 20));
+    if (getenv("RK_BIG_DEV_MB")) dev_cap = (uint64_t)std::max(1, atoi(getenv("RK_BIG_DEV_MB"))) << 20;   // tests: force the growth
+    dev_cap = (dev_cap + 1023) & ~1023ULL;
+    void *d_buf = nullptr;
+    gpu.check(rk_dev_alloc(gpu.ctx, dev_cap, &d_buf), "rk_dev_alloc");
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<Piece>> todo;              // read, not yet parsed
+    std::deque<std::pair<std::unique_ptr<Piece>, int>> ready;   // parsed into ring slot
+    std::deque<int> free_slots;
+    for (int j = 0; j < n_ring; j++) free_slots.push_back(j);
+    bool eof = false;
+    std::atomic<bool> bad{false};
+    size_t n_pieces_read = 0, n_parsed = 0;
+    uint64_t text_bytes = 0;
+
+    // where a text may be cut so that what follows parses on its own: returns the length of the part to keep
+    auto cut_point = [&](const uint8_t *b, size_t n) -> size_t {
+        if (fastq) {
+            // the last '@' line start whose next line but one starts with '+' (a quality line may start with '@' too: the
+            // line after ITS next is a sequence line, never '+')
+            size_t pos = n;
+            for (int tries = 0; tries < 4096 && pos > 0; tries++) {
+                const void *q = memrchr(b, '\n', pos - 1);
+                const size_t ls = q ? (size_t)((const uint8_t *)q - b) + 1 : 0;
+                if (b[ls] == '@') {
+                    const void *e1 = memchr(b + ls, '\n', n - ls);
+                    const void *e2 = e1 ? memchr((const uint8_t *)e1 + 1, '\n', n - ((const uint8_t *)e1 + 1 - b)) : nullptr;
+                    if (e2 && (size_t)((const uint8_t *)e2 + 1 - b) < n && ((const uint8_t *)e2)[1] == '+') return ls;
+                }
+                if (ls == 0) break;
+                pos = ls;   // (the newline before this line start is at ls - 1)
+                if (pos == 0) break;
+            }
+            return 0;
+        }
+        const void *q = memrchr(b, '\n', n);
+        return q ? (size_t)((const uint8_t *)q - b) + 1 : 0;
+    };
+    // FASTA: the last k-1 bases of a text that ends at a line start, unless a header line lies between
+    auto tail_bases = [&](const uint8_t *b, size_t n, const uint8_t *older, size_t n_older, uint8_t *out) -> size_t {
+        uint8_t tmp[64];
+        size_t got = 0;
+        auto walk = [&](const uint8_t *t, size_t len) -> bool {   // false: stop (a header line, or enough)
+            size_t le = len;
+            while (got < need && le > 0) {
+                const size_t nl = le - 1;
+                const void *q = nl ? memrchr(t, '\n', nl) : nullptr;
+                const size_t ls = q ? (size_t)((const uint8_t *)q - t) + 1 : 0;
+                if (t[ls] == '>') return false;
+                for (size_t c = nl; c > ls && got < need; c--) tmp[need - 1 - got++] = t[c - 1];
+                le = ls;
+            }
+            return got < need;
+        };
+        if (walk(b, n) && older)   // (`older`: the bases in front of this text, no line structure)
+            for (size_t c = n_older; c > 0 && got < need; c--) tmp[need - 1 - got++] = older[c - 1];
+        memcpy(out, tmp + (need - got), got);
+        return got;
+    };
+
+    std::thread reader([&]() {
+        std::unique_ptr<Piece> cur(new Piece);
+        cur->text.resize(2 * piece + (1u << 20));
+        cur->first = true;
+        uint8_t carry_prefix[64];
+        size_t n_carry_prefix = 0;
+        for (;;) {
+            // fill the current piece up to `piece` bytes beyond what it already holds
+            bool end = false;
+            while (cur->len < piece) {
+                const int r = gzread(fp, cur->text.data() + cur->len, (unsigned)std::min<size_t>(piece - cur->len, 1u << 30));
+                if (r <= 0) { end = true; break; }
+                cur->len += (size_t)r;
+            }
+            if (cur->first && cur->len && cur->text.data()[0] != (fastq ? '@' : '>')) { bad = true; end = true; cur->len = 0; }
+            std::unique_ptr<Piece> next(new Piece);
+            if (!end) {
+                const size_t keep = cut_point(cur->text.data(), cur->len);
+                if (keep == 0) { bad = true; end = true; cur->len = 0; }   // no cut point inside a piece: not a file for this path
+                else {
+                    next->text.resize(2 * piece + (1u << 20));
+                    next->len = cur->len - keep;
+                    memcpy(next->text.data(), cur->text.data() + keep, next->len);
+                    cur->len = keep;
+                }
+            }
+            if (!fastq) {
+                memcpy(cur->prefix, carry_prefix, n_carry_prefix);
+                cur->n_prefix = cur->first ? 0 : n_carry_prefix;
+                // (a piece with fewer than k-1 bases of its own hands the bases in front of it on)
+                if (cur->len) n_carry_prefix = tail_bases(cur->text.data(), cur->len, cur->prefix, cur->n_prefix, carry_prefix);
+            }
+            if (cur->len) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return todo.size() < (size_t)n_ring || bad; });   // (bounded: the reader runs at most n_ring pieces ahead)
+                text_bytes += cur->len;
+                n_pieces_read++;
+                todo.push_back(std::move(cur));
+                lk.unlock();
+                cv.notify_all();
+            }
+            if (end) break;
+            cur = std::move(next);
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            eof = true;
+        }
+        cv.notify_all();
+    });
+
+    auto parse_piece = [&](Piece &pc, uint8_t *dst) -> uint64_t {   // returns the bytes written (padded to 1 KiB by the caller)
+        uint8_t *w = dst;
+        const uint8_t *b = pc.text.data();
+        if (fastq) {
+            const RecordReader::Packed pk = RecordReader::parse_packed(b, pc.len, w, slot_cap - 1024, least_qual);
+            if (pk.overflow) { bad = true; return 0; }
+            w += pk.bytes;
+            *w++ = 0;   // the next piece starts a new record
+            return (uint64_t)(w - dst);
+        }
+        memcpy(w, pc.prefix, pc.n_prefix);
+        w += pc.n_prefix;
+        size_t pos = 0;
+        while (pos < pc.len) {
+            const void *q = memchr(b + pos, '\n', pc.len - pos);
+            const size_t e = q ? (size_t)((const uint8_t *)q - b) : pc.len;
+            const uint8_t c = b[pos];
+            if (c == '>') {
+                if (!(pc.first && pos == 0)) *w++ = 0;   // record separator (a window never spans records, src/sketch.cpp:487-488)
+            } else if (c == '+' || c == '@') {
+                bad = true;
+                return 0;
+            } else if (e > pos) {
+                if (b[e - 1] == '\r') { bad = true; return 0; }
+                memcpy(w, b + pos, e - pos);
+                w += e - pos;
+            }
+            pos = e + 1;
+        }
+        return (uint64_t)(w - dst);
+    };
+    vector<std::thread> pool;
+    const int nt = std::max(1, std::min(threads, n_ring));
+    for (int t = 0; t < nt; t++)
+        pool.emplace_back([&]() {
+            for (;;) {
+                std::unique_ptr<Piece> pc;
+                int j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return (!todo.empty() && !free_slots.empty()) || (eof && todo.empty()); });
+                    if (todo.empty()) return;
+                    pc = std::move(todo.front());
+                    todo.pop_front();
+                    j = free_slots.front();
+                    free_slots.pop_front();
+                }
+                cv.notify_all();
+                uint64_t bytes = bad ? 0 : parse_piece(*pc, ring[(size_t)j]);
+                const uint64_t cap = (bytes + 1023) & ~1023ULL;
+                memset(ring[(size_t)j] + bytes, 0, (size_t)(cap - bytes));   // padding: invalid bases
+                pc->cap = cap;
+                pc->text.resize(0);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready.emplace_back(std::move(pc), j);
+                }
+                cv.notify_all();
+            }
+        });
+    // this thread: every parsed piece to the next free stretch of the device buffer (the order of the pieces in the buffer
+    // does not matter to a FASTQ file -- every record is a record --, but it does to FASTA: a piece carries the bases in
+    // front of it, so pieces may go in any order as long as each is followed by padding, which they are)
+    uint64_t dev_used = 0;
+    for (;;) {
+        std::pair<std::unique_ptr<Piece>, int> pj;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty() || (eof && todo.empty() && n_parsed == n_pieces_read); });
+            if (ready.empty()) break;
+            pj = std::move(ready.front());
+            ready.pop_front();
+            n_parsed++;
+        }
+        if (!bad && pj.first->cap) {
+            if (dev_used + pj.first->cap > dev_cap) {   // the inflated file outgrew the buffer: twice the size, copy, go on
+                const uint64_t bigger = std::max(dev_cap * 2, dev_used + pj.first->cap);
+                void *d_new = nullptr;
+                gpu.check(rk_dev_alloc(gpu.ctx, bigger, &d_new), "rk_dev_alloc");
+                gpu.check(rk_dev_copy_async(gpu.ctx, d_new, d_buf, dev_used, stream), "rk_dev_copy_async");
+                gpu.check(rk_stream_sync(gpu.ctx, stream), "rk_stream_sync");
+                rk_dev_free(d_buf);
+                d_buf = d_new;
+                dev_cap = bigger;
+            }
+            gpu.check(rk_upload_async(gpu.ctx, (uint8_t *)d_buf + dev_used, ring[(size_t)pj.second], pj.first->cap, stream), "rk_upload_async");
+            gpu.check(rk_stream_sync(gpu.ctx, stream), "rk_stream_sync");
+            dev_used += pj.first->cap;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            free_slots.push_back(pj.second);
+        }
+        cv.notify_all();
+    }
+    reader.join();
+    for (auto &th : pool) th.join();
+    gzclose(fp);
+    const double t1 = get_sec();
+    bool ok = !bad;
+    if (ok) {
+        const uint64_t gbeg = 0, gend = dev_used;
+        gpu.check(rk_sketch_packed_dev_ex(gpu.ctx, flt, (const uint8_t *)d_buf, dev_used, &gbeg, &gend, 1, min_count, stream, sk_out),
+                  "rk_sketch_packed_dev_ex");
+    }
+    if (timing) fprintf(stderr, "[timing] big file (sequential reader): %zu piece(s), %.1f MB of text, %.1f MB packed, read + parse + upload "
+                        "(overlapped, %d parser thread(s)): %.3f s, sketch kernels: %.3f s\n", n_pieces_read, text_bytes / 1e6, dev_used / 1e6, nt,
+                        t1 - t0, get_sec() - t1);
+    for (int j = 0; j < n_ring; j++) rk_pinned_free(ring[(size_t)j]);
+    rk_dev_free(d_buf);
+    return ok;
+}
+
+
 // HIP runtime start-up (hipInit: 150-190 ms on an MI355X box) is the largest single item of a short alldist/dist run:
 // it starts on a thread of its own while the main thread reads the .sketch files
 struct AsyncGpu {
@@ -497,9 +760,12 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
             rk_sketches *sk = nullptr;
             const double t_gpu = get_sec();
             if (bt.streamed) {
-                if (!sketch_big_fasta_streamed(gpu, flt, files[bt.first], 2 * shuf.k, threads, (uint32_t)std::max(1, fq.least_num), stream,
-                                               &sk, timing))
-                    slow_path(bt.first, &sk);   // not a file this path takes (FASTQ-like lines, '\r' line ends): the serial reader
+                const bool plain_fasta = !fq.fastq && !ends_with(files[bt.first], ".gz");
+                const bool done = plain_fasta
+                    ? sketch_big_fasta_streamed(gpu, flt, files[bt.first], 2 * shuf.k, threads, (uint32_t)std::max(1, fq.least_num), stream, &sk, timing)
+                    : sketch_big_sequential(gpu, flt, files[bt.first], fq.fastq, fq.fastq ? fq.least_qual : 0, 2 * shuf.k, threads,
+                                            (uint32_t)std::max(1, fq.least_num), stream, &sk, timing);
+                if (!done) slow_path(bt.first, &sk);   // not a file these paths take ('\r' line ends, odd records): the serial reader
                 {
                     std::lock_guard<std::mutex> lk(mu);
                     consumed = k + 1;
@@ -554,8 +820,8 @@ static void sketch_list(Gpu &gpu, const string &list, bool is_query, const Shuf 
             cv.wait(lk, [&] { return k < (size_t)n_buf || consumed + (size_t)n_buf > k; });
         }
         Batch &bt = batches[k];
-        if (bt.pageable && !fq.fastq && !ends_with(files[bt.first], ".gz") && !getenv("RK_BIG_WHOLE")) {
-            // a big plain FASTA file: the GPU thread streams it piece by piece (parse, upload and kernels overlap)
+        if (bt.pageable && !getenv("RK_BIG_WHOLE")) {
+            // a big file: the GPU thread streams it piece by piece (read / inflate, parse, upload and kernels overlap)
             bt.streamed = true;
             {
                 std::lock_guard<std::mutex> lk(mu);

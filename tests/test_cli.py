@@ -339,6 +339,87 @@ def test_cli_sketch_gzip_inputs_incl_multi_member(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_big_gzip_and_fastq_files_are_streamed(tmp_path):
+    """One big gzip'ed FASTA file (three members, 210 MB of text) and one big FASTQ file (plain and gzip'ed) are read by a
+    reader thread piece by piece -- inflate, parse into page-locked buffers, upload overlap -- instead of being inflated and
+    parsed whole (the role of the RabbitFX producer, src/sketch.cpp:380-450 / :658-737).  The device buffer is forced to
+    start small so that it has to grow; small pieces (RK_BIG_PIECE_KB) put boundaries everywhere.  Hash sets == oracle,
+    also with the quality gate and -n 2 (occurrences counted over the whole file)."""
+    import gzip
+    k, s, l = 8, 5, 2
+    shuf = tmp_path / "L2K8.shuf"
+    run(["shuffle", "-k", k, "-s", s, "-l", l, "-o", shuf])
+    param, table = ok.init_param(k, s, l), ok.shuffle_table(k, s, l)
+    rng = np.random.default_rng(99)
+    lut = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+    # ---- FASTA: records of every size, 60 / 80 / 200-column lines, N runs, 210 MB of text in three gzip members
+    recs, text = [], []
+    total = 0
+    while total < (205 << 20):
+        n = int(rng.choice([1, 15, 16, 17, 300, 5000, 1_000_000, 9_000_000]))
+        codes = rng.integers(0, 8, n, dtype=np.uint8)
+        if n > 1000 and rng.random() < 0.5:
+            a = int(rng.integers(0, n - 100))
+            codes[a:a + int(rng.integers(1, 90))] = 8
+        bases = lut[codes]
+        recs.append(bases)
+        width = int(rng.choice([60, 80, 200]))
+        body = bases.tobytes()
+        text.append(b">r%d c\n" % len(recs) + b"\n".join(body[i:i + width] for i in range(0, n, width)) + b"\n")
+        total += n
+    blob = b"".join(text)
+    c1, c2 = len(blob) // 3, len(blob) - 777
+    big = tmp_path / "big.fa.gz"
+    big.write_bytes(gzip.compress(blob[:c1], 1, mtime=0) + gzip.compress(blob[c1:c2], 1, mtime=0) + gzip.compress(blob[c2:], 1, mtime=0))
+    small = tmp_path / "small.fa"
+    small.write_bytes(b">s\nACGTACGTACGTACGTACGTAAAACCCCGGGGTTTT\n")
+    lst = tmp_path / "g.list"
+    lst.write_text("%s\n%s\n" % (small, big))
+    seq = np.concatenate(recs)
+    rec_off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+    want = ok.sketch_records(param, table, seq, rec_off)
+    for env in ({"RK_BIG_DEV_MB": "64"}, {"RK_BIG_PIECE_KB": "997", "RK_BIG_DEV_MB": "16"}):
+        p = subprocess.run([TOOL, "sketch", "-i", str(lst), "-L", str(shuf), "-o", str(tmp_path / "gz"), "-t", "6", "-q"], cwd=tmp_path,
+                           env=dict(os.environ, RK_TIMING="1", **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        assert b"big file (sequential reader):" in p.stderr
+        _, names, h, off = ok.read_sketches32(str(tmp_path / "gz.sketch"))
+        assert np.array_equal(h[int(off[1]):int(off[2])].astype(np.uint64), want), env
+    # ---- FASTQ: 150-base reads with qualities, some reads with N; plain and gzip'ed; -Q 36 -n 2 and the defaults
+    n_reads = 500_000
+    codes = rng.integers(0, 4, (n_reads, 150), dtype=np.uint8)
+    codes[rng.random((n_reads, 150)) < 0.001] = 8
+    codes[n_reads // 2:] = codes[: n_reads - n_reads // 2]            # every read twice: -n 2 keeps what -n 1 keeps
+    reads = lut[codes]
+    quals = rng.integers(33, 75, (n_reads, 150), dtype=np.uint8)
+    quals[::7, 0] = ord("@")                                           # quality lines that start like a header line
+    lines = []
+    for i in range(n_reads):
+        lines.append(b"@read%d/1\n" % i + reads[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n")
+    fq_text = b"".join(lines)
+    assert len(fq_text) > (150 << 20)
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(fq_text)
+    fqz = tmp_path / "readsz.fq.gz"
+    fqz.write_bytes(gzip.compress(fq_text, 1, mtime=0))
+    smallq = tmp_path / "small.fq"
+    smallq.write_bytes(b"@q\nACGTACGTACGTACGTACGTAAAACCCCGGGGTTTT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n")
+    off_q = (np.arange(n_reads + 1, dtype=np.uint64) * 150)
+    for least_qual, least_num in ((0, 1), (36, 2)):
+        want = ok.sketch_records_fastq(param, table, reads.reshape(-1), quals.reshape(-1), off_q, least_qual, least_num)
+        assert len(want) > 1000
+        for f, env in ((fq, {"RK_BIG_PIECE_KB": "2053"}), (fqz, {"RK_BIG_DEV_MB": "32"})):
+            lst.write_text("%s\n%s\n" % (smallq, f))
+            p = subprocess.run([TOOL, "sketch", "-i", str(lst), "-L", str(shuf), "-o", str(tmp_path / "fq"), "-t", "6", "-q", "-Q", str(least_qual),
+                                "-n", str(least_num)], cwd=tmp_path, env=dict(os.environ, RK_TIMING="1", **env), stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE)
+            assert p.returncode == 0, p.stderr.decode()[-2000:]
+            assert b"big file (sequential reader):" in p.stderr
+            _, names, h, off = ok.read_sketches32(str(tmp_path / "fq.sketch"))
+            assert np.array_equal(h[int(off[1]):int(off[2])].astype(np.uint64), want), (str(f), least_qual, least_num)
+
+
+@pytest.mark.gpu
 def test_cli_dist_matches_reference_text(tmp_path):
     d = os.path.join(GOLDEN, "dist")
     man = json.load(open(os.path.join(d, "manifest.json")))
