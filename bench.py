@@ -851,6 +851,31 @@ def alldist_variant(env, head, n_genomes, steps, strains, tiny, what):
     return res
 
 
+def use64_block(env, n_genomes=10000, steps=10):
+    """a K12 L3 collection (36-bit hashes: the 64-bit layout, half_k - drlevel > 8): index build and alldist kernel"""
+    from rabbitkssd_amd import capi, synth
+    torch, ctx = env.torch, env.ctx
+    names, hashes, off = synth.clade_sketches(n_genomes, HASHES_PER_GENOME, 36, kmer_size=24, seed=20261003, wide=True)
+    sk = ctx.sketches_from_host64(hashes, off)
+    ts = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        index = ctx.index_build(sk, 36)
+        ts.append(time.perf_counter() - t0)
+    hits_cap = 1 << 20
+    hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=env.dev)
+    counters = torch.zeros(counter_slots(steps, 2), dtype=torch.int64, device=env.dev)
+
+    def launch(i):
+        ctx.dist_rows_dev(index, 1, 0, 24, MAX_DIST, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i, stream=env.stream.cuda_stream)
+    _, kernel_ms, _ = timed_steps(env, launch, steps, 2)
+    n_pairs = n_genomes * (n_genomes - 1) // 2
+    return {"workload": "alldist over %d synthetic sketches with 36-bit hashes (K12 S6 L3: the 64-bit hash layout), -D %g" % (n_genomes, MAX_DIST),
+            "index_build_ms": sorted(ts[1:])[1] * 1e3, "index_built_fast": bool(index.built_fast), "kernel": ctx.dist_kernel_name(index, None, 1, 0, 24, MAX_DIST),
+            "kernel_ms": kernel_ms, "pairs_per_s": n_pairs / (kernel_ms * 1e-3), "hits": int(counters[2 + steps - 1].item())}
+
+
 def dist_rq_cpu_baseline(keep, n_pairs):
     """the reference's index_dist (src/dist.cpp:429-776) on a bounded sample of the same queries"""
     from oracle import oracle as ok
@@ -1081,6 +1106,8 @@ def main():
                 if cb:
                     rq["cpu_baseline"] = cb
         out["dist_rq"] = rq
+    if world == 1 and not args.no_variants:
+        out["use64"] = use64_block(env)
     if world == 1 and not args.no_sketch:
         out["sketch"] = sketch_block(env, args.sketch_genomes, args.sketch_length,
                                      pmc_file="pmc_traffic_sketch%d.json" % args.sketch_genomes)

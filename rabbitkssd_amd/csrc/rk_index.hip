@@ -848,11 +848,16 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     while ((1ULL << gb) < N) gb++;
     while ((1ULL << rb) < s->max_size) rb++;
     const int low_bits = hash_bits - B;
-    const bool fast_ok = ctx->sw_index_fast && !no_self && H && H < (1ULL << 30) && !idx->wide && s->is_set && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 &&
+    // (64-bit hashes -- use64, e.g. K12 L3: 36 bits -- take the same path as long as the key fields fit: the kernels that read
+    // the sketches are templated on the hash type, the bucket sort itself only ever sees the low bits)
+    const bool fast_ok = ctx->sw_index_fast && !no_self && H && H < (1ULL << 30) && s->is_set && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 &&
                          low_bits + gb + rb <= 63 && gb <= 31 && rb <= 31;
+    if (ctx->sw_dist_debug && !fast_ok)
+        fprintf(stderr, "[rk] index build: general path (H %llu, wide %d, sets %d, B %d, low bits %d, genome bits %d, position bits %d)\n",
+                (unsigned long long)H, (int)idx->wide, (int)s->is_set, B, low_bits, gb, rb);
     if (fast_ok) {
         FastArgs fa;
-        fa.hashes = s->d_hashes;
+        fa.hashes = idx->wide ? (const void *)s->d_hashes64 : (const void *)s->d_hashes;
         fa.off = s->d_off;
         fa.orig = idx->d_orig;
         fa.off_new = idx->d_src_off;
@@ -866,15 +871,17 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         fa.nb = 1u << B;
         fa.n_chunks = (uint32_t)((H + kPartChunk - 1) / kPartChunk);
         DevBuf<uint32_t> chunk_first(ctx), matrix(ctx), total(ctx), bstart(ctx), ucount(ctx), ubase(ctx), tmp_uhash(ctx), tmp_upos(ctx), n_open(ctx), n_cov(ctx);
-        DevBuf<unsigned long long> keys(ctx);
+        DevBuf<unsigned long long> keys(ctx), tmp_uhash64(ctx);
         DevBuf<uint2> self_raw(ctx);
+        const bool wide = idx->wide;
         RK_HIP(ctx, chunk_first.alloc((size_t)fa.n_chunks + 1));
         RK_HIP(ctx, matrix.alloc((size_t)fa.n_chunks * fa.nb));
         RK_HIP(ctx, total.alloc(fa.nb));
         RK_HIP(ctx, bstart.alloc((size_t)fa.nb + 1));
         RK_HIP(ctx, ucount.alloc(fa.nb));
         RK_HIP(ctx, ubase.alloc((size_t)fa.nb + 1));
-        RK_HIP(ctx, tmp_uhash.alloc(H));
+        if (wide) RK_HIP(ctx, tmp_uhash64.alloc(H));
+        else RK_HIP(ctx, tmp_uhash.alloc(H));
         RK_HIP(ctx, tmp_upos.alloc(H));
         RK_HIP(ctx, keys.alloc(H));
         RK_HIP(ctx, self_raw.alloc(H));
@@ -882,11 +889,14 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
         const size_t part_lds = (size_t)fa.nb * 4 + 2 * kStageGenomes * 8;   // bucket counters + the chunk's genome bounds
         if (part_lds > 48 * 1024) {
-            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
-            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
+            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_hist<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
+            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_scatter<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
+            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_hist<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
+            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_scatter<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
         }
         hipLaunchKernelGGL(k_chunk_first, dim3(blocks_for((uint64_t)fa.n_chunks + 1)), dim3(kThreads), 0, st, idx->d_src_off, N, fa.n_chunks, chunk_first.p);
-        hipLaunchKernelGGL(k_part_hist, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, res.p);
+        if (wide) hipLaunchKernelGGL(k_part_hist<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, res.p);
+        else hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, res.p);
         hipLaunchKernelGGL(k_part_colscan, dim3((fa.nb + 63) / 64), dim3(1024), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
         hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart.p, res.p);
         // the partition itself: two coalescing passes (rk_index_fast.inc), or one scattering pass
@@ -900,18 +910,19 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             const bool small_wgs = (fa.nb >> kFineBits) <= 128;   // several workgroups per chunk: they share its stretch through counters
             RK_HIP(ctx, seg_taken.alloc(small_wgs ? (size_t)fa.n_chunks * (fa.nb >> kFineBits) : 1));
             if (small_wgs) RK_HIP(ctx, hipMemsetAsync(seg_taken.p, 0, (size_t)fa.n_chunks * (fa.nb >> kFineBits) * 4, st));
-            if (small_wgs) {
-                RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_coarse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds(256)));
-                hipLaunchKernelGGL(k_part_coarse<256>, dim3(fa.n_chunks * 4), dim3(256), part2_lds(256), st, fa, chunk_first.p, matrix.p, bstart.p,
-                                   seg_taken.p, mid.p);
-            } else {
-                RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_coarse<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds(1024)));
-                hipLaunchKernelGGL(k_part_coarse<1024>, dim3(fa.n_chunks), dim3(1024), part2_lds(1024), st, fa, chunk_first.p, matrix.p, bstart.p,
-                                   seg_taken.p, mid.p);
-            }
+#define RK_COARSE(TT, HT, GRID)                                                                                                              \
+    do {                                                                                                                                     \
+        RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_coarse<TT, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds(TT))); \
+        hipLaunchKernelGGL((k_part_coarse<TT, HT>), dim3(GRID), dim3(TT), part2_lds(TT), st, fa, chunk_first.p, matrix.p, bstart.p, seg_taken.p, mid.p); \
+    } while (0)
+            if (small_wgs) { if (wide) RK_COARSE(256, uint64_t, fa.n_chunks * 4); else RK_COARSE(256, uint32_t, fa.n_chunks * 4); }
+            else { if (wide) RK_COARSE(1024, uint64_t, fa.n_chunks); else RK_COARSE(1024, uint32_t, fa.n_chunks); }
+#undef RK_COARSE
             hipLaunchKernelGGL(k_part_fine, dim3(fa.nb >> kFineBits, 16), dim3(kPartThreads), 0, st, fa, bstart.p, mid.p, keys.p, fine_cursor.p);
+        } else if (wide) {
+            hipLaunchKernelGGL(k_part_scatter<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
         } else {
-            hipLaunchKernelGGL(k_part_scatter, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
+            hipLaunchKernelGGL(k_part_scatter<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
         }
         EmitArgs ea;
         ea.keys = keys.p;
@@ -923,6 +934,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         ea.nb = fa.nb;
         ea.postings = idx->d_postings;
         ea.tmp_uhash = tmp_uhash.p;
+        ea.tmp_uhash64 = wide ? tmp_uhash64.p : nullptr;
         ea.tmp_upos = tmp_upos.p;
         ea.ucount = ucount.p;
         ea.self_raw = self_raw.p;
@@ -945,14 +957,19 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
 #undef RK_EMIT
         }
         hipLaunchKernelGGL(k_heads_scan, dim3(1), dim3(1024), 0, st, ucount.p, fa.nb, ubase.p, res.p);
-        hipLaunchKernelGGL(k_heads_place, dim3(fa.nb), dim3(kThreads), 0, st, tmp_uhash.p, tmp_upos.p, bstart.p, ucount.p, ubase.p, fa.nb,
-                           (uint32_t)H, idx->d_uhash, idx->d_upos);
+        if (wide)
+            hipLaunchKernelGGL(k_heads_place<unsigned long long>, dim3(fa.nb), dim3(kThreads), 0, st, tmp_uhash64.p, tmp_upos.p, bstart.p, ucount.p, ubase.p,
+                               fa.nb, (uint32_t)H, (unsigned long long *)idx->d_uhash64, idx->d_upos);
+        else
+            hipLaunchKernelGGL(k_heads_place<uint32_t>, dim3(fa.nb), dim3(kThreads), 0, st, tmp_uhash.p, tmp_upos.p, bstart.p, ucount.p, ubase.p, fa.nb,
+                               (uint32_t)H, idx->d_uhash, idx->d_upos);
         hipLaunchKernelGGL(k_row_counts2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, n_open.p, n_cov.p);
         hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, res.p);
         hipLaunchKernelGGL(k_row_place2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, idx->d_self_off,
                            idx->d_self_split, idx->d_selfrange);
         RK_HIP(ctx, hipGetLastError());
         RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));  // the one synchronisation of the build
+        if (ctx->sw_dist_debug) fprintf(stderr, "[rk] index build: fast path flags %llu (B %d, low bits %d, genome bits %d, position bits %d)\n", r.flags, B, low_bits, gb, rb);
         if (r.flags == 0) built = true;
         else {  // a bucket beyond the LDS sort, or a hash outside the hash space: the general path decides
             RK_HIP(ctx, hipMemsetAsync(res.p, 0, sizeof(BuildResult), st));

@@ -50,19 +50,20 @@ def strain_rates(s):
     return a, b, c
 
 
-def clade_sketches(n_genomes, m, hash_bits, kmer_size=20, strains_per_clade=10, seed=20261003, tiny=0, tiny_size=40):
+def clade_sketches(n_genomes, m, hash_bits, kmer_size=20, strains_per_clade=10, seed=20261003, tiny=0, tiny_size=40, wide=False):
     """Sketch-level generator: per clade draw `m` distinct uniform values in
     [0, 2^hash_bits); strain s keeps each with probability (1-0.002 s)^kmer_size and
     replaces the rest with fresh uniform values; per-genome sets are deduplicated and
     returned SORTED.  Returns (names, hashes uint32[H], off uint64[N+1]).
     strains_per_clade > 10: a species tree of lineages / sub-lineages / strains (strain_rates).
     tiny: that many extra sketches of `tiny_size` hashes (plasmids, small contigs) are spread over the collection; each is a
-    random subset of one clade ancestor (so it has relatives and reportable pairs under containment)."""
+    random subset of one clade ancestor (so it has relatives and reportable pairs under containment).
+    wide: hashes as uint64 (the 64-bit layout of half_k - drlevel > 8, e.g. K12 L3: 36 bits)."""
     rng = np.random.default_rng(seed)
     space = 1 << hash_bits
     names, parts = [], []
     anc = None
-    wide = strains_per_clade > 10
+    tree = strains_per_clade > 10
 
     def mutate(src, rate):
         keep = rng.random(len(src)) < (1.0 - rate) ** kmer_size
@@ -76,7 +77,7 @@ def clade_sketches(n_genomes, m, hash_bits, kmer_size=20, strains_per_clade=10, 
             anc = np.unique(rng.integers(0, space, size=m + m // 8, dtype=np.uint64))
             rng.shuffle(anc)
             anc = anc[:m]
-        if not wide:
+        if not tree:
             h = mutate(anc, 0.002 * s)
         else:
             a, b, cc = strain_rates(s)
@@ -85,15 +86,15 @@ def clade_sketches(n_genomes, m, hash_bits, kmer_size=20, strains_per_clade=10, 
             if s % 10 == 0:
                 sub = mutate(lineage, 0.006)
             h = mutate(sub, 0.001 * cc)
-        parts.append(np.unique(h).astype(np.uint32))
+        parts.append(np.unique(h).astype(np.uint64 if wide else np.uint32))
         names.append("syn/c%04d_s%d.fna" % (c, s))
         if tiny and (g + 1) % max(1, n_genomes // tiny) == 0 and len(names) - (g + 1) < tiny:
-            t = np.unique(anc[rng.permutation(len(anc))[:tiny_size]]).astype(np.uint32)
+            t = np.unique(anc[rng.permutation(len(anc))[:tiny_size]]).astype(np.uint64 if wide else np.uint32)
             parts.append(t)
             names.append("syn/tiny%04d.fna" % (len(names) - (g + 1)))
     off = np.zeros(len(parts) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(p) for p in parts])
-    hashes = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32)
+    hashes = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64 if wide else np.uint32)
     return names, hashes, off
 
 

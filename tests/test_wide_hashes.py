@@ -128,6 +128,36 @@ def test_gpu_wide_sketch_vs_oracle(ctx, k, s, l):
     assert np.array_equal(mine["dist"], want["dist"])
 
 
+@pytest.mark.gpu
+def test_gpu_wide_index_fast_build_equals_general_build(monkeypatch):
+    """36-bit hashes (K12 L3) take the bucket-sort build like 32-bit ones (the kernels that read the sketches are templated
+    on the hash type): postings, distinct hashes, list lengths and the self join equal the general build's and the oracle's"""
+    names, h, off = synth.clade_sketches(3000, 400, 36, kmer_size=24, seed=5, wide=True)
+    order = synth.genome_order(len(names), "shuffled", seed=3)
+    names, h, off = synth.permute_genomes(names, h, off, order)
+    assert h.dtype == np.uint64 and int(h.max()) >= (1 << 32)
+    fast = capi.Context(0)
+    monkeypatch.setenv("RK_INDEX_FAST", "0")
+    slow = capi.Context(0)
+    monkeypatch.delenv("RK_INDEX_FAST")
+    i_fast = fast.index_build(fast.sketches_from_host64(h, off), 36)
+    i_slow = slow.index_build(slow.sketches_from_host64(h, off), 36)
+    assert i_fast.built_fast and not i_slow.built_fast
+    uhash, ucount, postings = ok.index_build64(h, off)
+    for idx in (i_fast, i_slow):
+        p2, h2, c2 = idx.export64()
+        assert np.array_equal(p2, postings) and np.array_equal(h2, uhash) and np.array_equal(c2, ucount)
+    want, _ = ok.index_dist64(uhash, ucount, postings, np.diff(off).astype(np.uint32), h, off, 1, 0, 24, 0.05)
+    assert len(want) > 3000
+    for c, idx in ((fast, i_fast), (slow, i_slow)):
+        mine, _ = c.dist_rows(idx, None, 1, 0, 24, 0.05)
+        assert len(mine) == len(want) and np.array_equal(mine["row"], want["row"]) and np.array_equal(mine["col"], want["col"])
+        assert np.array_equal(mine["common"], want["common"]) and np.array_equal(mine["dist"], want["dist"])
+    del i_fast, i_slow
+    fast.close()
+    slow.close()
+
+
 # ------------------------------------------------------------------ host tool on the 64-bit layout
 def _tool(args, cwd=None, check=True):
     import subprocess
