@@ -1217,7 +1217,8 @@ static int cmd_alldist(const Args &a)
     vector<rk_index *> idx(G, nullptr);
     build_everywhere(set, s, sketch_path, missing, idx);
     stamp("index built");
-    cerr << "===================time of read sketches and build the index is " << get_sec() - t0 << endl;
+    // (the reference's phase line, src/dist.cpp:132-135: there the phase loads .dict/.index, here it builds the index on the device)
+    cerr << "===================time of read index and offset sketch file is: " << get_sec() - t0 << endl;
     const double t1 = get_sec();
     cerr << "=====total: " << s.size() << endl;
     vector<rk_hit *> hits(G, nullptr);
@@ -1271,6 +1272,7 @@ static int cmd_dist(const Args &a)
     const int metric = a.num("M", 0);
     const int threads = a.num("t", (int)std::thread::hardware_concurrency());
     GpuSet set(a.num("device", 0), a.num("gpus", 1), a.has("same-device"));
+    const double t_cmd0 = get_sec();
     SketchSet ref, qry;
     string ref_path, qry_path;
     {   // .sketch inputs are read while the runtime starts
@@ -1296,6 +1298,7 @@ static int cmd_dist(const Args &a)
     vector<rk_index *> idx(G, nullptr);
     build_everywhere(set, ref, ref_path, missing, idx);
     const double t1 = get_sec();
+    cerr << "===================time of read index and offset sketch file is: " << t1 - t_cmd0 << endl;   // src/dist.cpp:482-485
     cerr << "=====total: " << qry.size() << endl;
     // contiguous query blocks: GPU g gets queries [q0[g], q0[g+1]) as a sketch set of its own (the host scatters the
     // queries) and reports rows relative to it
