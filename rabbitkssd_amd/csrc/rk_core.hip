@@ -265,6 +265,9 @@ void rk_ctx_destroy(rk_ctx *ctx)
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
+        if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+        if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+        if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     }
     rk_ctx_trim(ctx);
     // blocks still handed out belong to objects the caller has not freed: they are released with the context

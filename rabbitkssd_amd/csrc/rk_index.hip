@@ -527,6 +527,13 @@ __global__ void k_gather_sketches(const K *hashes, const uint64_t *off, const ui
     for (uint64_t k = threadIdx.x & 63; k < n; k += 64) out[dst + k] = hashes[src + k];
 }
 
+// inv[orig[i]] = i
+__global__ void k_invert_order(const uint32_t *orig, uint32_t n, uint32_t *inv)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[orig[i]] = i;
+}
+
 __global__ void k_iota(uint32_t n, uint32_t *out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -787,49 +794,80 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     // ---- internal genome order: relatives next to each other (see k_minhash_insert) ---------------------------------
     // d_orig, d_sizes and d_src_off (the CSR offsets in internal order); the rest of the build, and every kernel that
     // uses the index, works in that order
+    // (round 4) It runs on a stream of its own: the partition of the hashes below does not need it -- it walks the sketches
+    // in the CALLER's order and k_bucket_emit translates the genome ids through `inv` --, so the two overlap (≈ 70 us of
+    // small dependent kernels next to ≈ 160 us of partition); `join()` makes ctx->stream wait for it where its results are
+    // first used.  The temporaries live until the function returns (the pool's reuse is ordered on ctx->stream only).
+    DevBuf<unsigned long long> rl_table(ctx), rl_keys(ctx), rl_keys_sorted(ctx);
+    DevBuf<uint32_t> rl_parent(ctx), rl_keys32(ctx), rl_rank(ctx), rl_inv(ctx);
+    DevBuf<char> rl_tmp(ctx);
+    const uint32_t *inv = nullptr;   // caller's genome index -> internal id (null: identity)
+    bool forked = false, joined = true;
+    auto join = [&]() -> int {
+        if (!joined) {
+            RK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+            joined = true;
+        }
+        return RK_OK;
+    };
     if (ctx->sw_index_relabel && s->is_set && N > 1 && H) {
+        hipStream_t s2 = st;
+        if (!getenv("RK_INDEX_ONE_STREAM")) {
+            if (!ctx->stream2) {
+                RK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+                RK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                RK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            }
+            s2 = ctx->stream2;
+            RK_HIP(ctx, hipEventRecord(ctx->ev_fork, st));          // (everything enqueued on ctx->stream so far comes first)
+            RK_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+            forked = true;
+        }
         int id_bits = 1;
         while ((1ULL << id_bits) < N) id_bits++;
         uint32_t slots = 1024;
         while (slots < 4ull * N * kMinK && slots < (1u << 30)) slots <<= 1;
-        DevBuf<unsigned long long> table(ctx);
-        DevBuf<uint32_t> parent(ctx);
-        RK_HIP(ctx, table.alloc(slots));
-        RK_HIP(ctx, parent.alloc(N));
-        RK_HIP(ctx, hipMemsetAsync(table.p, 0xFF, (size_t)slots * 8, st));
+        RK_HIP(ctx, rl_table.alloc(slots));
+        RK_HIP(ctx, rl_parent.alloc(N));
+        RK_HIP(ctx, hipMemsetAsync(rl_table.p, 0xFF, (size_t)slots * 8, s2));
         const unsigned nb_k = blocks_for((uint64_t)N * kMinK), nb_n = blocks_for(N);
         if (idx->wide) {
-            hipLaunchKernelGGL(k_minhash_insert<uint64_t>, dim3(nb_k), dim3(kThreads), 0, st, s->d_hashes64, s->d_off, N, table.p, slots - 1);
-            hipLaunchKernelGGL(k_minhash_vote<uint64_t>, dim3(nb_n), dim3(kThreads), 0, st, s->d_hashes64, s->d_off, N, table.p, slots - 1, parent.p);
+            hipLaunchKernelGGL(k_minhash_insert<uint64_t>, dim3(nb_k), dim3(kThreads), 0, s2, s->d_hashes64, s->d_off, N, rl_table.p, slots - 1);
+            hipLaunchKernelGGL(k_minhash_vote<uint64_t>, dim3(nb_n), dim3(kThreads), 0, s2, s->d_hashes64, s->d_off, N, rl_table.p, slots - 1, rl_parent.p);
         } else {
-            hipLaunchKernelGGL(k_minhash_insert<uint32_t>, dim3(nb_k), dim3(kThreads), 0, st, s->d_hashes, s->d_off, N, table.p, slots - 1);
-            hipLaunchKernelGGL(k_minhash_vote<uint32_t>, dim3(nb_n), dim3(kThreads), 0, st, s->d_hashes, s->d_off, N, table.p, slots - 1, parent.p);
+            hipLaunchKernelGGL(k_minhash_insert<uint32_t>, dim3(nb_k), dim3(kThreads), 0, s2, s->d_hashes, s->d_off, N, rl_table.p, slots - 1);
+            hipLaunchKernelGGL(k_minhash_vote<uint32_t>, dim3(nb_n), dim3(kThreads), 0, s2, s->d_hashes, s->d_off, N, rl_table.p, slots - 1, rl_parent.p);
         }
         if (N <= kRankMaxN) {
-            DevBuf<uint32_t> keys32(ctx), rank(ctx);
-            RK_HIP(ctx, keys32.alloc(N));
-            RK_HIP(ctx, rank.alloc(N));
-            RK_HIP(ctx, hipMemsetAsync(rank.p, 0, (size_t)N * 4, st));
-            hipLaunchKernelGGL(k_cluster_keys32, dim3(nb_n), dim3(kThreads), 0, st, parent.p, N, id_bits, keys32.p);
-            hipLaunchKernelGGL(k_rank_keys, dim3((N + kRankQ - 1) / kRankQ, (N + kRankStretch - 1) / kRankStretch), dim3(kRankThreads), 0, st,
-                               keys32.p, N, rank.p);
-            hipLaunchKernelGGL(k_order_from_rank, dim3(nb_n), dim3(kThreads), 0, st, rank.p, N, s->d_off, idx->d_orig, idx->d_sizes);
-            hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, st, idx->d_sizes, N, idx->d_src_off);
+            RK_HIP(ctx, rl_keys32.alloc(N));
+            RK_HIP(ctx, rl_rank.alloc(N));
+            RK_HIP(ctx, hipMemsetAsync(rl_rank.p, 0, (size_t)N * 4, s2));
+            hipLaunchKernelGGL(k_cluster_keys32, dim3(nb_n), dim3(kThreads), 0, s2, rl_parent.p, N, id_bits, rl_keys32.p);
+            hipLaunchKernelGGL(k_rank_keys, dim3((N + kRankQ - 1) / kRankQ, (N + kRankStretch - 1) / kRankStretch), dim3(kRankThreads), 0, s2,
+                               rl_keys32.p, N, rl_rank.p);
+            hipLaunchKernelGGL(k_order_from_rank, dim3(nb_n), dim3(kThreads), 0, s2, rl_rank.p, N, s->d_off, idx->d_orig, idx->d_sizes);
+            hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, s2, idx->d_sizes, N, idx->d_src_off);
+            inv = rl_rank.p;   // (a genome's rank among the keys IS its internal id)
         } else {
-            DevBuf<unsigned long long> keys(ctx), keys_sorted(ctx);
-            DevBuf<char> tmp(ctx);
-            RK_HIP(ctx, keys.alloc(N));
-            RK_HIP(ctx, keys_sorted.alloc(N));
-            hipLaunchKernelGGL(k_cluster_keys, dim3(nb_n), dim3(kThreads), 0, st, parent.p, N, id_bits, keys.p);
+            RK_HIP(ctx, rl_keys.alloc(N));
+            RK_HIP(ctx, rl_keys_sorted.alloc(N));
+            RK_HIP(ctx, rl_inv.alloc(N));
+            hipLaunchKernelGGL(k_cluster_keys, dim3(nb_n), dim3(kThreads), 0, s2, rl_parent.p, N, id_bits, rl_keys.p);
             size_t tb = 0;
-            RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, keys.p, keys_sorted.p, N, 0, (unsigned)(2 * id_bits), st));
-            RK_HIP(ctx, tmp.alloc(tb));
-            RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, tb, keys.p, keys_sorted.p, N, 0, (unsigned)(2 * id_bits), st));
-            hipLaunchKernelGGL(k_order_from_keys, dim3(nb_n), dim3(kThreads), 0, st, keys_sorted.p, N, id_bits, s->d_off, idx->d_orig, idx->d_sizes);
-            hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, st, idx->d_sizes, N, idx->d_src_off);
+            RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, rl_keys.p, rl_keys_sorted.p, N, 0, (unsigned)(2 * id_bits), s2));
+            RK_HIP(ctx, rl_tmp.alloc(tb));
+            RK_HIP(ctx, rocprim::radix_sort_keys(rl_tmp.p, tb, rl_keys.p, rl_keys_sorted.p, N, 0, (unsigned)(2 * id_bits), s2));
+            hipLaunchKernelGGL(k_order_from_keys, dim3(nb_n), dim3(kThreads), 0, s2, rl_keys_sorted.p, N, id_bits, s->d_off, idx->d_orig, idx->d_sizes);
+            hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, s2, idx->d_sizes, N, idx->d_src_off);
+            hipLaunchKernelGGL(k_invert_order, dim3(nb_n), dim3(kThreads), 0, s2, idx->d_orig, N, rl_inv.p);
+            inv = rl_inv.p;
         }
         idx->relabeled = true;
         RK_HIP(ctx, hipGetLastError());
+        if (forked) {
+            RK_HIP(ctx, hipEventRecord(ctx->ev_join, s2));
+            joined = false;
+        }
     } else {
         hipLaunchKernelGGL(k_iota, dim3(blocks_for((uint64_t)N + 1)), dim3(kThreads), 0, st, N, idx->d_orig);
         hipLaunchKernelGGL(k_sizes, dim3(blocks_for((uint64_t)N + 1)), dim3(kThreads), 0, st, s->d_off, N, idx->d_sizes, idx->d_src_off);
@@ -859,8 +897,8 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         FastArgs fa;
         fa.hashes = idx->wide ? (const void *)s->d_hashes64 : (const void *)s->d_hashes;
         fa.off = s->d_off;
-        fa.orig = idx->d_orig;
-        fa.off_new = idx->d_src_off;
+        fa.orig = nullptr;           // the partition walks the sketches in the caller's order (see the renumbering above)
+        fa.off_new = s->d_off;
         fa.n_genomes = N;
         fa.H = H;
         fa.hash_bits = hash_bits;
@@ -894,7 +932,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_hist<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
             RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_scatter<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
         }
-        hipLaunchKernelGGL(k_chunk_first, dim3(blocks_for((uint64_t)fa.n_chunks + 1)), dim3(kThreads), 0, st, idx->d_src_off, N, fa.n_chunks, chunk_first.p);
+        hipLaunchKernelGGL(k_chunk_first, dim3(blocks_for((uint64_t)fa.n_chunks + 1)), dim3(kThreads), 0, st, s->d_off, N, fa.n_chunks, chunk_first.p);
         if (wide) hipLaunchKernelGGL(k_part_hist<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, res.p);
         else hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, res.p);
         hipLaunchKernelGGL(k_part_colscan, dim3((fa.nb + 63) / 64), dim3(1024), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
@@ -928,6 +966,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         ea.keys = keys.p;
         ea.bstart = bstart.p;
         ea.off_new = idx->d_src_off;
+        ea.inv = inv;
         ea.low_bits = low_bits;
         ea.gb = gb;
         ea.rb = rb;
@@ -946,6 +985,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             RK_HIP(ctx, hipMemsetAsync(self_raw.p, 0, H * sizeof(uint2), st));
             RK_HIP(ctx, hipMemsetAsync(tmp_upos.p, 0, H * 4, st));
         }
+        RK_TRY(join());   // the internal order (inv, the offsets in internal order) is needed from here on
         {
             const int emit_t = getenv("RK_INDEX_EMIT_T") ? atoi(getenv("RK_INDEX_EMIT_T")) : 512;
             const bool narrow = low_bits + gb <= 32;  // (hash_low, genome) fits 32 bits
@@ -977,6 +1017,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         }
     }
 
+    RK_TRY(join());
     if (!built && H) {
         // ---- general path: device-wide stable radix sort of (hash, source element) -------------------------------------
         const uint32_t *src_hashes = s->d_hashes;

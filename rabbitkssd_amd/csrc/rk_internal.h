@@ -22,6 +22,10 @@ struct rk_ctx {
     // the context's own stream: every synchronous API call enqueues here (never on the null stream, whose implicit
     // synchronisation would serialise the caller's other streams) and synchronises it before returning
     hipStream_t stream = nullptr;
+    // a second stream + two events (created on first use): rk_index_build computes the internal genome order there while
+    // the partition of the hashes runs on `stream`
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void *pinned = nullptr;  // page-locked scratch for small read-backs / uploads (grow-only, see rk_pinned_scratch)
     size_t pinned_bytes = 0;
     // caching device allocator: hipMalloc / hipFree cost 50-300 us each (hipFree also synchronises the device) and the
