@@ -996,18 +996,31 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             else RK_EMIT(512);
 #undef RK_EMIT
         }
-        hipLaunchKernelGGL(k_heads_scan, dim3(1), dim3(1024), 0, st, ucount.p, fa.nb, ubase.p, res.p);
+        // the list heads (scan + placement) and the rows (counts, scan, placement) both hang on the emission alone: the heads go
+        // to the second stream, the rows stay here
+        hipStream_t sh = st;
+        if (forked) {
+            RK_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+            RK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            sh = ctx->stream2;
+        }
+        hipLaunchKernelGGL(k_heads_scan, dim3(1), dim3(1024), 0, sh, ucount.p, fa.nb, ubase.p, res.p);
         if (wide)
-            hipLaunchKernelGGL(k_heads_place<unsigned long long>, dim3(fa.nb), dim3(kThreads), 0, st, tmp_uhash64.p, tmp_upos.p, bstart.p, ucount.p, ubase.p,
+            hipLaunchKernelGGL(k_heads_place<unsigned long long>, dim3(fa.nb), dim3(kThreads), 0, sh, tmp_uhash64.p, tmp_upos.p, bstart.p, ucount.p, ubase.p,
                                fa.nb, (uint32_t)H, (unsigned long long *)idx->d_uhash64, idx->d_upos);
         else
-            hipLaunchKernelGGL(k_heads_place<uint32_t>, dim3(fa.nb), dim3(kThreads), 0, st, tmp_uhash.p, tmp_upos.p, bstart.p, ucount.p, ubase.p, fa.nb,
+            hipLaunchKernelGGL(k_heads_place<uint32_t>, dim3(fa.nb), dim3(kThreads), 0, sh, tmp_uhash.p, tmp_upos.p, bstart.p, ucount.p, ubase.p, fa.nb,
                                (uint32_t)H, idx->d_uhash, idx->d_upos);
+        if (forked) {
+            RK_HIP(ctx, hipEventRecord(ctx->ev_join, sh));
+            joined = false;
+        }
         hipLaunchKernelGGL(k_row_counts2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, n_open.p, n_cov.p);
         hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, res.p);
         hipLaunchKernelGGL(k_row_place2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, idx->d_self_off,
                            idx->d_self_split, idx->d_selfrange);
         RK_HIP(ctx, hipGetLastError());
+        RK_TRY(join());
         RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));  // the one synchronisation of the build
         if (ctx->sw_dist_debug) fprintf(stderr, "[rk] index build: fast path flags %llu (B %d, low bits %d, genome bits %d, position bits %d)\n", r.flags, B, low_bits, gb, rb);
         if (r.flags == 0) built = true;
