@@ -5,10 +5,6 @@ timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -k "tile_self
 tail -2 gpurun_out/tile_tests.log
 export RK_DIST_TILES=1
 drv() { timeout -k 10 300 python3 tools/prof_driver.py "$@" 2>&1 | grep -v amdgpu.ids | tail -${LINES:-1} | cut -c1-60; }
-echo "10k: $(drv dist 10000 20)"
-echo "c100: $(drv dist 10000 20 1 0 0 100)"
-echo "c1000: $(drv dist 10000 20 1 0 0 1000)"
-echo "50k: $(drv dist 50000 10)"
-echo "10k: $(drv dist 10000 20)"
-echo "c100: $(drv dist 10000 20 1 0 0 100)"
-echo "c1000: $(drv dist 10000 20 1 0 0 1000)"
+for ms in 1 4 8 16; do
+echo "min share $ms: 10k $(RK_TILE_MIN_SHARE=$ms drv dist 10000 20) | c100 $(RK_TILE_MIN_SHARE=$ms drv dist 10000 20 1 0 0 100) | c1000 $(RK_TILE_MIN_SHARE=$ms drv dist 10000 20 1 0 0 1000) | 50k $(RK_TILE_MIN_SHARE=$ms drv dist 50000 10)"
+done
