@@ -90,6 +90,11 @@ void rk_ctx_pool_stats(rk_ctx *ctx, uint64_t out[4]);
  * rk_sketch_* call.  (The distance entry points launch one kernel per call or band: bracket rk_dist_rows_dev yourself.) */
 #define RK_MS_SKETCH_KERNEL 0
 void rk_ctx_set_timing(rk_ctx *ctx, int on);
+/* A process that makes ONE pass (a command-line tool) says so: the library then keeps work on the host where the device path
+ * would first have to load a code object that costs more than it saves on a single call (today: ordering up to 2^18 hit
+ * records by (row, col) in rk_dist_rows: 8 ms to load the sort against 3 ms of std::sort for 45,000 records).  Results are
+ * the same either way. */
+void rk_ctx_set_single_shot(rk_ctx *ctx, int on);
 double rk_ctx_last_ms(const rk_ctx *ctx, int which);
 const char *rk_last_error(const rk_ctx *ctx);
 const char *rk_version(void);

@@ -16,7 +16,7 @@ HIT_DTYPE = np.dtype([("row", "<u4"), ("col", "<u4"), ("common", "<i4"), ("size0
                       ("size1", "<i4"), ("pad", "<i4"), ("jorc", "<f8"), ("dist", "<f8")])
 
 EXPORTS = [
-    "rk_device_count", "rk_ctx_create", "rk_ctx_destroy", "rk_ctx_trim", "rk_ctx_pool_stats", "rk_ctx_set_timing", "rk_ctx_last_ms", "rk_dist_kernel_name", "rk_last_error", "rk_version",
+    "rk_device_count", "rk_ctx_create", "rk_ctx_destroy", "rk_ctx_trim", "rk_ctx_pool_stats", "rk_ctx_set_timing", "rk_ctx_set_single_shot", "rk_ctx_last_ms", "rk_dist_kernel_name", "rk_last_error", "rk_version",
     "rk_free_host", "rk_pinned_alloc", "rk_pinned_free", "rk_dev_alloc", "rk_dev_free", "rk_stream_create",
     "rk_stream_destroy", "rk_stream_sync", "rk_upload_async", "rk_dev_copy_async", "rk_params_init", "rk_hash_bits", "rk_filter_create", "rk_filter_free",
     "rk_sketch_batch", "rk_sketch_batch_ex", "rk_sketch_packed_dev", "rk_sketch_packed_dev_ex", "rk_pack_layout", "rk_pack_genomes",

@@ -223,6 +223,11 @@ int rk_ctx_create(int device, rk_ctx **out)
     return RK_OK;
 }
 
+void rk_ctx_set_single_shot(rk_ctx *ctx, int on)
+{
+    if (ctx) ctx->single_shot = on != 0;
+}
+
 void rk_ctx_set_timing(rk_ctx *ctx, int on)
 {
     if (!ctx) return;

@@ -28,7 +28,6 @@
 #include <tuple>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
 
 #include "rk_internal.h"
 #include "rk_dist_common.h"
@@ -1468,18 +1467,13 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
         const rk_hit *src = hits.p;
         DevBuf<rk_hit> ordered(ctx);
         bool on_device = false;
-        if (n > 2048) {  // order the result on the device (45,000 hits: 0.1 ms against 2 ms of std::sort); on any failure the host sorts
+        if (n > (ctx->single_shot ? (1ULL << 18) : 2048ULL)) {  // order the result on the device (45,000 hits: 0.1 ms against 2 ms of std::sort); on any failure the host sorts
             DevBuf<unsigned long long> keys(ctx), keys_out(ctx);
-            DevBuf<char> tmp(ctx);
-            size_t tb = 0;
             int bits = 33;
             while (bits < 64 && (1ULL << (bits - 32)) < n_query) bits++;
-            if (keys.alloc(n) == hipSuccess && keys_out.alloc(n) == hipSuccess && ordered.alloc(n) == hipSuccess &&
-                rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys_out.p, hits.p, ordered.p, n, 0, (unsigned)bits, stream) == hipSuccess &&
-                tmp.alloc(tb) == hipSuccess) {
+            if (keys.alloc(n) == hipSuccess && keys_out.alloc(n) == hipSuccess && ordered.alloc(n) == hipSuccess) {
                 hipLaunchKernelGGL(k_hit_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, hits.p, n, keys.p);
-                on_device = rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys_out.p, hits.p, ordered.p, n, 0, (unsigned)bits, stream) == hipSuccess &&
-                            hipStreamSynchronize(stream) == hipSuccess;
+                on_device = rk_prim_sort_hits(ctx, keys.p, keys_out.p, hits.p, ordered.p, n, (unsigned)bits, stream) == RK_OK;
             }
             if (on_device) src = ordered.p;
             else (void)hipGetLastError();

@@ -19,7 +19,6 @@
 // stream, every buffer from the context's pool, ONE 32-byte read-back at the end: no hipMalloc, no hipFree and
 // no intermediate synchronisation in steady state.
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -27,6 +26,8 @@
 #include <thread>
 
 #include "rk_internal.h"
+
+#define RK_TRY(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
 
 namespace {
 
@@ -576,10 +577,7 @@ int postings_in_caller_ids(rk_ctx *ctx, const rk_index *idx, hipStream_t st, uin
     while (ubits < 32 && (1ULL << ubits) < idx->U) ubits++;
     hipLaunchKernelGGL(k_export_keys, dim3(blocks_for(idx->H)), dim3(kThreads), 0, st, idx->d_postings, idx->d_upos, idx->U, idx->H,
                        idx->d_orig, keys.p);
-    size_t tb = 0;
-    RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, keys.p, sorted.p, idx->H, 0, (unsigned)(32 + ubits), st));
-    RK_HIP(ctx, tmp.alloc(tb));
-    RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, tb, keys.p, sorted.p, idx->H, 0, (unsigned)(32 + ubits), st));
+    RK_TRY(rk_prim_sort_keys_u64(ctx, keys.p, sorted.p, idx->H, 0, (unsigned)(32 + ubits), st));
     hipLaunchKernelGGL(k_low_halves, dim3(blocks_for(idx->H)), dim3(kThreads), 0, st, sorted.p, idx->H, res.p);
     RK_HIP(ctx, hipGetLastError());
     RK_HIP(ctx, hipStreamSynchronize(st));  // the temporaries return to the pool
@@ -594,7 +592,6 @@ template <class T> int pool_array(rk_ctx *ctx, T **out, size_t n)
     *out = static_cast<T *>(rk_pool_alloc(ctx, (n ? n : 1) * sizeof(T)));
     return *out ? RK_OK : rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu bytes on the device", (unsigned long long)(n * sizeof(T)));
 }
-#define RK_TRY(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
 
 void set_dir_shape(rk_index *idx)
 {
@@ -800,7 +797,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     // first used.  The temporaries live until the function returns (the pool's reuse is ordered on ctx->stream only).
     DevBuf<unsigned long long> rl_table(ctx), rl_keys(ctx), rl_keys_sorted(ctx);
     DevBuf<uint32_t> rl_parent(ctx), rl_keys32(ctx), rl_rank(ctx), rl_inv(ctx);
-    DevBuf<char> rl_tmp(ctx);
+    DevBuf<char> rl_tmp(ctx);   // the sort's scratch (kept until this function returns: the sort runs on the second stream)
     const uint32_t *inv = nullptr;   // caller's genome index -> internal id (null: identity)
     bool forked = false, joined = true;
     auto join = [&]() -> int {
@@ -853,10 +850,9 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             RK_HIP(ctx, rl_keys_sorted.alloc(N));
             RK_HIP(ctx, rl_inv.alloc(N));
             hipLaunchKernelGGL(k_cluster_keys, dim3(nb_n), dim3(kThreads), 0, s2, rl_parent.p, N, id_bits, rl_keys.p);
-            size_t tb = 0;
-            RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, tb, rl_keys.p, rl_keys_sorted.p, N, 0, (unsigned)(2 * id_bits), s2));
-            RK_HIP(ctx, rl_tmp.alloc(tb));
-            RK_HIP(ctx, rocprim::radix_sort_keys(rl_tmp.p, tb, rl_keys.p, rl_keys_sorted.p, N, 0, (unsigned)(2 * id_bits), s2));
+            void *scratch = nullptr;
+            RK_TRY(rk_prim_sort_keys_u64(ctx, rl_keys.p, rl_keys_sorted.p, N, 0, (unsigned)(2 * id_bits), s2, &scratch));
+            rl_tmp.p = static_cast<char *>(scratch);
             hipLaunchKernelGGL(k_order_from_keys, dim3(nb_n), dim3(kThreads), 0, s2, rl_keys_sorted.p, N, id_bits, s->d_off, idx->d_orig, idx->d_sizes);
             hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, s2, idx->d_sizes, N, idx->d_src_off);
             hipLaunchKernelGGL(k_invert_order, dim3(nb_n), dim3(kThreads), 0, s2, idx->d_orig, N, rl_inv.p);
@@ -1068,25 +1064,14 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         hipLaunchKernelGGL(k_fill_gid, dim3(wave_blocks), dim3(kThreads), 0, st, src_off, N, gid.p, iota.p);
         // stable LSD radix sort by hash; values = source element index (genome-major), so equal hashes stay in
         // ascending genome order == hashMapId[hash].push_back(i) for i ascending (src/sketch.cpp:979-985)
-        size_t t_sort = 0, t_scan = 0;
-        if (idx->wide)
-            RK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t_sort, src_hashes64, keys_sorted64.p, iota.p, sorted_e.p, H, 0,
-                                                  (unsigned)hash_bits, st));
-        else
-            RK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t_sort, src_hashes, keys_sorted.p, iota.p, sorted_e.p, H, 0,
-                                                  (unsigned)hash_bits, st));
-        RK_HIP(ctx, rocprim::inclusive_scan(nullptr, t_scan, flags.p, iota.p, H, rocprim::plus<uint32_t>(), st));
-        RK_HIP(ctx, tmp.alloc(std::max(t_sort, t_scan)));
         if (idx->wide) {
-            RK_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, t_sort, src_hashes64, keys_sorted64.p, iota.p, sorted_e.p, H, 0,
-                                                  (unsigned)hash_bits, st));
+            RK_TRY(rk_prim_sort_pairs_u64_u32(ctx, src_hashes64, keys_sorted64.p, iota.p, sorted_e.p, H, (unsigned)hash_bits, st));
             hipLaunchKernelGGL(k_head_flags<uint64_t>, dim3(blocks_for(H)), dim3(kThreads), 0, st, keys_sorted64.p, H, flags.p);
         } else {
-            RK_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, t_sort, src_hashes, keys_sorted.p, iota.p, sorted_e.p, H, 0,
-                                                  (unsigned)hash_bits, st));
+            RK_TRY(rk_prim_sort_pairs_u32_u32(ctx, src_hashes, keys_sorted.p, iota.p, sorted_e.p, H, (unsigned)hash_bits, st));
             hipLaunchKernelGGL(k_head_flags<uint32_t>, dim3(blocks_for(H)), dim3(kThreads), 0, st, keys_sorted.p, H, flags.p);
         }
-        RK_HIP(ctx, rocprim::inclusive_scan(tmp.p, t_scan, flags.p, iota.p, H, rocprim::plus<uint32_t>(), st));
+        RK_TRY(rk_prim_inclusive_scan_u32(ctx, flags.p, iota.p, H, st));
         uint32_t *gidx = iota.p;  // 1-based group number of each sorted position
         if (idx->wide)
             hipLaunchKernelGGL(k_scatter_heads<uint64_t>, dim3(blocks_for(H)), dim3(kThreads), 0, st, keys_sorted64.p, gidx, H,
@@ -1169,12 +1154,8 @@ int rk_index_import(rk_ctx *ctx, const uint32_t *postings, uint64_t total, const
     RK_HIP(ctx, cpos.alloc(hs));
     RK_HIP(ctx, hipMemcpyAsync(d_counts.p, counts, hs * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_nonzero_flags, dim3(blocks_for(hs)), dim3(kThreads), 0, st, d_counts.p, hs, flags.p);
-    size_t tb = 0;
-    RK_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, flags.p, rank.p, 0u, hs, rocprim::plus<uint32_t>(), st));
-    DevBuf<char> tmp(ctx);
-    RK_HIP(ctx, tmp.alloc(tb));
-    RK_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb, flags.p, rank.p, 0u, hs, rocprim::plus<uint32_t>(), st));
-    RK_HIP(ctx, rocprim::exclusive_scan(tmp.p, tb, d_counts.p, cpos.p, 0u, hs, rocprim::plus<uint32_t>(), st));
+    RK_TRY(rk_prim_exclusive_scan_u32(ctx, flags.p, rank.p, hs, st));
+    RK_TRY(rk_prim_exclusive_scan_u32(ctx, d_counts.p, cpos.p, hs, st));
     uint32_t last[4] = {0, 0, 0, 0};  // rank, flag, cpos, count of the last hash value
     DevBuf<uint32_t> last_dev(ctx);
     RK_HIP(ctx, last_dev.alloc(4));

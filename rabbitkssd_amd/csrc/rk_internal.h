@@ -40,6 +40,8 @@ struct rk_ctx {
     size_t cache_limit = 0;          // idle bytes above this go straight back to the driver (RK_POOL_LIMIT_MB, default 32 GiB)
     std::map<std::tuple<const void *, int, size_t>, int> occupancy;  // hipOccupancy... costs 10-70 us per query
     // optional HIP-event timing of the dominant kernel of a pass (rk_ctx_set_timing): [0] sketch kernel
+    bool single_shot = false;  // rk_ctx_set_single_shot: a command-line run -- avoid device-side paths whose one-time setup (a code
+                               // object load) costs more than they save on one call
     bool timing = false;
     hipEvent_t ev[2] = {nullptr, nullptr};
     double last_ms[4] = {0, 0, 0, 0};
@@ -195,7 +197,7 @@ struct rk_index {
     unsigned long long *d_tile_start = nullptr; // u64[n_tiles + 1]
     uint32_t *d_blk_min = nullptr;              // u32[ceil(n_ref / 32)]: smallest non-empty sketch of the block
     uint32_t *d_tile_order[2] = {nullptr, nullptr};  // tile numbers by records per smallest sketch, descending: [0] jaccard, [1] containment
-    unsigned long long tile_prefix[2][256] = {};     // [metric][k]: tiles with at least 2^(-k/8) records per smallest sketch
+    unsigned long long tile_prefix[2][256] = {};     // (kTileTable entries each)     // [metric][k]: tiles with at least 2^(-k/8) records per smallest sketch
     uint64_t n_tiles = 0, n_tile_records = 0;
     bool tiles_ready = false;
     int spread_known = 0;            // 1: `spread` below is valid (rk_dist.hip self_uses_tiles)
@@ -204,6 +206,29 @@ struct rk_index {
                                      // squares): two host threads may query one index
 };
 
+// device-wide primitives behind plain functions (rk_prims.hip, rk_prims_hits.hip: translation units of their own, so that
+// the code objects of the callers stay small -- a code object is loaded when the first kernel of its translation unit runs).
+// All enqueue on `st`; temporaries come from the context's pool and return to it when the wrapper returns.
+int rk_prim_sort_keys_u64(rk_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint64_t n, unsigned begin_bit, unsigned end_bit,
+                          hipStream_t st, void **tmp_keep = nullptr);   // tmp_keep: the scratch block is handed to the caller (rk_pool_free)
+int rk_prim_sort_pairs_u32_u32(rk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n, unsigned end_bit,
+                               hipStream_t st);
+int rk_prim_sort_pairs_u64_u32(rk_ctx *ctx, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n, unsigned end_bit,
+                               hipStream_t st);
+int rk_prim_inclusive_scan_u32(rk_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t st);
+int rk_prim_exclusive_scan_u32(rk_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t st);
+int rk_prim_unique_u64(rk_ctx *ctx, const unsigned long long *in, unsigned long long *out, unsigned long long *n_out_dev, uint64_t n, hipStream_t st);
+int rk_prim_rle_u64(rk_ctx *ctx, const unsigned long long *in, uint64_t n, unsigned long long *runs, unsigned int *counts, unsigned long long *n_runs_dev,
+                    hipStream_t st);
+int rk_prim_select_u64(rk_ctx *ctx, const unsigned long long *in, const unsigned char *flags, unsigned long long *out, unsigned long long *n_out_dev,
+                       uint64_t n, hipStream_t st);
+int rk_prim_segmented_sort_u32(rk_ctx *ctx, const uint32_t *in, uint32_t *out, unsigned n, unsigned segments, const uint64_t *off, hipStream_t st);
+int rk_prim_segmented_sort_u64(rk_ctx *ctx, const uint64_t *in, uint64_t *out, unsigned n, unsigned segments, const uint64_t *off, hipStream_t st);
+int rk_prim_sort_hits(rk_ctx *ctx, const unsigned long long *keys, unsigned long long *keys_out, const rk_hit *hits, rk_hit *hits_out, uint64_t n,
+                      unsigned end_bit, hipStream_t st);   // synchronises `st`
+// tile records of the self join over 32 x 32 tiles, built on first use and cached in the index (rk_tiles.hip)
+constexpr int kTileTable = 256;   // entries of rk_index::tile_prefix per metric
+int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t stream);
 // prefix directory into the sorted distinct hashes, built on first use (rk_index.hip)
 int rk_index_ensure_dir(rk_ctx *ctx, rk_index *idx, hipStream_t stream);
 // explicit queries (index_dist): lookup + counting + epilogue in one kernel (rk_distq.hip).  Enqueues on `stream`,

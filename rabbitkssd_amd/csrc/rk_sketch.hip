@@ -20,7 +20,6 @@
 // Per-genome dedup (the reference's unordered_set): one workgroup per genome sorts its region in LDS
 // (k_dedup), a scan and a placement kernel build the CSR; one upload and one read-back per batch.
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cstdlib>
@@ -905,39 +904,27 @@ static int dedup_big(rk_ctx *ctx, unsigned long long *region, uint32_t n, int ha
     *n_out = 0;
     if (!n) return RK_OK;
     DevBuf<unsigned long long> sorted(ctx), uniq(ctx), d_n(ctx);
-    DevBuf<char> tmp(ctx);
     RK_HIP(ctx, sorted.alloc(n));
     RK_HIP(ctx, uniq.alloc(n));
     RK_HIP(ctx, d_n.alloc(1));
-    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-    RK_HIP(ctx, rocprim::radix_sort_keys(nullptr, t1, region, sorted.p, n, 0, (unsigned)hash_bits, stream));
-    RK_HIP(ctx, tmp.alloc(t1));
-    RK_HIP(ctx, rocprim::radix_sort_keys(tmp.p, t1, region, sorted.p, n, 0, (unsigned)hash_bits, stream));
+    RK_TRY(rk_prim_sort_keys_u64(ctx, region, sorted.p, n, 0, (unsigned)hash_bits, stream));
     unsigned long long nu = 0;
     if (min_count <= 1) {  // set semantics (FASTA, src/sketch.cpp:526-529)
-        RK_HIP(ctx, rocprim::unique(nullptr, t2, sorted.p, uniq.p, d_n.p, n, rocprim::equal_to<unsigned long long>(), stream));
-        DevBuf<char> tmp2(ctx);
-        RK_HIP(ctx, tmp2.alloc(t2));
-        RK_HIP(ctx, rocprim::unique(tmp2.p, t2, sorted.p, uniq.p, d_n.p, n, rocprim::equal_to<unsigned long long>(), stream));
+        RK_TRY(rk_prim_unique_u64(ctx, sorted.p, uniq.p, d_n.p, n, stream));
         RK_TRY(rk_read_back(ctx, &nu, d_n.p, 8, stream));
     } else {  // FASTQ: keep a hash only if it occurred >= min_count times (src/sketch.cpp:828-845)
         DevBuf<unsigned long long> runs(ctx);
         DevBuf<unsigned int> counts(ctx);
         DevBuf<unsigned char> flags(ctx);
-        DevBuf<char> tmp3(ctx), tmp4(ctx);
         RK_HIP(ctx, runs.alloc(n));
         RK_HIP(ctx, counts.alloc(n));
         RK_HIP(ctx, flags.alloc(n));
-        RK_HIP(ctx, rocprim::run_length_encode(nullptr, t3, sorted.p, n, runs.p, counts.p, d_n.p, stream));
-        RK_HIP(ctx, tmp3.alloc(t3));
-        RK_HIP(ctx, rocprim::run_length_encode(tmp3.p, t3, sorted.p, n, runs.p, counts.p, d_n.p, stream));
+        RK_TRY(rk_prim_rle_u64(ctx, sorted.p, n, runs.p, counts.p, d_n.p, stream));
         unsigned long long n_runs = 0;
         RK_TRY(rk_read_back(ctx, &n_runs, d_n.p, 8, stream));
         if (n_runs) {
             hipLaunchKernelGGL(k_count_flags, dim3(blocks_for(n_runs)), dim3(256), 0, stream, counts.p, n_runs, min_count, flags.p);
-            RK_HIP(ctx, rocprim::select(nullptr, t4, runs.p, flags.p, uniq.p, d_n.p, n_runs, stream));
-            RK_HIP(ctx, tmp4.alloc(t4));
-            RK_HIP(ctx, rocprim::select(tmp4.p, t4, runs.p, flags.p, uniq.p, d_n.p, n_runs, stream));
+            RK_TRY(rk_prim_select_u64(ctx, runs.p, flags.p, uniq.p, d_n.p, n_runs, stream));
             RK_TRY(rk_read_back(ctx, &nu, d_n.p, 8, stream));
         }
     }
@@ -1262,25 +1249,18 @@ int rk_sketches_classify(rk_ctx *ctx, rk_sketches *s)
     bool ascending = true;
     RK_TRY(check_sets(ctx, s, &ascending));
     if (!ascending && s->total < 0xFFFFFFFFULL) {
-        size_t tb = 0;
         const unsigned int n = (unsigned int)s->total;
         if (s->wide) {
             DevBuf<uint64_t> sorted(ctx);
-            DevBuf<char> tmp(ctx);
             RK_HIP(ctx, sorted.alloc(s->total + 1));
-            RK_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, s->d_hashes64, sorted.p, n, s->n, s->d_off, s->d_off + 1, 0, 64, ctx->stream));
-            RK_HIP(ctx, tmp.alloc(tb));
-            RK_HIP(ctx, rocprim::segmented_radix_sort_keys(tmp.p, tb, s->d_hashes64, sorted.p, n, s->n, s->d_off, s->d_off + 1, 0, 64, ctx->stream));
+            RK_TRY(rk_prim_segmented_sort_u64(ctx, s->d_hashes64, sorted.p, n, s->n, s->d_off, ctx->stream));
             RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
             rk_pool_free(ctx, s->d_hashes64);
             s->d_hashes64 = sorted.release();
         } else {
             DevBuf<uint32_t> sorted(ctx);
-            DevBuf<char> tmp(ctx);
             RK_HIP(ctx, sorted.alloc(s->total + 1));
-            RK_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, s->d_hashes, sorted.p, n, s->n, s->d_off, s->d_off + 1, 0, 32, ctx->stream));
-            RK_HIP(ctx, tmp.alloc(tb));
-            RK_HIP(ctx, rocprim::segmented_radix_sort_keys(tmp.p, tb, s->d_hashes, sorted.p, n, s->n, s->d_off, s->d_off + 1, 0, 32, ctx->stream));
+            RK_TRY(rk_prim_segmented_sort_u32(ctx, s->d_hashes, sorted.p, n, s->n, s->d_off, ctx->stream));
             RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
             rk_pool_free(ctx, s->d_hashes);
             s->d_hashes = sorted.release();

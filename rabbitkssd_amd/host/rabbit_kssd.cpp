@@ -71,6 +71,7 @@ struct Gpu {
         stamp("before rk_ctx_create");
         int rc = rk_ctx_create(device, &ctx);
         if (rc) die("no usable GPU (rk_ctx_create(%d) = %d): this build has no CPU path", device, rc);
+        rk_ctx_set_single_shot(ctx, 1);   // one pass per process: nothing amortises a one-time device-side setup
         stamp("context ready");
     }
     // The process ends right after its last GPU call (main leaves through _exit): returning ~600 MB of pooled device
