@@ -9,7 +9,7 @@ alldist from precomputed .sketch/.dict").
 
 One "step" = one pass of the hot path (intersection counting through the inverted index +
 Jaccard->Mash epilogue + hit compaction, ONE kernel launch per rank) over this rank's query rows.
-Multi-GPU: blocks of 16 consecutive query rows are dealt round-robin to the ranks (block-cyclic),
+Multi-GPU: blocks of 32 consecutive query rows are dealt round-robin to the ranks (block-cyclic),
 the reference index is built on rank 0 and sent to every peer with ONE RCCL broadcast (outside the
 timed region); there is no data-path collective and no reduction.  Scaling is STRONG by default --
 the metric is "10k bacteria at 1/2/4/8 GPUs", so the dataset stays 10,000 genomes at every N
@@ -404,7 +404,7 @@ def shard_rehearsal(env, index, n_genomes, steps=30):
         if S == 1:
             t1 = per[0]
         out[str(S)] = {"shard_ms": per, "slowest_ms": max(per), "predicted_efficiency": t1 / (S * max(per))}
-    # the floor of any shard: ONE block of 16 rows (8 units, 8 waves) -- a kernel launch plus one unit's chain of dependent loads
+    # the floor of any shard: ONE block of 32 rows (16 units, 16 waves) -- a kernel launch plus one unit's chain of dependent loads
     blocks = (n_genomes + shard.ROW_BLOCK - 1) // shard.ROW_BLOCK
     counters = torch.zeros(counter_slots(steps, 2), dtype=torch.int64, device=env.dev)
 
@@ -1060,7 +1060,7 @@ def main():
                    "postings_streamed_T": head["postings_streamed_T"], "hits": head["hits"], "max_dist": MAX_DIST,
                    "slice_records": head["slice_records"], "compact_share": head["compact_share"],
                    "records_walked_per_launch": head["records_walked"],
-                   "sharding": "query rows in blocks of 16 dealt round-robin to %d rank(s); index broadcast once (RCCL on GPUs)" % world,
+                   "sharding": "query rows in blocks of %d dealt round-robin to %d rank(s); sketches broadcast once (RCCL on GPUs), index built per rank" % (shard.ROW_BLOCK, world),
                    "step": "one rk_dist_rows_dev call: rk_near_kernel counts and evaluates every pair of the launch; its exact "
                            "fallback pass (rows whose far cells could be reportable) is launched until a completed launch with "
                            "the same options has shown that list to be empty -- here after the warm-up -- and skipped from then on "

@@ -259,8 +259,9 @@ typedef struct rk_dist_opts {
     int32_t kmer_size;  /* 2*half_k                                                    */
     int32_t row_block;  /* rows are dealt to the shards in blocks of row_block consecutive rows
                            (block-cyclic); 0,1 = single rows.  An even row_block lets the
-                           all-vs-all kernel walk neighbouring rows in pairs (16 is a good
-                           value for multi-GPU runs)                                       */
+                           all-vs-all kernel walk neighbouring rows in pairs, a multiple of 32
+                           lets the tile kernel count every tile on one shard only (32 is a
+                           good value for multi-GPU runs)                                   */
     double max_dist;    /* -D                                                          */
     uint32_t row_first; /* this shard owns blocks row_first, row_first+row_step, ...:  */
     uint32_t row_step;  /*   row sharding across GPUs; 0,1 = all rows.  queries == NULL (self join): rows of the

@@ -1156,7 +1156,7 @@ static int cmd_sketch(const Args &a)
 
 // ---- several GPUs in one process (rows are independent: `#pragma omp parallel for` over rows, src/dist.cpp:174,560)
 // One context and one host thread per GPU.  Every GPU builds its own copy of the index from the host's sketches
-// (build_everywhere; RK_MULTI_BROADCAST=1: built once, replicated with rk_index_broadcast); alldist deals blocks of 16 rows round-robin,
+// (build_everywhere; RK_MULTI_BROADCAST=1: built once, replicated with rk_index_broadcast); alldist deals blocks of 32 rows round-robin,
 // dist hands every GPU a contiguous block of queries; per-GPU hits go to the writer as they are (no reduction).
 struct GpuSet {
     vector<std::unique_ptr<AsyncGpu>> gpus;
@@ -1169,7 +1169,7 @@ struct GpuSet {
     Gpu &operator[](size_t g) { return gpus[g]->get(); }
 };
 
-static const int kRowBlock = 16;
+static const int kRowBlock = 32;   // rows are dealt to the GPUs in blocks of 32: a multiple of the tile kernel's block, an even number for the row pairs
 
 // The index on every GPU of the set.  Default: every GPU uploads the sketches over its own PCIe link and builds its own
 // index, all at the same time (the build is deterministic: same internal genome order, same postings everywhere) -- 49 MB
@@ -1350,7 +1350,7 @@ static int cmd_dist(const Args &a)
 }
 
 // test helper: the text writer alone (no GPU): `_format alldist|dist names.txt hits.bin out pieces threads`;
-// hits.bin = rk_hit records sorted by (row, col), dealt to `pieces` parts in blocks of 16 rows like --gpus does
+// hits.bin = rk_hit records sorted by (row, col), dealt to `pieces` parts in blocks of 32 rows like --gpus does
 static int cmd_format(int argc, char **argv)
 {
     if (argc != 8) die("_format alldist|dist names.txt hits.bin out parts threads");

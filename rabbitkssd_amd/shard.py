@@ -11,7 +11,7 @@ import math
 import numpy as np
 
 
-ROW_BLOCK = 16  # rk_dist_opts.row_block used by the multi-GPU callers
+ROW_BLOCK = 32  # rk_dist_opts.row_block used by the multi-GPU callers (whole 32-genome blocks: the tile kernel counts a tile once)
 
 
 def rank_rows(n_rows, rank, world, row_block=ROW_BLOCK):

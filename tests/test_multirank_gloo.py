@@ -77,10 +77,11 @@ def test_partition_arithmetic():
             assert sum(shard.rank_pairs(n, r, world) for r in range(world)) == n * (n - 1) // 2
     assert shard.weak_scaling_genomes(10000, 1) == 10000
     assert shard.weak_scaling_genomes(10000, 4) == 20000
-    # dealing blocks of 16 rows round-robin keeps the triangle balanced: max/min pairs per rank
-    # within 3 % at 10k x 8
+    # dealing blocks of 32 rows round-robin keeps the triangle balanced: max/min pairs per rank within 5 % at 10k x 8 (the
+    # kernels of the sparse self join cost the same per row whatever the number of columns behind it: what has to be even
+    # is the number of rows, and it is to one block)
     p = [shard.rank_pairs(10000, r, 8) for r in range(8)]
-    assert max(p) / min(p) < 1.03
+    assert max(p) / min(p) < 1.05
 
 
 # --------------------------------------------------------------------------- the same plumbing with the HIP path (GPU)

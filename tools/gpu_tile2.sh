@@ -1,10 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -x -q -k "tile_self_join or without_slice or crowded" > gpurun_out/tile_tests.log 2>&1 || { tail -40 gpurun_out/tile_tests.log; exit 1; }
-tail -2 gpurun_out/tile_tests.log
+drv() { timeout -k 10 300 python3 tools/prof_driver.py "$@" 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-40; }
+for rb in 16 32 64; do
+echo "near rb $rb: 10k 1/8 $(drv dist 10000 40 8 $rb) | 10k 1/2 $(drv dist 10000 40 2 $rb) | 50k 1/8 $(drv dist 50000 20 8 $rb) | 50k 1/2 $(drv dist 50000 20 2 $rb)"
+done
 export RK_DIST_TILES=1
-drv() { timeout -k 10 300 python3 tools/prof_driver.py "$@" 2>&1 | grep -v amdgpu.ids | tail -${LINES:-1} | cut -c1-60; }
-for ms in 1 4 8 16; do
-echo "min share $ms: 10k $(RK_TILE_MIN_SHARE=$ms drv dist 10000 20) | c100 $(RK_TILE_MIN_SHARE=$ms drv dist 10000 20 1 0 0 100) | c1000 $(RK_TILE_MIN_SHARE=$ms drv dist 10000 20 1 0 0 1000) | 50k $(RK_TILE_MIN_SHARE=$ms drv dist 50000 10)"
+for rb in 16 32 64; do
+echo "tile rb $rb: c100 1/8 $(drv dist 10000 40 8 $rb 0 100) | c100 1/2 $(drv dist 10000 40 2 $rb 0 100) | c1000 1/8 $(drv dist 10000 20 8 $rb 0 1000)"
 done
