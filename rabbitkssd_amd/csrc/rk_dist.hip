@@ -1157,7 +1157,9 @@ int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bo
         idx->spread = flagged * 8 > idx->n_self;
         idx->spread_known = 1;
     }
-    *use = idx->spread;
+    // ... or a completed launch of the near-window kernel over this index found rows in its fallback list (fb_state 3: clusters
+    // a little wider than the window, an order that does not cluster): the tile kernel takes the later launches
+    *use = idx->spread || idx->fb_state == 3;
     return RK_OK;
 }
 

@@ -379,6 +379,29 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     auto.close()
 
 
+def test_self_join_moves_to_the_tile_kernel_after_a_fallback():
+    # default switches: clades of 36 -- only the first three rows of a clade have relatives beyond the near-window kernel's 32
+    # columns, so few slice records are wide ones (8 %: the index does not count as one with wide clusters) -- yet those rows
+    # fall back.  The first launches run on rk_near_kernel with its exact fallback; once a completed launch has shown the
+    # fallback list to be non-empty, later launches over this index take the tile kernel.  Same hits every time.
+    names, h, off = synth.clade_sketches(1296, 500, 26, strains_per_clade=36, seed=136)
+    order = np.arange(len(names))   # (the species tree of synth for clades > 10: 36 strains = 4 sub-lineages, all within -D 0.08)
+    names, h, off = synth.permute_genomes(names, h, off, order)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 0, 20, 0.08, threads=4)
+    c = capi.Context(0)
+    idx = c.index_build(c.sketches_from_host(h, off), 26)
+    seen = []
+    for _ in range(4):
+        seen.append(c.dist_kernel_name(idx, None, 1, 0, 20, 0.08).split("<")[0])
+        assert_hits_equal(c.dist_rows(idx, None, 1, 0, 20, 0.08)[0], want)
+    assert seen[0] == "rk_near_kernel" and seen[-1] == "rk_tile_kernel", seen
+    assert sorted(seen, key=lambda k: k == "rk_tile_kernel") == seen     # once on the tile kernel, it stays there
+    del idx
+    c.close()
+
+
 def test_index_without_slice_records(monkeypatch):
     # an index of 2^31 postings and more is built without slice records (their posting offsets would collide with the tag bit
     # of the compact form); RK_INDEX_NO_SELF=1 builds a small one that way: .dict / .index content, explicit queries and the
