@@ -39,33 +39,52 @@ struct BuildResult {  // written by the kernels, read back once
     unsigned long long flagged;   // slice records that are near-flagged posting ranges (fast path only): related lists wider than a compact record
 };
 
-// Single-workgroup exclusive scan in two sweeps over contiguous per-thread stretches (one block-wide exchange instead
-// of one per 1,024 entries): store(i, sum of load(j), j < i) for i < n; returns the grand total.
+// Single-workgroup exclusive scan: store(i, sum of load(j), j < i) for i < n; returns the grand total.  The array is taken as
+// rows of 64 (lane = column: every load and store of a wave is one coalesced access -- round 4; a thread owning a contiguous
+// stretch made each access 64 separate lines), a wave owns R consecutive rows of every stretch of nw * R rows and holds them
+// in registers: all its loads are in flight at once, so a stretch (16,384 entries with 16 waves) costs ONE memory round trip,
+// a block-wide exchange of the waves' totals and R wave scans with a running carry.
 template <class Acc, class L, class W> __device__ inline Acc block_scan_sweeps(uint32_t n, L load, W store)
 {
     __shared__ Acc scan_part[1024 / 64];
+    constexpr uint32_t R = 16;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    const uint32_t per = (n + blockDim.x - 1) / blockDim.x;
-    const uint32_t i0 = min(n, tid * per), i1 = min(n, i0 + per);
-    Acc sum = 0;
-    for (uint32_t i = i0; i < i1; i++) sum += load(i);
-    Acc incl = sum;
-    for (int o = 1; o < 64; o <<= 1) {
-        const Acc t = __shfl_up(incl, o);
-        if ((int)lane >= o) incl += t;
+    const uint32_t rows = (n + 63) / 64;
+    Acc carry = 0;
+    for (uint32_t base = 0; base < rows; base += nw * R) {
+        const uint32_t r0 = base + wave * R;
+        Acc v[R], sum = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < R; u++) {
+            const uint32_t i = (r0 + u) * 64 + lane;
+            v[u] = i < n ? load(i) : Acc(0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < R; u++) sum += v[u];
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) scan_part[wave] = sum;
+        __syncthreads();
+        Acc run = carry, all = 0;
+        for (uint32_t w = 0; w < nw; w++) {
+            if (w < wave) run += scan_part[w];
+            all += scan_part[w];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < R; u++) {
+            const uint32_t i = (r0 + u) * 64 + lane;
+            if ((r0 + u) * 64 >= n) break;   // (wave-uniform)
+            Acc incl = v[u];
+            for (int o = 1; o < 64; o <<= 1) {
+                const Acc t = __shfl_up(incl, o);
+                if ((int)lane >= o) incl += t;
+            }
+            if (i < n) store(i, run + incl - v[u]);
+            run += __shfl(incl, 63);
+        }
+        carry += all;
+        __syncthreads();
     }
-    if (lane == 63) scan_part[wave] = incl;
-    __syncthreads();
-    Acc run = incl - sum, all = 0;
-    for (uint32_t w = 0; w < nw; w++) {
-        if (w < wave) run += scan_part[w];
-        all += scan_part[w];
-    }
-    for (uint32_t i = i0; i < i1; i++) {
-        store(i, run);
-        run += load(i);
-    }
-    return all;
+    return carry;
 }
 
 __global__ void k_sizes(const uint64_t *off, uint32_t n, uint32_t *sizes, uint64_t *off_copy)
@@ -167,54 +186,19 @@ __global__ void k_row_counts(const uint64_t *off, uint32_t n_genomes, const uint
 }
 
 // single workgroup: self_off = exclusive scan of the row lengths, self_split = where a row's covered slices start
-// (4 consecutive genomes per thread and iteration: 100,000 genomes are 25 iterations)
 __global__ void k_row_scan(const uint32_t *n_open, const uint32_t *n_cov, uint32_t n_genomes, uint64_t *self_off,
                            uint64_t *self_split, BuildResult *res)
 {
-    constexpr uint32_t V = 4;
-    __shared__ unsigned long long part[1024 / 64];
-    __shared__ unsigned long long carry;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_genomes; base += blockDim.x * V) {
-        const uint32_t g0 = base + tid * V;
-        uint32_t no[V], nc[V];
-        unsigned long long len = 0;
-#pragma unroll
-        for (uint32_t v = 0; v < V; v++) {
-            no[v] = g0 + v < n_genomes ? n_open[g0 + v] : 0;
-            nc[v] = g0 + v < n_genomes ? n_cov[g0 + v] : 0;
-            len += (unsigned long long)no[v] + nc[v];
-        }
-        unsigned long long incl = len;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long t = __shfl_up(incl, o);
-            if ((int)lane >= o) incl += t;
-        }
-        if (lane == 63) part[wave] = incl;
-        __syncthreads();
-        unsigned long long row0 = carry + incl - len;
-        for (uint32_t w = 0; w < wave; w++) row0 += part[w];
-#pragma unroll
-        for (uint32_t v = 0; v < V; v++)
-            if (g0 + v < n_genomes) {
-                self_off[g0 + v] = row0;
-                self_split[g0 + v] = row0 + no[v];
-                row0 += (unsigned long long)no[v] + nc[v];
-            }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long t = carry;
-            for (uint32_t w = 0; w < nw; w++) t += part[w];
-            carry = t;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        self_off[n_genomes] = carry;
-        self_split[n_genomes] = carry;
-        res->n_self = carry;
+    const unsigned long long all = block_scan_sweeps<unsigned long long>(
+        n_genomes, [&](uint32_t g) { return (unsigned long long)n_open[g] + n_cov[g]; },
+        [&](uint32_t g, unsigned long long before) {
+            self_off[g] = before;
+            self_split[g] = before + n_open[g];
+        });
+    if (threadIdx.x == 0) {
+        self_off[n_genomes] = all;
+        self_split[n_genomes] = all;
+        res->n_self = all;
     }
 }
 
@@ -468,10 +452,12 @@ __global__ void k_offsets_scan(const uint32_t *sizes, uint32_t n_genomes, uint64
 // microseconds -- a device-wide sort of so few keys costs 70 us of launches.
 constexpr uint32_t kRankThreads = 256, kRankPer = 4, kRankQ = kRankThreads * kRankPer, kRankStretch = 256, kRankMaxN = 32768;
 // (root, genome) packed into 32 bits: 2 * id_bits <= 30 for up to 32,768 genomes
-__global__ void k_cluster_keys32(const uint32_t *parent, uint32_t n_genomes, int id_bits, uint32_t *keys)
+// (also zeroes the rank counters k_rank_keys adds to: a fill of its own is one more 6 us dispatch in the chain)
+__global__ void k_cluster_keys32(const uint32_t *parent, uint32_t n_genomes, int id_bits, uint32_t *keys, uint32_t *rank)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_genomes) return;
+    rank[g] = 0;
     uint32_t p = parent[g];
     for (uint32_t hop = 0; hop < n_genomes; hop++) {
         const uint32_t q = parent[p];
@@ -529,6 +515,14 @@ __global__ void k_gather_sketches(const K *hashes, const uint64_t *off, const ui
 }
 
 // inv[orig[i]] = i
+// tab[caller's genome] = (internal id, start of its sketch in the internal-order element space): what k_bucket_emit needs of
+// a key's genome, in one gather (the fast build takes H < 2^30)
+__global__ void k_emit_table(const uint32_t *inv, const uint64_t *off_new, uint32_t n, uint2 *tab)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) tab[g] = make_uint2(inv[g], (uint32_t)off_new[inv[g]]);
+}
+
 __global__ void k_invert_order(const uint32_t *orig, uint32_t n, uint32_t *inv)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -797,6 +791,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     // first used.  The temporaries live until the function returns (the pool's reuse is ordered on ctx->stream only).
     DevBuf<unsigned long long> rl_table(ctx), rl_keys(ctx), rl_keys_sorted(ctx);
     DevBuf<uint32_t> rl_parent(ctx), rl_keys32(ctx), rl_rank(ctx), rl_inv(ctx);
+    DevBuf<uint2> rl_tab(ctx);
     DevBuf<char> rl_tmp(ctx);   // the sort's scratch (kept until this function returns: the sort runs on the second stream)
     const uint32_t *inv = nullptr;   // caller's genome index -> internal id (null: identity)
     bool forked = false, joined = true;
@@ -807,16 +802,27 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         }
         return RK_OK;
     };
-    if (ctx->sw_index_relabel && s->is_set && N > 1 && H) {
+    const bool relabel = ctx->sw_index_relabel && s->is_set && N > 1 && H;
+    const bool two_streams = relabel && !getenv("RK_INDEX_ONE_STREAM");
+    if (two_streams) {
+        if (!ctx->stream2) {
+            RK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            RK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            RK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        RK_HIP(ctx, hipEventRecord(ctx->ev_fork, st));          // (everything enqueued on ctx->stream so far comes first)
+    }
+    // The launches of the renumbering are ENQUEUED after the partition's (the fast path calls this once its own first
+    // kernels are in the queue): the host needs ~5 us per launch, and with the renumbering's ten launches in front the
+    // partition started 70 us late.
+    bool renumbering_enqueued = false, want_tab = false;   // want_tab: the fast path is taken (H < 2^30) and wants k_emit_table's table
+    auto enqueue_renumbering = [&]() -> int {
+      if (renumbering_enqueued) return RK_OK;
+      renumbering_enqueued = true;
+      if (relabel) {
         hipStream_t s2 = st;
-        if (!getenv("RK_INDEX_ONE_STREAM")) {
-            if (!ctx->stream2) {
-                RK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-                RK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-                RK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-            }
+        if (two_streams) {
             s2 = ctx->stream2;
-            RK_HIP(ctx, hipEventRecord(ctx->ev_fork, st));          // (everything enqueued on ctx->stream so far comes first)
             RK_HIP(ctx, hipStreamWaitEvent(s2, ctx->ev_fork, 0));
             forked = true;
         }
@@ -838,8 +844,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         if (N <= kRankMaxN) {
             RK_HIP(ctx, rl_keys32.alloc(N));
             RK_HIP(ctx, rl_rank.alloc(N));
-            RK_HIP(ctx, hipMemsetAsync(rl_rank.p, 0, (size_t)N * 4, s2));
-            hipLaunchKernelGGL(k_cluster_keys32, dim3(nb_n), dim3(kThreads), 0, s2, rl_parent.p, N, id_bits, rl_keys32.p);
+            hipLaunchKernelGGL(k_cluster_keys32, dim3(nb_n), dim3(kThreads), 0, s2, rl_parent.p, N, id_bits, rl_keys32.p, rl_rank.p);
             hipLaunchKernelGGL(k_rank_keys, dim3((N + kRankQ - 1) / kRankQ, (N + kRankStretch - 1) / kRankStretch), dim3(kRankThreads), 0, s2,
                                rl_keys32.p, N, rl_rank.p);
             hipLaunchKernelGGL(k_order_from_rank, dim3(nb_n), dim3(kThreads), 0, s2, rl_rank.p, N, s->d_off, idx->d_orig, idx->d_sizes);
@@ -858,20 +863,25 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             hipLaunchKernelGGL(k_invert_order, dim3(nb_n), dim3(kThreads), 0, s2, idx->d_orig, N, rl_inv.p);
             inv = rl_inv.p;
         }
+        if (want_tab) {
+            RK_HIP(ctx, rl_tab.alloc(N));
+            hipLaunchKernelGGL(k_emit_table, dim3(nb_n), dim3(kThreads), 0, s2, inv, idx->d_src_off, N, rl_tab.p);
+        }
         idx->relabeled = true;
         RK_HIP(ctx, hipGetLastError());
         if (forked) {
             RK_HIP(ctx, hipEventRecord(ctx->ev_join, s2));
             joined = false;
         }
-    } else {
+      } else {
         hipLaunchKernelGGL(k_iota, dim3(blocks_for((uint64_t)N + 1)), dim3(kThreads), 0, st, N, idx->d_orig);
         hipLaunchKernelGGL(k_sizes, dim3(blocks_for((uint64_t)N + 1)), dim3(kThreads), 0, st, s->d_off, N, idx->d_sizes, idx->d_src_off);
-    }
+      }
+      return RK_OK;
+    };
 
     DevBuf<BuildResult> res(ctx);
     RK_HIP(ctx, res.alloc(1));
-    RK_HIP(ctx, hipMemsetAsync(res.p, 0, sizeof(BuildResult), st));
     BuildResult r{0, 0, 0, 0, 0};
     bool built = false;
 
@@ -905,7 +915,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         fa.nb = 1u << B;
         fa.n_chunks = (uint32_t)((H + kPartChunk - 1) / kPartChunk);
         DevBuf<uint32_t> chunk_first(ctx), matrix(ctx), total(ctx), bstart(ctx), ucount(ctx), ubase(ctx), tmp_uhash(ctx), tmp_upos(ctx), n_open(ctx), n_cov(ctx);
-        DevBuf<unsigned long long> keys(ctx), tmp_uhash64(ctx);
+        DevBuf<unsigned long long> keys(ctx), tmp_uhash64(ctx), zeroed(ctx);
         DevBuf<uint2> self_raw(ctx);
         const bool wide = idx->wide;
         RK_HIP(ctx, chunk_first.alloc((size_t)fa.n_chunks + 1));
@@ -921,6 +931,17 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         RK_HIP(ctx, self_raw.alloc(H));
         RK_HIP(ctx, n_open.alloc((size_t)N + 1));
         RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
+        // everything the kernels expect zeroed, in one buffer and one fill (each fill is ~5 us on the stream): the result
+        // record and the cursors of the two-pass partition
+        const bool part2 = (getenv("RK_INDEX_PART2") ? atoi(getenv("RK_INDEX_PART2")) != 0 : true) && B >= 7 && low_bits + gb + rb <= 64 - (int)kFineBits;
+        const bool small_wgs = (fa.nb >> kFineBits) <= 128;   // several workgroups per chunk: they share its stretch through counters
+        const size_t z_res = 0, z_cursor = z_res + (sizeof(BuildResult) + 7) / 8,
+                     z_taken = z_cursor + (part2 ? (fa.nb + 1) / 2 : 0),
+                     z_end = z_taken + (part2 && small_wgs ? ((size_t)fa.n_chunks * (fa.nb >> kFineBits) + 1) / 2 : 0);
+        RK_HIP(ctx, zeroed.alloc(z_end));   // (zeroed by k_chunk_first, the first launch)
+        BuildResult *const fres = reinterpret_cast<BuildResult *>(zeroed.p + z_res);
+        uint32_t *const fine_cursor = reinterpret_cast<uint32_t *>(zeroed.p + z_cursor);
+        uint32_t *const seg_taken = reinterpret_cast<uint32_t *>(zeroed.p + z_taken);
         const size_t part_lds = (size_t)fa.nb * 4 + 2 * kStageGenomes * 8;   // bucket counters + the chunk's genome bounds
         if (part_lds > 48 * 1024) {
             RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_hist<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
@@ -928,41 +949,38 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_hist<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
             RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_scatter<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
         }
-        hipLaunchKernelGGL(k_chunk_first, dim3(blocks_for((uint64_t)fa.n_chunks + 1)), dim3(kThreads), 0, st, s->d_off, N, fa.n_chunks, chunk_first.p);
-        if (wide) hipLaunchKernelGGL(k_part_hist<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, res.p);
-        else hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, res.p);
+        hipLaunchKernelGGL(k_chunk_first, dim3(blocks_for(std::max<uint64_t>((uint64_t)fa.n_chunks + 1, z_end))), dim3(kThreads), 0, st, s->d_off, N, fa.n_chunks,
+                           chunk_first.p, zeroed.p, (uint32_t)z_end);
+        if (wide) hipLaunchKernelGGL(k_part_hist<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, fres);
+        else hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, fres);
         hipLaunchKernelGGL(k_part_colscan, dim3((fa.nb + 63) / 64), dim3(1024), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
-        hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart.p, res.p);
+        hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart.p, fres);
         // the partition itself: two coalescing passes (rk_index_fast.inc), or one scattering pass
-        const bool part2 = (getenv("RK_INDEX_PART2") ? atoi(getenv("RK_INDEX_PART2")) != 0 : true) && B >= 7 && low_bits + gb + rb <= 64 - (int)kFineBits;
         DevBuf<unsigned long long> mid(ctx);
-        DevBuf<uint32_t> fine_cursor(ctx), seg_taken(ctx);
         if (part2) {
             RK_HIP(ctx, mid.alloc(H));
-            RK_HIP(ctx, fine_cursor.alloc(fa.nb));
-            RK_HIP(ctx, hipMemsetAsync(fine_cursor.p, 0, (size_t)fa.nb * 4, st));
-            const bool small_wgs = (fa.nb >> kFineBits) <= 128;   // several workgroups per chunk: they share its stretch through counters
-            RK_HIP(ctx, seg_taken.alloc(small_wgs ? (size_t)fa.n_chunks * (fa.nb >> kFineBits) : 1));
-            if (small_wgs) RK_HIP(ctx, hipMemsetAsync(seg_taken.p, 0, (size_t)fa.n_chunks * (fa.nb >> kFineBits) * 4, st));
 #define RK_COARSE(TT, HT, GRID)                                                                                                              \
     do {                                                                                                                                     \
         RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_coarse<TT, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds(TT))); \
-        hipLaunchKernelGGL((k_part_coarse<TT, HT>), dim3(GRID), dim3(TT), part2_lds(TT), st, fa, chunk_first.p, matrix.p, bstart.p, seg_taken.p, mid.p); \
+        hipLaunchKernelGGL((k_part_coarse<TT, HT>), dim3(GRID), dim3(TT), part2_lds(TT), st, fa, chunk_first.p, matrix.p, bstart.p, seg_taken, mid.p); \
     } while (0)
             if (small_wgs) { if (wide) RK_COARSE(256, uint64_t, fa.n_chunks * 4); else RK_COARSE(256, uint32_t, fa.n_chunks * 4); }
             else { if (wide) RK_COARSE(1024, uint64_t, fa.n_chunks); else RK_COARSE(1024, uint32_t, fa.n_chunks); }
 #undef RK_COARSE
-            hipLaunchKernelGGL(k_part_fine, dim3(fa.nb >> kFineBits, 16), dim3(kPartThreads), 0, st, fa, bstart.p, mid.p, keys.p, fine_cursor.p);
+            hipLaunchKernelGGL(k_part_fine, dim3(fa.nb >> kFineBits, 16), dim3(kPartThreads), 0, st, fa, bstart.p, mid.p, keys.p, fine_cursor);
         } else if (wide) {
             hipLaunchKernelGGL(k_part_scatter<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
         } else {
             hipLaunchKernelGGL(k_part_scatter<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
         }
+        want_tab = true;
+        RK_TRY(enqueue_renumbering());   // (behind the partition's launches in the host's queue, beside them on the device)
         EmitArgs ea;
         ea.keys = keys.p;
         ea.bstart = bstart.p;
         ea.off_new = idx->d_src_off;
         ea.inv = inv;
+        ea.tab = inv ? rl_tab.p : nullptr;
         ea.low_bits = low_bits;
         ea.gb = gb;
         ea.rb = rb;
@@ -973,7 +991,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         ea.tmp_upos = tmp_upos.p;
         ea.ucount = ucount.p;
         ea.self_raw = self_raw.p;
-        ea.res = res.p;
+        ea.res = fres;
         ea.xcd_map = fa.xcd_map;
         ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
         if (ea.debug) {  // developer ablations leave stages out: whatever they do not write must still be harmless downstream
@@ -1000,7 +1018,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             RK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
             sh = ctx->stream2;
         }
-        hipLaunchKernelGGL(k_heads_scan, dim3(1), dim3(1024), 0, sh, ucount.p, fa.nb, ubase.p, res.p);
+        hipLaunchKernelGGL(k_heads_scan, dim3(1), dim3(1024), 0, sh, ucount.p, fa.nb, ubase.p, fres);
         if (wide)
             hipLaunchKernelGGL(k_heads_place<unsigned long long>, dim3(fa.nb), dim3(kThreads), 0, sh, tmp_uhash64.p, tmp_upos.p, bstart.p, ucount.p, ubase.p,
                                fa.nb, (uint32_t)H, (unsigned long long *)idx->d_uhash64, idx->d_upos);
@@ -1012,22 +1030,21 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             joined = false;
         }
         hipLaunchKernelGGL(k_row_counts2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, n_open.p, n_cov.p);
-        hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, res.p);
+        hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, fres);
         hipLaunchKernelGGL(k_row_place2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, idx->d_self_off,
                            idx->d_self_split, idx->d_selfrange);
         RK_HIP(ctx, hipGetLastError());
         RK_TRY(join());
-        RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));  // the one synchronisation of the build
+        RK_TRY(rk_read_back(ctx, &r, fres, sizeof(r), st));  // the one synchronisation of the build
         if (ctx->sw_dist_debug) fprintf(stderr, "[rk] index build: fast path flags %llu (B %d, low bits %d, genome bits %d, position bits %d)\n", r.flags, B, low_bits, gb, rb);
         if (r.flags == 0) built = true;
-        else {  // a bucket beyond the LDS sort, or a hash outside the hash space: the general path decides
-            RK_HIP(ctx, hipMemsetAsync(res.p, 0, sizeof(BuildResult), st));
-            r = BuildResult{0, 0, 0, 0, 0};
-        }
+        else r = BuildResult{0, 0, 0, 0, 0};  // a bucket beyond the LDS sort, or a hash outside the hash space: the general path decides
     }
 
+    RK_TRY(enqueue_renumbering());
     RK_TRY(join());
     if (!built && H) {
+        RK_HIP(ctx, hipMemsetAsync(res.p, 0, sizeof(BuildResult), st));
         // ---- general path: device-wide stable radix sort of (hash, source element) -------------------------------------
         const uint32_t *src_hashes = s->d_hashes;
         const uint64_t *src_hashes64 = s->d_hashes64;
