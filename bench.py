@@ -315,6 +315,12 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
                       stream=env.stream.cuda_stream, row_block=shard.ROW_BLOCK)
     env.stream.synchronize()
     t_first = time.perf_counter() - t0
+    # ... and the second: an index that is joined again gets its tile records now (a context that is not single-shot)
+    t0 = time.perf_counter()
+    ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, first.data_ptr(), row_first=rank, row_step=world,
+                      stream=env.stream.cuda_stream, row_block=shard.ROW_BLOCK)
+    env.stream.synchronize()
+    t_second = time.perf_counter() - t0
     elapsed, kernel_ms, spread = timed_steps(env, launch, steps, warmup)
     # cold steps: other options in between make the library forget what it learned about this (index, options) pair -- here
     # that rk_near_kernel's fallback list is empty --, so every launch of this stretch is a first one (two option sets taking turns)
@@ -366,7 +372,13 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
     # what THIS kernel streams by construction: the 8-byte slice records it walks + the 40-byte hit records it writes
     # (counts stay in LDS; compact records carry their posting list)
     b_stream = 8.0 * stats[2] / world + 40.0 * my_hits
+    tile_records = None
+    if kernel.startswith("rk_tile_kernel"):
+        # the tile kernel's stream: its 8-byte tile records (one per posting list and pair of 32-genome blocks) + 40 B per hit
+        tile_records = int(index.self_stats[3])
+        b_stream = 8.0 * tile_records + 40.0 * my_hits
     return {
+        "tile_records": tile_records,
         "value": n_pairs * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "genomes": n_genomes, "pairs": n_pairs,
         "hashes": int(H), "postings_streamed_T": int(T), "hits": int(tot_hits), "steps": steps, "warmup": warmup,
         "kernel": kernel, "kernel_ms": kernel_ms, "kernel_ms_min_median_max": spread,
@@ -377,7 +389,7 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
         "e2e_ms": t_bcast * 1e3 + elapsed / steps * 1e3 + gather_ms,
         "slice_records": stats[0], "compact_share": (stats[1] / stats[0]) if stats[0] else None, "records_walked": stats[2],
         "build_plus_dist_ms": t_bd * 1e3 if t_bd else None, "pairs_canonical": pairs, "order": order_mode,
-        "first_call_ms": t_first * 1e3, "kernel_ms_cold": kernel_ms_cold,
+        "first_call_ms": t_first * 1e3, "second_call_ms": t_second * 1e3, "kernel_ms_cold": kernel_ms_cold,
     }
 
 
@@ -944,6 +956,18 @@ def dist_roofline(block, pmc_file=None):
                           "stream is the 8-byte slice records (a compact record is its own posting list; the window counts stay in "
                           "registers), DESIGN.md 4.3; issue_frac = share of the kernel's duration the SIMDs spent issuing vector "
                           "instructions (SQ_ACTIVE_INST_VALU x 4 / 1,024 SIMDs / 2.4 GHz)"}
+    if block["kernel"].startswith("rk_tile_kernel"):
+        roof["achieved_from"] = "the kernel's own stream: 8 B per tile record + 40 B per hit written"
+        roof["tile_records"] = block.get("tile_records")
+        roof["cold_note"] = ("an index that is joined again (a context that is not single-shot) runs on the tile kernel from its second "
+                             "unsharded self join on: kernel_ms and kernel_ms_cold are both the tile kernel's (it has no per-launch state); "
+                             "first_call_ms is the first join (rk_near_kernel), build_plus_dist the path of a single join")
+        roof["limited_by"] = ("vector issue (bit-sliced adds: ~4 vector instructions per tile record) and the length of a tile's chain of "
+                              "records per wave; HBM traffic is a few per cent of the roof by construction (a record stands for up to "
+                              "1,024 cell increments), DESIGN.md 4.3c; issue_frac = share of the kernel's duration the SIMDs spent issuing "
+                              "vector instructions (SQ_ACTIVE_INST_VALU x 4 / 1,024 SIMDs / 2.4 GHz)")
+        if pmc_file:
+            pmc_file = {"pmc_traffic.json": "pmc_traffic_tile_clade10.json", "pmc_traffic_50k.json": "pmc_traffic_tile_50k.json"}.get(pmc_file, pmc_file)
     if pmc_file:
         apply_pmc(roof, load_pmc(block["kernel"], pmc_file))
     return roof
@@ -1038,6 +1062,7 @@ def main():
     n_pairs = head["pairs"]
     u16 = head["kernel"].startswith("rk_dist_kernel<true")
     near = head["kernel"].startswith("rk_near_kernel")
+    tile = head["kernel"].startswith("rk_tile_kernel")
     out = {
         "metric": "genome-pairs/sec alldist (10k bacteria, L3K10)",
         "value": head["value"],
@@ -1049,7 +1074,8 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": ("u32 window counts in registers, accumulated bit-sliced per lane (exact)" if near else
+        "dtype": ("bit-sliced counters of 32 x 32 tiles in registers, 16 planes (exact), u32 counts after extraction" if tile else
+                  "u32 window counts in registers, accumulated bit-sliced per lane (exact)" if near else
                   "u16 intersection counters in LDS (exact: a count is bounded by the sketch size, < 65536)" if u16 else
                   "u32 intersection counters in LDS") + " / f64 jaccard + distance",
         "data": "synthetic",
@@ -1061,10 +1087,16 @@ def main():
                    "slice_records": head["slice_records"], "compact_share": head["compact_share"],
                    "records_walked_per_launch": head["records_walked"],
                    "sharding": "query rows in blocks of %d dealt round-robin to %d rank(s); sketches broadcast once (RCCL on GPUs), index built per rank" % (shard.ROW_BLOCK, world),
-                   "step": "one rk_dist_rows_dev call: rk_near_kernel counts and evaluates every pair of the launch; its exact "
-                           "fallback pass (rows whose far cells could be reportable) is launched until a completed launch with "
-                           "the same options has shown that list to be empty -- here after the warm-up -- and skipped from then on "
-                           "(RK_DIST_FB_SKIP=0 launches it always: +3 us per step)"},
+                   "first_call_ms": head["first_call_ms"], "second_call_ms": head["second_call_ms"], "tile_records": head.get("tile_records"),
+                   "step": ("one rk_dist_rows_dev call over the resident index: rk_tile_kernel counts 32 x 32 tiles of the pair matrix from "
+                            "one 8-byte record per posting list and pair of 32-genome blocks and evaluates their cells.  The library takes "
+                            "this kernel from the second unsharded self join over one index on (second_call_ms: that call builds the tile "
+                            "records); the first join (first_call_ms) and row shards (--gpus N > 1, scaling_rehearsal) run on "
+                            "rk_near_kernel, as does a single-shot context (the command-line tool, build_plus_dist)") if tile else
+                           ("one rk_dist_rows_dev call: rk_near_kernel counts and evaluates every pair of the launch; its exact "
+                            "fallback pass (rows whose far cells could be reportable) is launched until a completed launch with "
+                            "the same options has shown that list to be empty -- here after the warm-up -- and skipped from then on "
+                            "(RK_DIST_FB_SKIP=0 launches it always: +3 us per step)")},
         "roofline": dist_roofline(head, "pmc_traffic.json" if world == 1 else None),
         # second headline: what an alldist costs when the index is NOT there yet -- sketches resident in HBM -> hits in HBM
         "build_plus_dist": {

@@ -92,8 +92,11 @@ void rk_ctx_pool_stats(rk_ctx *ctx, uint64_t out[4]);
 void rk_ctx_set_timing(rk_ctx *ctx, int on);
 /* A process that makes ONE pass (a command-line tool) says so: the library then keeps work on the host where the device path
  * would first have to load a code object that costs more than it saves on a single call (today: ordering up to 2^18 hit
- * records by (row, col) in rk_dist_rows: 8 ms to load the sort against 3 ms of std::sort for 45,000 records).  Results are
- * the same either way. */
+ * records by (row, col) in rk_dist_rows: 8 ms to load the sort against 3 ms of std::sort for 45,000 records), and a self join
+ * never pays for structures that only pay off on later joins.  A context that is NOT single-shot treats an index as resident:
+ * from the second unsharded sparse self join over one index on, the tile kernel runs (its records are built by that second
+ * call, 1-2 ms once; 0.030 against 0.032 ms per join at 10,000 genomes, 0.084 against 0.115 at 50,000).  Results are the same
+ * either way. */
 void rk_ctx_set_single_shot(rk_ctx *ctx, int on);
 double rk_ctx_last_ms(const rk_ctx *ctx, int which);
 const char *rk_last_error(const rk_ctx *ctx);

@@ -69,6 +69,7 @@ def lib():
         L.rk_ctx_trim.argtypes = [C.c_void_p]
         L.rk_ctx_pool_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.rk_ctx_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.rk_ctx_set_single_shot.argtypes = [C.c_void_p, C.c_int]
         L.rk_ctx_last_ms.argtypes = [C.c_void_p, C.c_int]
         L.rk_ctx_last_ms.restype = C.c_double
         for f in ("rk_filter_free", "rk_sketches_free", "rk_index_free"):
@@ -124,6 +125,10 @@ class Context:
 
     def set_timing(self, on=True):
         lib().rk_ctx_set_timing(self._h, 1 if on else 0)
+
+    def set_single_shot(self, on=True):
+        """a process that makes one pass (rk_ctx_set_single_shot): host-side ordering of small hit sets, no switch to the tile kernel"""
+        lib().rk_ctx_set_single_shot(self._h, 1 if on else 0)
 
     def last_ms(self, which=0):
         """duration of the dominant kernel of the last pass (0: sketch kernel), HIP events on its stream"""

@@ -72,14 +72,15 @@ template <class Acc, class L, class W> __device__ inline Acc block_scan_sweeps(u
 #pragma unroll
         for (uint32_t u = 0; u < R; u++) {
             const uint32_t i = (r0 + u) * 64 + lane;
-            if ((r0 + u) * 64 >= n) break;   // (wave-uniform)
-            Acc incl = v[u];
-            for (int o = 1; o < 64; o <<= 1) {
-                const Acc t = __shfl_up(incl, o);
-                if ((int)lane >= o) incl += t;
+            if ((r0 + u) * 64 < n) {   // (wave-uniform)
+                Acc incl = v[u];
+                for (int o = 1; o < 64; o <<= 1) {
+                    const Acc t = __shfl_up(incl, o);
+                    if ((int)lane >= o) incl += t;
+                }
+                if (i < n) store(i, run + incl - v[u]);
+                run += __shfl(incl, 63);
             }
-            if (i < n) store(i, run + incl - v[u]);
-            run += __shfl(incl, 63);
         }
         carry += all;
         __syncthreads();

@@ -53,7 +53,8 @@ struct rk_ctx {
     int sw_dist_near = 1;   // RK_DIST_NEAR=0: the self join always with full counter rows (rk_dist_kernel)
     int sw_dist_near_uw = 0;    // RK_DIST_NEAR_UW=1|2|4: waves that share a unit of the near-window kernel (default: by the launch's size)
     int sw_dist_fb_skip = 1;   // RK_DIST_FB_SKIP=0: always launch the fallback pass of the near-window self join
-    int sw_dist_tiles = 2;      // RK_DIST_TILES: 0 never the tile kernel (rk_dist_tile.inc), 1 for every sparse self join over sets, 2 when the index is wide
+    int sw_dist_tiles = 2;      // RK_DIST_TILES: 0 never the tile kernel (rk_dist_tile.inc), 1 for every sparse self join over sets, 2 when the index is wide or joined repeatedly
+    int sw_dist_tiles_after = 1; // RK_DIST_TILES_AFTER: unsharded self joins over one index after which the tile kernel takes over (a context that is not single-shot)
     int sw_dist_near_min = 16;  // RK_DIST_NEAR_MIN: the near-window kernel is used when a reportable pair of the smallest sketch needs at least this count
     int sw_dist_debug = 0;  // RK_DIST_DEBUG=1: the bands of every self join on stderr
     int sw_dist_lds_kb = 0;  // RK_DIST_LDS_KB: plan as if a CU had this much LDS (tests: tiled bands at small sizes)
@@ -189,6 +190,7 @@ struct rk_index {
     // 2 known empty, 3 known non-empty.  Guarded by lazy_mu.
     unsigned char fb_key[40] = {0};
     int fb_state = 0;
+    int self_joins = 0;              // sparse unsharded self joins launched over this index so far (guarded by lazy_mu): see self_uses_tiles
     void *fb_event = nullptr;        // hipEvent_t
     // Tile records of the self join over 32 x 32 tiles (rk_dist_tile.inc), built on first use: per tile (block b of rows,
     // block w >= b of columns) the (row mask, column mask) pairs of the posting lists that touch both blocks, sorted by tile

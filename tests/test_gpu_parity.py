@@ -379,7 +379,31 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     auto.close()
 
 
-def test_self_join_moves_to_the_tile_kernel_after_a_fallback():
+def test_self_join_moves_to_the_tile_kernel_when_the_index_is_joined_again():
+    # a context that is not single-shot (a resident index queried repeatedly): the first unsharded self join runs on
+    # rk_near_kernel, the following ones on the tile kernel (its records are built by the second); a row shard keeps the
+    # near-window kernel; a single-shot context (the command-line tool) never switches.  Same hits every time.
+    names, h, off = synth.clade_sketches(2000, 600, 26, seed=91)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 0, 20, 0.05, threads=4)
+    for single_shot in (False, True):
+        c = capi.Context(0)
+        if single_shot:
+            c.set_single_shot(True)
+        idx = c.index_build(c.sketches_from_host(h, off), 26)
+        seen = []
+        for _ in range(3):
+            seen.append(c.dist_kernel_name(idx, None, 1, 0, 20, 0.05).split("<")[0])
+            assert_hits_equal(c.dist_rows(idx, None, 1, 0, 20, 0.05)[0], want)
+        assert seen == (["rk_near_kernel"] * 3 if single_shot else ["rk_near_kernel", "rk_tile_kernel", "rk_tile_kernel"]), seen
+        assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.05, row_first=1, row_step=2, row_block=32).startswith("rk_near_kernel")
+        del idx
+        c.close()
+
+
+def test_self_join_moves_to_the_tile_kernel_after_a_fallback(monkeypatch):
+    monkeypatch.setenv("RK_DIST_TILES_AFTER", "1000000")   # (not the switch of a repeatedly joined index: the one after a fallback)
     # default switches: clades of 36 -- only the first three rows of a clade have relatives beyond the near-window kernel's 32
     # columns, so few slice records are wide ones (8 %: the index does not count as one with wide clusters) -- yet those rows
     # fall back.  The first launches run on rk_near_kernel with its exact fallback; once a completed launch has shown the

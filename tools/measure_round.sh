@@ -9,9 +9,14 @@ export TMPDIR=/tmp
 for w in 4 8 16; do
   printf 'FETCH_SIZE\n' | tools/pmc_pass.sh pmcC$w k_calib_read calib 1024 $w || exit 1
 done
-tools/pmc_pass.sh pmcD rk_near_kernel dist 10000 4 < tools/pmc_groups_dist.txt || exit 1
+# (the near-window kernel: what a first join, a row shard and the command-line tool run; RK_DIST_TILES_AFTER keeps a repeatedly
+# joined index on it)
+RK_DIST_TILES_AFTER=1000000 tools/pmc_pass.sh pmcD rk_near_kernel dist 10000 4 < tools/pmc_groups_dist.txt || exit 1
 printf 'FETCH_SIZE\nWRITE_SIZE\nSQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY\nSQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA\nSQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD\n' > /tmp/groups_short.txt
-tools/pmc_pass.sh pmcD50 rk_near_kernel dist 50000 3 < /tmp/groups_short.txt || exit 1
+RK_DIST_TILES_AFTER=1000000 tools/pmc_pass.sh pmcD50 rk_near_kernel dist 50000 3 < /tmp/groups_short.txt || exit 1
+# (the tile kernel: a resident index from its second join on -- the headline and config3 --, and wide species)
+tools/pmc_pass.sh pmcT10 rk_tile_kernel dist 10000 4 < /tmp/groups_short.txt || exit 1
+tools/pmc_pass.sh pmcT50 rk_tile_kernel dist 50000 3 < /tmp/groups_short.txt || exit 1
 tools/pmc_pass.sh pmcT100 rk_tile_kernel dist 10000 4 1 0 0 100 < /tmp/groups_short.txt || exit 1
 tools/pmc_pass.sh pmcT1000 rk_tile_kernel dist 10000 4 1 0 0 1000 < /tmp/groups_short.txt || exit 1
 printf 'FETCH_SIZE\nWRITE_SIZE\nSQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES\n' | tools/pmc_pass.sh pmcSk1000 rk_scan2_kernel sketch 1000 5000000 2 || exit 1
