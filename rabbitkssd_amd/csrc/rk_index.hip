@@ -659,6 +659,8 @@ void rk_index_free(rk_index *idx)
     rk_pool_free(ctx, idx->d_tile_key);
     rk_pool_free(ctx, idx->d_tile_start);
     rk_pool_free(ctx, idx->d_blk_min);
+    rk_pool_free(ctx, idx->d_tile_dir[0]);
+    rk_pool_free(ctx, idx->d_tile_dir[1]);
     rk_pool_free(ctx, idx->d_tile_order[0]);
     rk_pool_free(ctx, idx->d_tile_order[1]);
     if (idx->h_fb_seen) (void)hipHostFree(idx->h_fb_seen);

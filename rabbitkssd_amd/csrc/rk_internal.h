@@ -198,6 +198,7 @@ struct rk_index {
     unsigned long long *d_tile_key = nullptr;   // u64[n_tiles]: b << 32 | w, ascending
     unsigned long long *d_tile_start = nullptr; // u64[n_tiles + 1]
     uint32_t *d_blk_min = nullptr;              // u32[ceil(n_ref / 32)]: smallest non-empty sketch of the block
+    uint4 *d_tile_dir[2] = {nullptr, nullptr};       // the directory in launch order, one 32-byte entry per tile (rk_tiles.hip k_tile_dir): all a workgroup needs in one access
     uint32_t *d_tile_order[2] = {nullptr, nullptr};  // tile numbers by records per smallest sketch, descending: [0] jaccard, [1] containment
     unsigned long long tile_prefix[2][256] = {};     // (kTileTable entries each)     // [metric][k]: tiles with at least 2^(-k/8) records per smallest sketch
     uint64_t n_tiles = 0, n_tile_records = 0;

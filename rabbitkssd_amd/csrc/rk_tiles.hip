@@ -149,6 +149,22 @@ __global__ void k_tile_prefix_table(const uint32_t *keys, unsigned long long n_t
     table[k] = lo;
 }
 
+// the directory in launch order (tiles by density, descending, for one metric), everything a workgroup of rk_tile_kernel needs
+// to know in ONE 32-byte entry -- before: order -> key -> start, start + 1 -> two block minima, a chain of four round trips at
+// the start of every workgroup.  Entry: {b, w, start (2 words)} {records, lower bound of any cell's denominator, 0, 0}
+__global__ void k_tile_dir(const uint32_t *order, const unsigned long long *tile_key, const unsigned long long *tile_start, const uint32_t *blk_min,
+                           unsigned long long n_tiles, int metric, uint4 *out)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles) return;
+    const uint32_t t = order[i];
+    const unsigned long long key = tile_key[t], s0 = tile_start[t], s1 = tile_start[t + 1];
+    const uint32_t b = (uint32_t)(key >> 32), w = (uint32_t)key;
+    const uint32_t mb = blk_min[b], mw = blk_min[w];
+    out[2 * i] = make_uint4(b, w, (uint32_t)s0, (uint32_t)(s0 >> 32));
+    out[2 * i + 1] = make_uint4((uint32_t)min(s1 - s0, 0xFFFFFFFFULL), metric ? min(mb, mw) : max(mb, mw), 0u, 0u);
+}
+
 #define RK_TILE_TRY(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
 
 // exclusive scan of n u64 values in place + their total (one read-back: the build is lazy and once per index)
@@ -185,6 +201,7 @@ int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
     DevBuf<unsigned long long> keys_out(ctx), tile_key(ctx), tile_start(ctx);
     DevBuf<uint2> vals_out(ctx);
     DevBuf<uint32_t> order_j(ctx), order_c(ctx);
+    DevBuf<uint4> dir_j(ctx), dir_c(ctx);
     unsigned long long n_c = 0, n_t = 0;
     if (H && U) {
         DevBuf<uint32_t> bm(ctx), rank(ctx);
@@ -277,6 +294,10 @@ int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
             RK_HIP(ctx, hipStreamSynchronize(st));   // (key_out is reused)
             RK_HIP(ctx, rocprim::radix_sort_pairs(tmp3.p, tb3, key_c.p, key_out.p, ids.p, order_c.p, (size_t)n_t, 0, 32, st));
             hipLaunchKernelGGL(k_tile_prefix_table, dim3(1), dim3(kTileTable), 0, st, key_out.p, n_t, table.p + kTileTable);
+            RK_HIP(ctx, dir_j.alloc(2 * n_t));
+            RK_HIP(ctx, dir_c.alloc(2 * n_t));
+            hipLaunchKernelGGL(k_tile_dir, nb(n_t), dim3(tpb), 0, st, order_j.p, tile_key.p, tile_start.p, blk_min.p, n_t, 0, dir_j.p);
+            hipLaunchKernelGGL(k_tile_dir, nb(n_t), dim3(tpb), 0, st, order_c.p, tile_key.p, tile_start.p, blk_min.p, n_t, 1, dir_c.p);
             RK_HIP(ctx, hipGetLastError());
             RK_HIP(ctx, hipMemcpyAsync(idx->tile_prefix, table.p, sizeof(idx->tile_prefix), hipMemcpyDeviceToHost, st));
             RK_HIP(ctx, hipStreamSynchronize(st));
@@ -287,6 +308,8 @@ int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
     idx->d_tile_key = tile_key.release();
     idx->d_tile_start = tile_start.release();
     idx->d_blk_min = blk_min.release();
+    idx->d_tile_dir[0] = dir_j.release();
+    idx->d_tile_dir[1] = dir_c.release();
     idx->d_tile_order[0] = order_j.release();
     idx->d_tile_order[1] = order_c.release();
     idx->n_tiles = n_t;
