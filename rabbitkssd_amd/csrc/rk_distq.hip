@@ -71,7 +71,9 @@ struct DistQArgs {
     int32_t *common_dense;
 };
 
-template <int CBITS, int LOOK>
+// PIPE: the look-up's three memory levels belong to three batches in flight (below); for counter rows of 64 KiB and more --
+// one or two workgroups per CU whatever the registers --: the 33 registers it costs take a resident workgroup from small rows
+template <int CBITS, int LOOK, bool PIPE>
 __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
 {
     typedef typename std::conditional<LOOK == kLookDir64, uint64_t, uint32_t>::type K;
@@ -219,6 +221,78 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
         };
 
         const uint64_t qb = a.q_off[row], qe = a.q_off[row + 1];
+        if (PIPE) {
+            // (round 4) The look-up is a chain of three dependent memory accesses per hash -- the hash, the bitmap entry it
+            // names, the list record of a present one -- and a workgroup holds ONE 100 KB counter row: four waves per SIMD,
+            // which waited 70 % of their time with the chain issued and awaited batch by batch (SQ_WAIT_ANY).  Now the three
+            // levels belong to three different batches: while the records of batch n-1 are queued and walked, the list records
+            // of batch n, the bitmap entries of batch n+1 and the hashes of batch n+2 are in flight.
+            const uint64_t step = (uint64_t)kLookups * nthreads;
+            K h0[kLookups], h1[kLookups];             // h0: the batch resolved next (its bitmap entries are in flight); h1: the one after (its hashes are)
+            uint2 w0[kLookups];
+            uint32_t base0[kLookups];
+            PostingPair r_old[kLookups];              // list records requested a turn ago
+            bool p_old[kLookups];
+            auto load_h = [&](uint64_t e0, K (&h)[kLookups]) {
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    const uint64_t e = e0 + (uint64_t)i * nthreads + tid;
+                    h[i] = e < qe ? qh[e] : (K)~(K)0;   // (all ones: outside every hash space of at most 30 bits -- "not in bounds")
+                }
+            };
+            auto in_bounds = [&](K h) { return (h >> a.hash_bits) == 0; };   // (kLookRank: hash_bits <= 30)
+            auto entry_of = [&](K h) { return in_bounds(h) ? (uint32_t)(((uint64_t)(uint32_t)h * 0xAAAAAAABull) >> 37) : 0u; };   // h / 48
+            auto request_entries = [&]() {
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    const uint32_t ent = entry_of(h0[i]);
+                    w0[i] = a.rankbm[ent];
+                    base0[i] = a.rankbase[ent >> 6];
+                }
+            };
+#pragma unroll
+            for (uint32_t i = 0; i < kLookups; i++) p_old[i] = false;
+            load_h(qb, h0);
+            request_entries();
+            load_h(qb + step, h1);
+            for (uint64_t e0 = qb; e0 < qe + step; e0 += step) {   // (one more turn than batches: the last batch's records are queued in it)
+                // A: resolve this turn's batch (its entries were requested a turn ago) and request the list records of the present hashes
+                PostingPair r_new[kLookups];
+                bool p_new[kLookups];
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    const uint32_t ent = entry_of(h0[i]);
+                    const uint32_t b = (uint32_t)h0[i] - 48u * ent;
+                    const uint64_t bits = (uint64_t)w0[i].x | ((uint64_t)(w0[i].y & 0xFFFFu) << 32);
+                    p_new[i] = e0 < qe && in_bounds(h0[i]) && ((bits >> b) & 1u);
+                    if (p_new[i]) {
+                        const uint2 t = a.urec[base0[i] + (w0[i].y >> 16) + (uint32_t)__popcll(bits & ((1ULL << b) - 1ULL))];
+                        r_new[i].x = t.x;
+                        r_new[i].y = t.y;
+                    }
+                }
+                // B: the next batch's hashes arrived during the last turn: request its entries; and the hashes of the batch after it
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) h0[i] = h1[i];
+                request_entries();
+                load_h(e0 + 2 * step, h1);
+                // C: queue and walk what the previous turn requested
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    const unsigned long long m = __ballot(p_old[i]);
+                    if (m) {  // uniform
+                        if (p_old[i]) queue[qn + __popcll(m & lt_mask)] = make_uint2(r_old[i].x, r_old[i].y);
+                        qn += __popcll(m);
+                        while (qn >= 64) walk();
+                    }
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    r_old[i] = r_new[i];
+                    p_old[i] = p_new[i];
+                }
+            }
+        } else
         for (uint64_t e0 = qb; e0 < qe; e0 += (uint64_t)kLookups * nthreads) {
             K h[kLookups];
             bool inb[kLookups];
@@ -530,12 +604,41 @@ struct PlanQ {
     size_t lds_bytes;
 };
 
+constexpr uint32_t kCandCap = 256, kStageHits = 96;
+size_t distq_fixed_bytes(uint32_t threads)
+{
+    return (size_t)(threads / 64) * kQueueCap * sizeof(uint2) + (size_t)kCandCap * sizeof(uint2) + (size_t)kStageHits * sizeof(rk_hit) + 64;
+}
+// one tile if the counter row fits next to the queues of a 1024-thread workgroup, else equal tiles
+void plan_tiles(const rk_ctx *ctx, const rk_index *idx, int cbits, uint32_t *tile_cols, uint32_t *n_tiles, uint32_t *cnt_words)
+{
+    const size_t lds_max = std::min<size_t>(ctx->max_lds, 160 * 1024);
+    const size_t row_cap = lds_max - distq_fixed_bytes(kMaxThreads);
+    const uint32_t max_cols = (uint32_t)(row_cap * 8 / cbits) & ~127u;
+    uint32_t tile = idx->n_ref;
+    if (tile > max_cols) {
+        const uint32_t nt = (idx->n_ref + max_cols - 1) / max_cols;
+        tile = ((idx->n_ref + nt - 1) / nt + 127) & ~127u;
+    }
+    *tile_cols = tile;
+    *n_tiles = (idx->n_ref + tile - 1) / tile;
+    *cnt_words = (uint32_t)((((uint64_t)tile * cbits + 31) / 32 + 3) & ~3ULL);  // whole 16-byte quads
+}
+// the pipelined look-up (PIPE) where the counter row alone limits a CU to one or two workgroups
+bool distq_pipe(const rk_ctx *ctx, const rk_index *idx, int cbits, int look)
+{
+    if (look != kLookRank || (getenv("RK_DISTQ_PIPE") && !atoi(getenv("RK_DISTQ_PIPE")))) return false;
+    uint32_t tile = 0, nt = 0, words = 0;
+    plan_tiles(ctx, idx, cbits, &tile, &nt, &words);
+    return (size_t)words * 4 >= 64 * 1024;
+}
+
 typedef void (*distq_kernel_t)(DistQArgs);
-distq_kernel_t pick_kernel(int cbits, int look)
+distq_kernel_t pick_kernel(int cbits, int look, bool pipe)
 {
 #define RK_Q(C)                                                                                                  \
-    (look == kLookRank ? rk_distq_kernel<C, kLookRank>                                                           \
-                       : (look == kLookDir32 ? rk_distq_kernel<C, kLookDir32> : rk_distq_kernel<C, kLookDir64>))
+    (look == kLookRank ? (pipe ? rk_distq_kernel<C, kLookRank, true> : rk_distq_kernel<C, kLookRank, false>)     \
+                       : (look == kLookDir32 ? rk_distq_kernel<C, kLookDir32, false> : rk_distq_kernel<C, kLookDir64, false>))
     return cbits == 8 ? RK_Q(8) : (cbits == 16 ? RK_Q(16) : RK_Q(32));
 #undef RK_Q
 }
@@ -554,8 +657,8 @@ static int counter_bits(const rk_index *idx, const rk_sketches *qs)
 int rk_distq_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, char *buf, size_t cap)
 {
     const int look = idx->wide ? kLookDir64 : (idx->hash_bits <= kRankMaxBits ? kLookRank : kLookDir32);
-    snprintf(buf, cap, "rk_distq_kernel<%d, %d>", counter_bits(idx, qs), look);
-    (void)ctx;
+    const int cbits = counter_bits(idx, qs);
+    snprintf(buf, cap, "rk_distq_kernel<%d, %d, %s>", cbits, look, distq_pipe(ctx, idx, cbits, look) ? "true" : "false");
     return RK_OK;
 }
 
@@ -579,30 +682,17 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
         rc = rk_index_ensure_dir(ctx, const_cast<rk_index *>(idx), stream);
         if (rc) return rc;
     }
-    p.cand_cap = 256;
-    p.stage_hits = 96;
-    // one tile if the row fits next to the queues of a 1024-thread workgroup, else equal tiles
+    p.cand_cap = kCandCap;
+    p.stage_hits = kStageHits;
     const size_t lds_max = std::min<size_t>(ctx->max_lds, 160 * 1024);
-    auto fixed_bytes = [&](uint32_t threads) {
-        return (size_t)(threads / 64) * kQueueCap * sizeof(uint2) + (size_t)p.cand_cap * sizeof(uint2) +
-               (size_t)p.stage_hits * sizeof(rk_hit) + 64;
-    };
-    const size_t row_cap = lds_max - fixed_bytes(kMaxThreads);
-    const uint32_t max_cols = (uint32_t)(row_cap * 8 / p.cbits) & ~127u;
-    uint32_t tile = idx->n_ref;
-    if (tile > max_cols) {
-        const uint32_t nt = (idx->n_ref + max_cols - 1) / max_cols;
-        tile = ((idx->n_ref + nt - 1) / nt + 127) & ~127u;
-    }
-    p.tile_cols = tile;
-    p.n_tiles = (idx->n_ref + tile - 1) / tile;
-    p.cnt_words = (uint32_t)((((uint64_t)tile * p.cbits + 31) / 32 + 3) & ~3ULL);  // whole 16-byte quads
+    auto fixed_bytes = [&](uint32_t threads) { return distq_fixed_bytes(threads); };
+    plan_tiles(ctx, idx, p.cbits, &p.tile_cols, &p.n_tiles, &p.cnt_words);
     // workgroup size follows the LDS footprint (it caps the resident workgroups): 7 x 256, 3 x 512, 2 x 768, 1 x 1024
     // workgroup size: the one that keeps most waves resident per CU (registers admit ~5 waves per SIMD, LDS comes in
     // 1,280-byte granules -- the runtime's occupancy answer, clamped by that rule); ties go to the bigger workgroup.
     // Small counter rows therefore run as many 256-thread workgroups (10,000 16-bit columns: 5 per CU instead of 2 x 512).
     const size_t row_bytes = (size_t)p.cnt_words * 4;
-    distq_kernel_t kern_for_plan = pick_kernel(p.cbits, p.look);
+    distq_kernel_t kern_for_plan = pick_kernel(p.cbits, p.look, distq_pipe(ctx, idx, p.cbits, p.look));
     auto resident_wgs = [&](uint32_t threads) -> int {
         const size_t lds = row_bytes + fixed_bytes(threads);
         if (lds > lds_max) return 0;
@@ -673,7 +763,7 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     a.n_hits = n_hits_dev;
     a.common_dense = dense_dev;
 
-    distq_kernel_t kern = pick_kernel(p.cbits, p.look);
+    distq_kernel_t kern = kern_for_plan;
     if (p.lds_bytes > 48 * 1024)
         RK_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
     // persistent grid: as many workgroups as the chip holds, in whole rounds of 8 XCDs x n_tiles
