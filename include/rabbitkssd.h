@@ -291,7 +291,9 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
  * Concurrency: calls with explicit queries and self joins that run on the tile kernel (collections with wide clusters or
  * tiny sketches, RK_DIST_TILES=1) keep no per-launch state in the index and may overlap freely on different streams.  A
  * self join that runs on the near-window kernel keeps its fallback list IN the index: at most one such self join per index
- * may be in flight at a time (serialise them on one stream, or use one index object per stream).
+ * may be in flight at a time (serialise them on one stream, or use one index object per stream).  (With RK_DISTQ_SLICED=1 --
+ * a measured, slower variant of the query path, off by default -- the scratch of the membership pass is kept with the QUERY
+ * sketches: one call per query-sketches object at a time.)
  * Limits: fewer than 2^31-1 genomes and 2^32-1 postings per index.  From 2^31-1 postings on (all of GenBank's bacteria at
  * ~1,200 hashes each) rk_index_build leaves out the slice records of the row kernels (their posting offsets would collide
  * with the tag bit of the compact form): export, explicit queries below 2^31 postings and SPARSE self joins (the tile

@@ -43,7 +43,8 @@ constexpr uint32_t kQueueCap = 128;     // ranges per wave: < 64 left over (the 
 constexpr uint32_t kMaxThreads = 1024;
 constexpr uint32_t kLookups = 4;        // query hashes per lane and iteration (independent loads in flight)
 
-enum { kLookRank = 0, kLookDir32 = 1, kLookDir64 = 2 };
+enum { kLookRank = 0, kLookDir32 = 1, kLookDir64 = 2, kLookPre = 3 };   // kLookPre: the present hashes were resolved by k_member_sliced
+constexpr uint32_t kSegStride = 8;   // slice ranges per query (kLookPre): room in the segment tables
 
 struct DistQArgs {
     const void *q_hashes;        // u32[] or u64[] (kLookDir64)
@@ -53,6 +54,7 @@ struct DistQArgs {
     const uint2 *urec;           // per distinct hash: posting range or compact list (rk_internal.h d_urec); null: ranges from upos
     const void *uhash;           // kLookDir*: sorted distinct hashes
     const uint32_t *dir;
+    const uint32_t *rec, *seg_start, *seg_cnt;   // kLookPre: ranks of the present hashes, per query and slice range where (relative to q_off) and how many
     const uint32_t *upos;        // u32[U+1] posting offsets of the distinct hashes
     const uint32_t *postings;
     const uint32_t *ref_sizes;
@@ -221,7 +223,49 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
         };
 
         const uint64_t qb = a.q_off[row], qe = a.q_off[row + 1];
-        if (PIPE) {
+        if (LOOK == kLookPre) {
+            // the query's present hashes were found by k_member_sliced: their ranks lie in up to kSegStride segments of
+            // a.rec; a flat index over them (the segment of an index by a compare chain over the eight prefix sums)
+            uint32_t pre[kSegStride + 1], rel[kSegStride];
+            pre[0] = 0;
+#pragma unroll
+            for (uint32_t y = 0; y < kSegStride; y++) {
+                pre[y + 1] = pre[y] + a.seg_cnt[(size_t)row * kSegStride + y];
+                rel[y] = a.seg_start[(size_t)row * kSegStride + y] - pre[y];   // record address = rel[segment] + flat index
+            }
+            const uint32_t total = pre[kSegStride];
+            const uint32_t *recs = a.rec + qb;
+            for (uint32_t i0 = 0; i0 < total; i0 += kLookups * nthreads) {
+                uint32_t pos[kLookups];
+                bool present[kLookups];
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    const uint32_t ix = i0 + i * nthreads + tid;
+                    present[i] = ix < total;
+                    uint32_t off = rel[0];
+#pragma unroll
+                    for (uint32_t y = 1; y < kSegStride; y++) off = ix >= pre[y] ? rel[y] : off;
+                    pos[i] = present[i] ? recs[off + ix] : 0u;
+                }
+                PostingPair r[kLookups];
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++)
+                    if (present[i]) {
+                        const uint2 t = a.urec[pos[i]];
+                        r[i].x = t.x;
+                        r[i].y = t.y;
+                    }
+#pragma unroll
+                for (uint32_t i = 0; i < kLookups; i++) {
+                    const unsigned long long m = __ballot(present[i]);
+                    if (m) {  // uniform
+                        if (present[i]) queue[qn + __popcll(m & lt_mask)] = make_uint2(r[i].x, r[i].y);
+                        qn += __popcll(m);
+                        while (qn >= 64) walk();
+                    }
+                }
+            }
+        } else if (PIPE) {
             // (round 4) The look-up is a chain of three dependent memory accesses per hash -- the hash, the bitmap entry it
             // names, the list record of a present one -- and a workgroup holds ONE 100 KB counter row: four waves per SIMD,
             // which waited 70 % of their time with the chain issued and awaited batch by batch (SQ_WAIT_ANY).  Now the three
@@ -518,6 +562,127 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
         if (at0 + i / kW < a.cap) dst[at0 * kW + i] = src[i];
 }
 
+// ---- sliced membership (round 4) ------------------------------------------------------------------------------
+// What bounds the fused look-up of a big query is the NUMBER of L1 misses: its sorted hashes lie ~60 bytes apart in the rank
+// bitmap, so every look-up of a wave is a cache line of its own and the L1's miss queue is full half of the kernel's time
+// (TCP_PENDING_STALL, 27 M requests to L2 for 45.8 M look-ups).  Here the bitmap comes to the hashes instead: a workgroup of
+// 16 waves -- one query each -- walks a range of 48 KiB slices of the bitmap; a slice is loaded into LDS once (coalesced),
+// every wave reads on through its sorted query (a cursor: no search after the first slice) and answers from LDS; the rank
+// of every present hash is appended to the query's record list (ballot + prefix: the records of a query and range are one
+// compact, sorted segment).  The counting kernel (LOOK == kLookPre) then reads 4 bytes per PRESENT hash.
+constexpr uint32_t kSliceEntries = 6144;   // bitmap entries (of 48 hash values) per slice: 48 KiB, 96 rank bases
+constexpr uint32_t kMemberWaves = 16;
+
+struct MemberArgs {
+    const uint32_t *q_hashes;
+    const uint64_t *q_off;
+    uint32_t n_query;
+    const uint2 *rankbm;
+    const uint32_t *rankbase;
+    uint64_t n_entries;
+    uint32_t n_slices, slices_per_range;
+    uint32_t *rec, *seg_start, *seg_cnt;
+    int debug;   // developer ablations (RK_MEMBER_DEBUG): 1 no look-ups, 2 no slice loads, 4 no search
+};
+
+// number of elements of the sorted array h[0 .. n) below `target`, found by the whole wave: 64 probes per round
+__device__ inline uint64_t wave_lower_bound(const uint32_t *h, uint64_t n, uint64_t target, uint32_t lane)
+{
+    uint64_t lo = 0, hi = n;   // the answer lies in [lo, hi]
+    while (hi - lo > 64) {
+        const uint64_t span = hi - lo;
+        const uint64_t p = lo + (uint64_t)(lane + 1) * span / 65;   // lo < p < hi, ascending with the lane
+        const unsigned long long below = __ballot((uint64_t)h[p] < target);   // (a prefix of the lanes: the array ascends)
+        const uint32_t c = (uint32_t)__popcll(below);
+        const uint64_t new_lo = c ? lo + (uint64_t)c * span / 65 + 1 : lo;        // probe c - 1 is below: the answer is behind it
+        const uint64_t new_hi = c < 64 ? lo + (uint64_t)(c + 1) * span / 65 : hi; // probe c is not: the answer is at most its index
+        lo = new_lo;
+        hi = new_hi;
+    }
+    const uint64_t ix = lo + lane;
+    const unsigned long long below = __ballot(ix < hi && (uint64_t)h[ix] < target);
+    return lo + (uint64_t)__popcll(below);
+}
+
+// (two workgroups per CU: 64 registers -- with 90 a launch of 315 workgroups ran in two rounds, 127 -> 205 us)
+__global__ __launch_bounds__(kMemberWaves * 64, 8) void k_member_sliced(MemberArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint2 bm[kSliceEntries];
+    __shared__ uint32_t base[kSliceEntries / 64];
+    // a wave's records gather here and leave in bursts: on this hardware stores and loads retire in one order, so a store per
+    // vector of hashes made the wait for the NEXT vector a wait for that store's acknowledgement (measured: 127 -> 205 us with
+    // the hashes prefetched and the stores left in the loop)
+    constexpr uint32_t kOutBuf = 192, kOutFlush = 128;
+    __shared__ uint32_t obuf[kMemberWaves][kOutBuf];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t q = blockIdx.x * kMemberWaves + wave, y = blockIdx.y;
+    const bool live = q < a.n_query;
+    const uint32_t s0 = y * a.slices_per_range, s1 = min(a.n_slices, s0 + a.slices_per_range);
+    const uint64_t qb = live ? a.q_off[q] : 0;
+    const uint32_t qn = live ? (uint32_t)(a.q_off[q + 1] - qb) : 0u;   // (the host takes this path for fewer than 2^32 query hashes in all)
+    const uint32_t *qh = a.q_hashes + qb;
+    const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    uint32_t cursor = live && s0 < s1 && !(a.debug & 4) ? (uint32_t)wave_lower_bound(qh, qn, (uint64_t)s0 * kSliceEntries * 48, lane) : 0u;
+    const uint32_t start = cursor;
+    uint32_t *out = a.rec + qb + start;   // (a range's records start where its hashes do: there are no more of them than hashes)
+    uint32_t n_out = 0, n_buf = 0;
+    auto flush_out = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < n_buf; i += 64) out[n_out + i] = obuf[wave][i];
+        __builtin_amdgcn_wave_barrier();
+        n_out += n_buf;
+        n_buf = 0;
+    };
+    // the query is read in aligned vectors of 64 hashes, four of them in flight: a vector stays when a slice ends inside it
+    // (its remaining lanes belong to the next slice), so the stream never waits for a slice boundary
+    constexpr int kAhead = 4;
+    uint32_t v = cursor & ~63u;
+    uint32_t hv[kAhead];
+    auto load_vec = [&](uint32_t at) { return at + lane < qn ? qh[at + lane] : 0xFFFFFFFFu; };   // (qn + 256 does not wrap: fewer than 2^32 - 2^20 hashes)
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) hv[j] = load_vec(v + 64u * j);
+    for (uint32_t s = s0; s < s1; s++) {
+        const uint64_t e_first = (uint64_t)s * kSliceEntries;
+        const uint32_t n_e = (uint32_t)min((uint64_t)kSliceEntries, a.n_entries - e_first);
+        __syncthreads();   // (every wave is done with the slice before)
+        // (the next slice prefetched into registers while this one is used: 12 registers that did not fit the 64 of two
+        // workgroups per CU -- spilled, the loop below ran ten times slower)
+        if (!(a.debug & 2))
+            for (uint32_t i = tid; i < n_e; i += kMemberWaves * 64) bm[i] = a.rankbm[e_first + i];
+        for (uint32_t i = tid; i < (n_e + 63) / 64; i += kMemberWaves * 64) base[i] = a.rankbase[(e_first >> 6) + i];
+        __syncthreads();
+        const uint64_t end_value = (e_first + n_e) * 48;   // first hash value behind the slice
+        while (v < qn && !(a.debug & 1)) {   // (uniform)
+            const uint32_t ix = v + lane;
+            const uint32_t h = hv[0];
+            const bool valid = ix >= cursor && ix < qn;
+            const bool in = valid && (uint64_t)h < end_value;   // (the query ascends: the lanes of a slice are a stretch of the vector)
+            const uint32_t ent = (uint32_t)(((uint64_t)h * 0xAAAAAAABull) >> 37);   // h / 48
+            const uint32_t loc = in ? ent - (uint32_t)e_first : 0u;
+            const uint2 w = bm[loc];
+            const uint32_t b = h - 48u * ent;
+            const uint64_t bits = (uint64_t)w.x | ((uint64_t)(w.y & 0xFFFFu) << 32);
+            const bool present = in && ((bits >> b) & 1u);
+            const unsigned long long m = __ballot(present);
+            if (present) obuf[wave][n_buf + (uint32_t)__popcll(m & lt_mask)] = base[loc >> 6] + (w.y >> 16) + (uint32_t)__popcll(bits & ((1ULL << b) - 1ULL));
+            n_buf += (uint32_t)__popcll(m);
+            if (n_buf > kOutFlush) flush_out();   // (uniform; at most 64 more fit behind kOutFlush)
+            cursor += (uint32_t)__popcll(__ballot(in));
+            if (__ballot(valid && !in)) break;   // the rest of this vector lies behind the slice
+            v += 64;
+#pragma unroll
+            for (int j = 0; j + 1 < kAhead; j++) hv[j] = hv[j + 1];
+            hv[kAhead - 1] = load_vec(v + 64u * (kAhead - 1));
+        }
+    }
+    flush_out();
+    if (live && lane == 0) {
+        a.seg_start[(size_t)q * kSegStride + y] = (uint32_t)start;
+        a.seg_cnt[(size_t)q * kSegStride + y] = n_out;
+    }
+}
+
 // ---- rank bitmap over the hash space --------------------------------------------------------------------
 // one thread per entry of 48 hash values: uhash is sorted, so a binary search finds the entry's first distinct hash
 // (its rank) and the few that follow set its presence bits -- no temporary, no atomics
@@ -633,12 +798,28 @@ bool distq_pipe(const rk_ctx *ctx, const rk_index *idx, int cbits, int look)
     return (size_t)words * 4 >= 64 * 1024;
 }
 
+// the sliced membership pass + the counting kernel on its records (sorted queries against an index with a rank bitmap).
+// NOT the default: built and measured in round 4 on the shape it was costed for (BASELINE configs[4], 1,000 queries of 45,776
+// hashes against 100,000 references) -- k_member_sliced 125 us + the counting kernel 118 us = 0.244 ms against 0.215 ms of the
+// fused kernel with the pipelined look-up.  The slices do what they were meant to (3.6 M requests from L1 to L2 instead of
+// 27 M), but the two kernels issue 77.8 M vector instructions where the fused one issues 60.7 M (61 per 64 look-ups for the
+// cursor, the slice bounds and the record list alone), and the counting half -- the walks, 34 M -- is as vector-bound as
+// before.  RK_DISTQ_SLICED=1 takes this path whenever it is possible (tests/test_gpu_parity.py runs it against the oracle).
+bool distq_sliced(const rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, int cbits, int look)
+{
+    (void)ctx; (void)idx; (void)cbits;
+    const char *e = getenv("RK_DISTQ_SLICED");
+    if (look != kLookRank || !qs->is_set || qs->wide || !qs->n || qs->total >= 0xFFF00000ULL) return false;
+    return e && *e && atoi(e) == 1;
+}
+
 typedef void (*distq_kernel_t)(DistQArgs);
 distq_kernel_t pick_kernel(int cbits, int look, bool pipe)
 {
 #define RK_Q(C)                                                                                                  \
     (look == kLookRank ? (pipe ? rk_distq_kernel<C, kLookRank, true> : rk_distq_kernel<C, kLookRank, false>)     \
                        : (look == kLookDir32 ? rk_distq_kernel<C, kLookDir32, false> : rk_distq_kernel<C, kLookDir64, false>))
+    if (look == kLookPre) return cbits == 8 ? rk_distq_kernel<8, kLookPre, false> : (cbits == 16 ? rk_distq_kernel<16, kLookPre, false> : rk_distq_kernel<32, kLookPre, false>);
     return cbits == 8 ? RK_Q(8) : (cbits == 16 ? RK_Q(16) : RK_Q(32));
 #undef RK_Q
 }
@@ -658,7 +839,8 @@ int rk_distq_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs
 {
     const int look = idx->wide ? kLookDir64 : (idx->hash_bits <= kRankMaxBits ? kLookRank : kLookDir32);
     const int cbits = counter_bits(idx, qs);
-    snprintf(buf, cap, "rk_distq_kernel<%d, %d, %s>", cbits, look, distq_pipe(ctx, idx, cbits, look) ? "true" : "false");
+    if (distq_sliced(ctx, idx, qs, cbits, look)) snprintf(buf, cap, "rk_distq_kernel<%d, %d, false>", cbits, (int)kLookPre);
+    else snprintf(buf, cap, "rk_distq_kernel<%d, %d, %s>", cbits, look, distq_pipe(ctx, idx, cbits, look) ? "true" : "false");
     return RK_OK;
 }
 
@@ -692,7 +874,8 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     // 1,280-byte granules -- the runtime's occupancy answer, clamped by that rule); ties go to the bigger workgroup.
     // Small counter rows therefore run as many 256-thread workgroups (10,000 16-bit columns: 5 per CU instead of 2 x 512).
     const size_t row_bytes = (size_t)p.cnt_words * 4;
-    distq_kernel_t kern_for_plan = pick_kernel(p.cbits, p.look, distq_pipe(ctx, idx, p.cbits, p.look));
+    const bool sliced = distq_sliced(ctx, idx, qs, p.cbits, p.look);
+    distq_kernel_t kern_for_plan = sliced ? pick_kernel(p.cbits, kLookPre, false) : pick_kernel(p.cbits, p.look, distq_pipe(ctx, idx, p.cbits, p.look));
     auto resident_wgs = [&](uint32_t threads) -> int {
         const size_t lds = row_bytes + fixed_bytes(threads);
         if (lds > lds_max) return 0;
@@ -774,6 +957,44 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     uint32_t resident = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, ctx->num_cu);
     resident = std::max(per_round, resident / per_round * per_round);
     p.grid = std::min(total_padded, resident);
+    a.rec = a.seg_start = a.seg_cnt = nullptr;
+    if (sliced) {
+        rk_sketches *q = const_cast<rk_sketches *>(qs);
+        {
+            std::lock_guard<std::mutex> lk(q->lazy_mu);
+            if (!q->d_member_rec) {
+                DevBuf<uint32_t> rec(ctx), seg(ctx);
+                if (rec.alloc(qs->total + 1) != hipSuccess || seg.alloc((size_t)2 * kSegStride * qs->n) != hipSuccess)
+                    return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate the membership records of %llu query hashes", (unsigned long long)qs->total);
+                q->d_member_rec = rec.release();
+                q->d_member_seg = seg.release();
+            }
+        }
+        MemberArgs m;
+        m.q_hashes = qs->d_hashes;
+        m.q_off = qs->d_off;
+        m.n_query = qs->n;
+        m.rankbm = idx->d_rankbm;
+        m.rankbase = idx->d_rankbase;
+        m.n_entries = ((1ULL << idx->hash_bits) + kRankSpan - 1) / kRankSpan;
+        m.n_slices = (uint32_t)((m.n_entries + kSliceEntries - 1) / kSliceEntries);
+        // slice ranges per batch of 16 queries: enough workgroups for the chip, at most kSegStride segments per query
+        const uint32_t batches = (qs->n + kMemberWaves - 1) / kMemberWaves;
+        uint32_t ranges = 1;
+        while (ranges < kSegStride && ranges < m.n_slices && (uint64_t)batches * (ranges + 1) <= 2ULL * (uint64_t)ctx->num_cu) ranges++;   // (two workgroups fit a CU: one round)
+        m.slices_per_range = (m.n_slices + ranges - 1) / ranges;
+        ranges = (m.n_slices + m.slices_per_range - 1) / m.slices_per_range;
+        m.debug = getenv("RK_MEMBER_DEBUG") ? atoi(getenv("RK_MEMBER_DEBUG")) : 0;
+        m.rec = q->d_member_rec;
+        m.seg_start = q->d_member_seg;
+        m.seg_cnt = q->d_member_seg + (size_t)kSegStride * qs->n;
+        RK_HIP(ctx, hipMemsetAsync(q->d_member_seg, 0, (size_t)2 * kSegStride * qs->n * 4, stream));   // (ranges a launch does not use count zero)
+        hipLaunchKernelGGL(k_member_sliced, dim3(batches, ranges), dim3(kMemberWaves * 64), 0, stream, m);
+        RK_HIP(ctx, hipGetLastError());
+        a.rec = m.rec;
+        a.seg_start = m.seg_start;
+        a.seg_cnt = m.seg_cnt;
+    }
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(p.threads), p.lds_bytes, stream, a);
     RK_HIP(ctx, hipGetLastError());
     return RK_OK;

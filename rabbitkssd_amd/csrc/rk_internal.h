@@ -134,6 +134,12 @@ struct rk_sketches {
     std::vector<uint64_t> h_off;  // host mirror of d_off (n+1)
     bool is_set = false;          // every genome's hashes are strictly ascending (sorted, no repeats)
     uint64_t max_size = 0;        // largest sketch
+    // scratch of the sliced membership pass (rk_distq.hip), kept with the QUERIES it belongs to: per query hash room for one
+    // 4-byte record (the rank of a present hash), per query and slice range the place and number of its records.  One
+    // query join per sketches object at a time may use it (the header says so).
+    std::mutex lazy_mu;
+    uint32_t *d_member_rec = nullptr;   // u32[total]
+    uint32_t *d_member_seg = nullptr;   // u32[2 * 8 * n]: starts, then counts
 };
 
 struct rk_index {

@@ -769,6 +769,8 @@ void rk_sketches_free(rk_sketches *s)
     rk_pool_free(s->ctx, s->d_hashes);
     rk_pool_free(s->ctx, s->d_hashes64);
     rk_pool_free(s->ctx, s->d_off);
+    rk_pool_free(s->ctx, s->d_member_rec);
+    rk_pool_free(s->ctx, s->d_member_seg);
     delete s;
 }
 

@@ -329,7 +329,7 @@ def test_config4_ref_vs_query_all_1000_queries(ctx):
     qh = np.concatenate(parts)
     idx = ctx.index_build(ctx.sketches_from_host(rh, roff), 24)
     qs = ctx.sketches_from_host(qh, qoff)
-    assert ctx.dist_kernel_name(idx, qs, 0, 1, 20, 0.05) == "rk_distq_kernel<8, 0, true>"   # one 100 KB tile of 8-bit counters
+    assert ctx.dist_kernel_name(idx, qs, 0, 1, 20, 0.05) == "rk_distq_kernel<8, 0, true>"   # one 100 KB tile of 8-bit counters, the look-up pipelined over three batches
     postings, counts = ok.index_build32(rh, roff, 24)
     sizes = np.diff(roff).astype(np.uint32)
     s_off = np.concatenate([[0], np.cumsum([len(parts[q]) for q in sample])]).astype(np.uint64)

@@ -563,6 +563,43 @@ def test_ref_vs_query_random_and_tiled_reference(ctx):
         assert_hits_equal(mine, want)
 
 
+def test_sliced_membership_pass_equals_the_fused_kernel(monkeypatch):
+    # RK_DISTQ_SLICED=1: the present hashes of every query are found by k_member_sliced (the rank bitmap in 48 KiB slices through
+    # LDS, a cursor per query) and counted by the kernel's pre-resolved variant; big queries (several slices and slice ranges,
+    # planted references), tiny and empty ones, a tiled reference row, both metrics, the dense counter matrix
+    rn, rh, roff = synth.clade_sketches(45000, 24, 24, seed=4)
+    rng = np.random.default_rng(21)
+    parts = []
+    for q in range(37):
+        size = [40000, 9000, 300, 1, 0][q % 5]
+        p = rng.integers(0, 1 << 24, size=size, dtype=np.uint64).astype(np.uint32)
+        if q % 3 == 0 and size:
+            refs = rng.choice(45000, size=4, replace=False)
+            p = np.concatenate([p] + [rh[int(roff[r]):int(roff[r + 1])] for r in refs])
+        parts.append(np.unique(p))
+    qoff = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    qh = np.concatenate(parts).astype(np.uint32)
+    postings, counts = ok.index_build32(rh, roff, 24)
+    sizes = np.diff(roff).astype(np.uint32)
+    monkeypatch.setenv("RK_DISTQ_SLICED", "1")
+    c = capi.Context(0)
+    idx = c.index_build(c.sketches_from_host(rh, roff), 24)
+    qs = c.sketches_from_host(qh, qoff)
+    assert c.dist_kernel_name(idx, qs, 0, 1, 20, 0.2).startswith("rk_distq_kernel<8, 3,")   # (references of 24 hashes: 8-bit counters)
+    for metric, D in ((1, 0.2), (0, 0.4)):
+        want, _ = ok.index_dist32(counts, 24, postings, sizes, qh, qoff, 0, metric, 20, D, threads=8)
+        assert len(want) >= 12 * 4
+        for _ in range(2):   # (the records' scratch is kept with the queries: a second pass reuses it)
+            assert_hits_equal(c.dist_rows(idx, qs, 0, metric, 20, D)[0], want)
+    few = c.sketches_from_host(qh[: int(qoff[4])], qoff[:5])
+    want, wdense = ok.index_dist32(counts, 24, postings, sizes, qh[: int(qoff[4])], qoff[:5], 0, 1, 20, 0.2, want_dense=True, threads=8)
+    mine, dense = c.dist_rows(idx, few, 0, 1, 20, 0.2, want_dense=True)
+    assert np.array_equal(dense, wdense)
+    assert_hits_equal(mine, want)
+    del idx
+    c.close()
+
+
 def test_large_query_sketch_uses_32bit_counters(ctx):
     # a query with >= 65536 hashes (3 Gb genome scale) forces the u32 LDS counter row;
     # the same data through the u16 path (small queries) must agree on the shared rows
