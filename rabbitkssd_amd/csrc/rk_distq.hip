@@ -54,6 +54,7 @@ struct DistQArgs {
     const uint2 *urec;           // per distinct hash: posting range or compact list (rk_internal.h d_urec); null: ranges from upos
     const void *uhash;           // kLookDir*: sorted distinct hashes
     const uint32_t *dir;
+    uint32_t min_fit;            // compact lists of a popped batch that must share the 32-column window before the wave counts columns (else all are scattered member by member)
     const uint32_t *rec, *seg_start, *seg_cnt;   // kLookPre: ranks of the present hashes, per query and slice range where (relative to q_off) and how many
     const uint32_t *upos;        // u32[U+1] posting offsets of the distinct hashes
     const uint32_t *postings;
@@ -180,11 +181,16 @@ __global__ __launch_bounds__(kMaxThreads) void rk_distq_kernel(DistQArgs a)
                 const uint32_t first = ent.x & 0x7FFFFFFFu;
                 const uint32_t base = wave_min(cpt ? first : 0xFFFFFFFFu);
                 const uint32_t rel = first - base;
-                const bool fits = cpt && rel < 32u && (rel == 0 || (ent.y >> (32u - rel)) == 0);
+                bool fits = cpt && rel < 32u && (rel == 0 || (ent.y >> (32u - rel)) == 0);
+                // (a query without relatives among the references: its 64 lists lie in 64 clades, one or two share the window of
+                // the smallest -- the column count would cost more than the members it saves from the loop below)
+                if (__popcll(__ballot(fits)) < (int)a.min_fit) fits = false;   // (uniform)
                 const uint32_t mw = fits ? ent.y << rel : 0u;
                 uint32_t ca = 0, cb = 0;
-                count_columns<false, 0>(wave_or(mw), mw, 0u, ca, cb);
-                bump_n(base + lane, ca);
+                if (__ballot(fits)) {   // (uniform)
+                    count_columns<false, 0>(wave_or(mw), mw, 0u, ca, cb);
+                    bump_n(base + lane, ca);
+                }
                 uint32_t m = cpt && !fits ? ent.y : 0u;
                 while (__ballot(m != 0)) {
                     const bool v = m != 0;
@@ -957,6 +963,7 @@ int rk_distq_launch(rk_ctx *ctx, const rk_index *idx, const rk_sketches *qs, con
     uint32_t resident = (uint32_t)std::max(1, per_cu) * (uint32_t)std::max(1, ctx->num_cu);
     resident = std::max(per_round, resident / per_round * per_round);
     p.grid = std::min(total_padded, resident);
+    a.min_fit = getenv("RK_DISTQ_MIN_FIT") ? (uint32_t)atoi(getenv("RK_DISTQ_MIN_FIT")) : 8u;
     a.rec = a.seg_start = a.seg_cnt = nullptr;
     if (sliced) {
         rk_sketches *q = const_cast<rk_sketches *>(qs);
