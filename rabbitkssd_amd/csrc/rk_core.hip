@@ -211,6 +211,8 @@ int rk_ctx_create(int device, rk_ctx **out)
     ctx->sw_dist_near = getenv("RK_DIST_NEAR") ? atoi(getenv("RK_DIST_NEAR")) != 0 : 1;
     if (getenv("RK_DIST_TILES")) ctx->sw_dist_tiles = atoi(getenv("RK_DIST_TILES"));
     if (getenv("RK_DIST_TILES_AFTER")) ctx->sw_dist_tiles_after = atoi(getenv("RK_DIST_TILES_AFTER"));
+    if (getenv("RK_DIST_TILES_MIN_GENOMES")) ctx->sw_dist_tiles_min_genomes = atoi(getenv("RK_DIST_TILES_MIN_GENOMES"));
+    if (getenv("RK_DIST_TILES_MIN_SHARD_ROWS")) ctx->sw_dist_tiles_min_shard_rows = atoi(getenv("RK_DIST_TILES_MIN_SHARD_ROWS"));
     if (getenv("RK_DIST_NEAR_UW")) ctx->sw_dist_near_uw = atoi(getenv("RK_DIST_NEAR_UW"));
     if (getenv("RK_DIST_NEAR_MIN")) ctx->sw_dist_near_min = std::max(1, atoi(getenv("RK_DIST_NEAR_MIN")));
     if (getenv("RK_DIST_FB_SKIP")) ctx->sw_dist_fb_skip = atoi(getenv("RK_DIST_FB_SKIP")) != 0;

@@ -1161,10 +1161,16 @@ int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bo
     // a little wider than the window, an order that does not cluster): the tile kernel takes the later launches
     *use = idx->spread || idx->fb_state == 3;
     // ... or the index is joined again and again (a resident index behind a service; not the command-line tool, whose context
-    // is single-shot): the tile kernel is the faster one on the whole matrix -- 0.030 against 0.032 ms at 10,000 genomes, 0.084
-    // against 0.115 at 50,000 -- once its records exist (1-2 ms, built by the launch that follows the first join).  Row shards
-    // stay with the near-window kernel (a 1/8 shard of 10,000 genomes: 0.012 against 0.020 ms).
-    if (o->row_step <= 1 && !ctx->single_shot) {
+    // is single-shot): the tile kernel is the faster one on a whole matrix of 4,000 genomes and more -- 0.0175 against 0.0179 ms
+    // at 4,000, 0.025 against 0.032 at 10,000, 0.075 against 0.115 at 50,000 -- once its records exist (1-2 ms, built by the launch
+    // that follows the first join); below, a launch is a handful of tiles, each a 15 us chain, and the near-window kernel wins
+    // (500 genomes: 0.010 against 0.016 ms).  Row shards: a tile costs the same whatever the shard, so only big shards move
+    // (12,000 rows and more: 1/2 and 1/4 of 50,000 genomes 0.053 / 0.037 against 0.067 / 0.047 ms; 1/8: 0.034 against 0.028;
+    // 1/2 of 10,000: 0.025 against 0.022).
+    const uint32_t step = o->row_step > 1 ? o->row_step : 1;
+    const bool worth = step == 1 ? idx->n_ref >= (uint32_t)ctx->sw_dist_tiles_min_genomes
+                                 : idx->n_ref / step >= (uint32_t)ctx->sw_dist_tiles_min_shard_rows;
+    if (worth && !ctx->single_shot) {
         if (idx->tiles_ready || idx->self_joins >= ctx->sw_dist_tiles_after) *use = true;
         if (launching) idx->self_joins++;
     }

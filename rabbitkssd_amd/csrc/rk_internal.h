@@ -54,6 +54,7 @@ struct rk_ctx {
     int sw_dist_near_uw = 0;    // RK_DIST_NEAR_UW=1|2|4: waves that share a unit of the near-window kernel (default: by the launch's size)
     int sw_dist_fb_skip = 1;   // RK_DIST_FB_SKIP=0: always launch the fallback pass of the near-window self join
     int sw_dist_tiles = 2;      // RK_DIST_TILES: 0 never the tile kernel (rk_dist_tile.inc), 1 for every sparse self join over sets, 2 when the index is wide or joined repeatedly
+    int sw_dist_tiles_min_genomes = 4000, sw_dist_tiles_min_shard_rows = 12000;   // RK_DIST_TILES_MIN_GENOMES / _MIN_SHARD_ROWS: below, a repeatedly joined index stays on the near-window kernel
     int sw_dist_tiles_after = 1; // RK_DIST_TILES_AFTER: unsharded self joins over one index after which the tile kernel takes over (a context that is not single-shot)
     int sw_dist_near_min = 16;  // RK_DIST_NEAR_MIN: the near-window kernel is used when a reportable pair of the smallest sketch needs at least this count
     int sw_dist_debug = 0;  // RK_DIST_DEBUG=1: the bands of every self join on stderr

@@ -379,7 +379,7 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     auto.close()
 
 
-def test_self_join_moves_to_the_tile_kernel_when_the_index_is_joined_again():
+def test_self_join_moves_to_the_tile_kernel_when_the_index_is_joined_again(monkeypatch):
     # a context that is not single-shot (a resident index queried repeatedly): the first unsharded self join runs on
     # rk_near_kernel, the following ones on the tile kernel (its records are built by the second); a row shard keeps the
     # near-window kernel; a single-shot context (the command-line tool) never switches.  Same hits every time.
@@ -387,6 +387,14 @@ def test_self_join_moves_to_the_tile_kernel_when_the_index_is_joined_again():
     postings, counts = ok.index_build32(h, off, 26)
     sizes = np.diff(off).astype(np.uint32)
     want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 0, 20, 0.05, threads=4)
+    c = capi.Context(0)   # (default switches: 2,000 genomes are below the size from which the move pays, 4,000)
+    idx = c.index_build(c.sketches_from_host(h, off), 26)
+    for _ in range(3):
+        assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.05).startswith("rk_near_kernel")
+        assert_hits_equal(c.dist_rows(idx, None, 1, 0, 20, 0.05)[0], want)
+    del idx
+    c.close()
+    monkeypatch.setenv("RK_DIST_TILES_MIN_GENOMES", "1000")
     for single_shot in (False, True):
         c = capi.Context(0)
         if single_shot:

@@ -53,8 +53,10 @@ def dist(n_genomes=10000, steps=5, row_step=1, row_block=0, order=0, clade=10, t
         def launch(i):
             ctx.dist_rows_dev(index, 1, metric, 20, 0.05, hits.data_ptr(), 1 << 23, counters.data_ptr() + 8 * i,
                               row_first=0, row_step=row_step, row_block=row_block, stream=stream.cuda_stream)
-        launch(steps)  # warm-up
+        launch(steps)  # warm-up: the first join over the index (near-window kernel) ...
+        launch(steps)  # ... and the second (a resident index moves to the tile kernel: its records are built here)
         torch.cuda.synchronize()
+        counters.zero_()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.time()
         ev0.record(stream)
