@@ -379,6 +379,36 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     auto.close()
 
 
+@pytest.mark.parametrize("threads", ["256", "512", "1024"])
+def test_tile_kernel_heavy_tiles_move_their_planes_mid_tile(monkeypatch, threads):
+    # 96 genomes (three blocks of 32) sharing up to 30,000 hashes: tiles of 30,000+ records, more than eleven bit planes
+    # hold for a lane of a four-wave workgroup (2 half-waves x 4 waves x 1,984) -- the planes move to the LDS counts in the
+    # middle of the tile (before the end-of-tile merge of the waves' planes adds the rest) -- and sketch sizes that leave
+    # steps of 1..8 groups of eight records behind (every arm of the adder tree: carries of weight 64, 32, 16 and 8)
+    rng = np.random.default_rng(5)
+    core = np.unique(rng.integers(0, 1 << 26, size=30000, dtype=np.uint64).astype(np.uint32))
+    parts = []
+    for g in range(96):
+        keep = core[rng.random(len(core)) < (0.97 if g < 40 else 0.6)]
+        own = rng.integers(0, 1 << 26, size=37 * (g % 9), dtype=np.uint64).astype(np.uint32)
+        parts.append(np.unique(np.concatenate([keep, own])))
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    h = np.concatenate(parts)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    monkeypatch.setenv("RK_DIST_TILES", "1")
+    monkeypatch.setenv("RK_TILE_THREADS", threads)
+    c = capi.Context(0)
+    idx = c.index_build(c.sketches_from_host(h, off), 26)
+    assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.2) == "rk_tile_kernel<%su>" % threads
+    for metric, D in ((0, 0.2), (1, 0.02)):
+        want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=8)
+        assert len(want) > 500 and want["common"].max() > 25000
+        assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+    del idx
+    c.close()
+
+
 def test_self_join_moves_to_the_tile_kernel_when_the_index_is_joined_again(monkeypatch):
     # a context that is not single-shot (a resident index queried repeatedly): the first unsharded self join runs on
     # rk_near_kernel, the following ones on the tile kernel (its records are built by the second); a row shard keeps the
