@@ -992,7 +992,8 @@ static void write_hits(const string &out, const vector<HitPart> &parts, bool all
     const int per_part = std::max(1, std::max(1, threads) / (int)std::max<size_t>(1, parts.size()));
     for (const HitPart &pt : parts) {
         // cut the part into up to per_part pieces of ~equal hit counts at row boundaries
-        uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_part * 4, (pt.n + 65535) / 65536));
+        // (pieces of ~4,096 hits: the 45,000 lines of a 10,000-genome alldist were ONE piece, formatted by one thread in 10 ms)
+        uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)per_part * 4, (pt.n + 4095) / 4096));
         if (max_size != (1ULL << 32)) want = (uint64_t)per_part;  // sub-file layout under test: one piece per worker
         uint64_t i0 = 0;
         size_t r0 = 0;
