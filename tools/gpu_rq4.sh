@@ -1,5 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-printf 'SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD\nSQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY\nTCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum\nSQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT\nSQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS\n' | tools/pmc_pass.sh pmcQ2 "rk_distq_kernel|k_member_sliced" dist_rq_dev 100000 1000 3
+export RK_DISTQ_SLICED=1
+printf 'SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD\nSQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_WAVE_CYCLES SQ_BUSY_CYCLES\n' | tools/pmc_pass.sh pmcQ2 "k_member_sliced" dist_rq_dev 100000 1000 3
 python3 tools/pmc_summary.py gpurun_out/pmcQ2_*
