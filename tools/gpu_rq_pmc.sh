@@ -1,4 +1,5 @@
 #!/bin/bash
+# counters of the sliced membership pass and its counting kernel (RK_DISTQ_SLICED=1) on configs[4]'s shape
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 export RK_DISTQ_SLICED=1

@@ -1,4 +1,5 @@
 #!/bin/bash
+# the sliced membership pass (RK_DISTQ_SLICED=1): its parity test, configs[4]'s shape against the fused kernel, the two kernels' times
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -x -q -k "sliced" > gpurun_out/rq_tests_sliced.log 2>&1 || { tail -40 gpurun_out/rq_tests_sliced.log; exit 1; }
