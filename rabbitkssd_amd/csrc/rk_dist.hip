@@ -1164,11 +1164,12 @@ int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bo
     // is single-shot): the tile kernel is the faster one on a whole matrix of 4,000 genomes and more -- 0.0175 against 0.0179 ms
     // at 4,000, 0.025 against 0.032 at 10,000, 0.075 against 0.115 at 50,000 -- once its records exist (1-2 ms, built by the launch
     // that follows the first join); below, a launch is a handful of tiles, each a 15 us chain, and the near-window kernel wins
-    // (500 genomes: 0.010 against 0.016 ms).  Row shards: a tile costs the same whatever the shard, so only big shards move
-    // (12,000 rows and more: 1/2 and 1/4 of 50,000 genomes 0.053 / 0.037 against 0.067 / 0.047 ms; 1/8: 0.034 against 0.028;
-    // 1/2 of 10,000: 0.025 against 0.022).
+    // (500 genomes: 0.010 against 0.016 ms).  Row shards: a tile costs the same whatever the shard, so only halves and big
+    // shards move (12,000 rows and more: 1/4 of 50,000 genomes 0.037 against 0.047 ms; 1/8: 0.034 against 0.028; 1/4 and 1/8 of
+    // 10,000: 0.0175 / 0.0127 against 0.0157 / 0.0121).
     const uint32_t step = o->row_step > 1 ? o->row_step : 1;
-    const bool worth = step == 1 ? idx->n_ref >= (uint32_t)ctx->sw_dist_tiles_min_genomes
+    // (half a matrix still holds enough tiles per round: 1/2 of 10,000 genomes 0.0172 against 0.0207 ms with the scalar row masks)
+    const bool worth = step <= 2 ? idx->n_ref >= (uint32_t)ctx->sw_dist_tiles_min_genomes
                                  : idx->n_ref / step >= (uint32_t)ctx->sw_dist_tiles_min_shard_rows;
     if (worth && !ctx->single_shot) {
         if (idx->tiles_ready || idx->self_joins >= ctx->sw_dist_tiles_after) *use = true;
@@ -1376,8 +1377,9 @@ int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *que
         const double t = exp(-(double)opts->kmer_size * opts->max_dist);
         unsigned long long grid = 0;
         int threads = 256;
-        tile_launch_shape(idx, opts, ((opts->metric != 0) ? t : t / (2.0 - t)) * (1.0 - 1e-6), &grid, &threads);
-        snprintf(buf, cap, "rk_tile_kernel<%du>", threads);
+        bool srow = false;
+        tile_launch_shape(idx, opts, ((opts->metric != 0) ? t : t / (2.0 - t)) * (1.0 - 1e-6), &grid, &threads, &srow);
+        snprintf(buf, cap, "rk_tile_kernel<%du, %s>", threads, srow ? "true" : "false");
         return RK_OK;
     }
     const NearPlan np = plan_near(ctx, idx, opts, rk_dense_mode(opts));

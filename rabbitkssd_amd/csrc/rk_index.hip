@@ -656,6 +656,8 @@ void rk_index_free(rk_index *idx)
     rk_pool_free(ctx, idx->d_orig);
     rk_pool_free(ctx, idx->d_fb);
     rk_pool_free(ctx, idx->d_tile_contrib);
+    rk_pool_free(ctx, idx->d_tile_rows);
+    rk_pool_free(ctx, idx->d_tile_cols);
     rk_pool_free(ctx, idx->d_tile_key);
     rk_pool_free(ctx, idx->d_tile_start);
     rk_pool_free(ctx, idx->d_blk_min);

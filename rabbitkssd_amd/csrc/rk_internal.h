@@ -201,7 +201,9 @@ struct rk_index {
     void *fb_event = nullptr;        // hipEvent_t
     // Tile records of the self join over 32 x 32 tiles (rk_dist_tile.inc), built on first use: per tile (block b of rows,
     // block w >= b of columns) the (row mask, column mask) pairs of the posting lists that touch both blocks, sorted by tile
-    uint2 *d_tile_contrib = nullptr;            // uint2[n_tile_records]
+    uint2 *d_tile_contrib = nullptr;            // uint2[n_tile_records + pad]: (row mask, column mask), sorted by tile
+    uint32_t *d_tile_rows = nullptr, *d_tile_cols = nullptr;   // u32[n_tile_slots + 256] each: a split copy of the records in which every tile starts at an EVEN slot (an odd tile is padded with one empty record): the SROW variant of the kernel (short launches) reads the row masks of two neighbouring records as one 64-bit scalar
+    uint64_t n_tile_slots = 0, tile_max_records = 0;   // (the biggest tile)
     unsigned long long *d_tile_key = nullptr;   // u64[n_tiles]: b << 32 | w, ascending
     unsigned long long *d_tile_start = nullptr; // u64[n_tiles + 1]
     uint32_t *d_blk_min = nullptr;              // u32[ceil(n_ref / 32)]: smallest non-empty sketch of the block

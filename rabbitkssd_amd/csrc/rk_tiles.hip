@@ -151,18 +151,47 @@ __global__ void k_tile_prefix_table(const uint32_t *keys, unsigned long long n_t
 
 // the directory in launch order (tiles by density, descending, for one metric), everything a workgroup of rk_tile_kernel needs
 // to know in ONE 32-byte entry -- before: order -> key -> start, start + 1 -> two block minima, a chain of four round trips at
-// the start of every workgroup.  Entry: {b, w, start (2 words)} {records, lower bound of any cell's denominator, 0, 0}
-__global__ void k_tile_dir(const uint32_t *order, const unsigned long long *tile_key, const unsigned long long *tile_start, const uint32_t *blk_min,
-                           unsigned long long n_tiles, int metric, uint4 *out)
+// the start of every workgroup.  Entry: {b, w, first record (2 words)} {records, lower bound of any cell's denominator, first slot
+// of its row masks in the padded array (2 words)}
+__global__ void k_tile_dir(const uint32_t *order, const unsigned long long *tile_key, const unsigned long long *tile_start,
+                           const unsigned long long *slot_start, const uint32_t *blk_min, unsigned long long n_tiles, int metric, uint4 *out)
 {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tiles) return;
     const uint32_t t = order[i];
-    const unsigned long long key = tile_key[t], s0 = tile_start[t], s1 = tile_start[t + 1];
+    const unsigned long long key = tile_key[t], s0 = tile_start[t], n = tile_start[t + 1] - s0, d0 = slot_start[t];   // (d0: even, in the row-mask array)
     const uint32_t b = (uint32_t)(key >> 32), w = (uint32_t)key;
     const uint32_t mb = blk_min[b], mw = blk_min[w];
     out[2 * i] = make_uint4(b, w, (uint32_t)s0, (uint32_t)(s0 >> 32));
-    out[2 * i + 1] = make_uint4((uint32_t)min(s1 - s0, 0xFFFFFFFFULL), metric ? min(mb, mw) : max(mb, mw), 0u, 0u);
+    out[2 * i + 1] = make_uint4((uint32_t)min(n, 0xFFFFFFFFULL), metric ? min(mb, mw) : max(mb, mw), (uint32_t)d0, (uint32_t)(d0 >> 32));
+}
+
+__global__ void k_tile_max(const unsigned long long *tile_start, unsigned long long n_tiles, unsigned long long *out)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = t < n_tiles ? tile_start[t + 1] - tile_start[t] : 0ULL;
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned long long)__shfl_xor((long long)v, o));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+}
+// padded[t] = the tile's record count rounded up to even (scanned in place into the tiles' first slots)
+__global__ void k_tile_padded_counts(const unsigned long long *tile_start, unsigned long long n_tiles, unsigned long long *padded)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tiles) padded[t] = (tile_start[t + 1] - tile_start[t] + 1ULL) & ~1ULL;
+}
+// one wave per tile: its records (sorted AoS) go to the split arrays from the tile's even first slot on
+__global__ void k_tile_split(const uint2 *recs, const unsigned long long *tile_start, const unsigned long long *slot_start, unsigned long long n_tiles,
+                             uint32_t *rows, uint32_t *cols)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long s0 = tile_start[t], n = tile_start[t + 1] - s0, d0 = slot_start[t];
+    for (unsigned long long i = lane; i < n; i += 64) {
+        const uint2 r = recs[s0 + i];
+        rows[d0 + i] = r.x;
+        cols[d0 + i] = r.y;
+    }
 }
 
 #define RK_TILE_TRY(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
@@ -202,6 +231,8 @@ int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
     DevBuf<uint2> vals_out(ctx);
     DevBuf<uint32_t> order_j(ctx), order_c(ctx);
     DevBuf<uint4> dir_j(ctx), dir_c(ctx);
+    DevBuf<uint32_t> t_rows(ctx), t_cols(ctx);
+    unsigned long long n_slots = 0;
     unsigned long long n_c = 0, n_t = 0;
     if (H && U) {
         DevBuf<uint32_t> bm(ctx), rank(ctx);
@@ -238,7 +269,7 @@ int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
         if (n_c) {
             DevBuf<unsigned long long> keys(ctx);
             DevBuf<uint2> vals(ctx);
-            if (keys.alloc(n_c) != hipSuccess || vals.alloc(n_c) != hipSuccess || keys_out.alloc(n_c) != hipSuccess || vals_out.alloc(n_c + 16) != hipSuccess)
+            if (keys.alloc(n_c) != hipSuccess || vals.alloc(n_c) != hipSuccess || keys_out.alloc(n_c) != hipSuccess || vals_out.alloc(n_c + 256) != hipSuccess)
                 return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %llu tile records", n_c);
             int kbits = 1;
             while (kbits < 32 && (1u << kbits) < n_blocks) kbits++;
@@ -282,7 +313,9 @@ int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
             RK_HIP(ctx, key_out.alloc(n_t));
             RK_HIP(ctx, order_j.alloc(n_t));
             RK_HIP(ctx, order_c.alloc(n_t));
-            RK_HIP(ctx, table.alloc(2 * kTileTable));
+            RK_HIP(ctx, table.alloc(2 * kTileTable + 1));
+            RK_HIP(ctx, hipMemsetAsync(table.p + 2 * kTileTable, 0, 8, st));
+            hipLaunchKernelGGL(k_tile_max, nb(n_t), dim3(tpb), 0, st, tile_start.p, n_t, table.p + 2 * kTileTable);
             hipLaunchKernelGGL(k_tile_ratio_keys, nb(n_t), dim3(tpb), 0, st, tile_key.p, tile_start.p, blk_min.p, n_t, key_j.p, key_c.p, ids.p);
             RK_HIP(ctx, hipGetLastError());
             size_t tb3 = 0;
@@ -294,17 +327,36 @@ int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
             RK_HIP(ctx, hipStreamSynchronize(st));   // (key_out is reused)
             RK_HIP(ctx, rocprim::radix_sort_pairs(tmp3.p, tb3, key_c.p, key_out.p, ids.p, order_c.p, (size_t)n_t, 0, 32, st));
             hipLaunchKernelGGL(k_tile_prefix_table, dim3(1), dim3(kTileTable), 0, st, key_out.p, n_t, table.p + kTileTable);
+            // a split copy of the records (row masks / column masks), every tile from an even slot on: the SROW variant of
+            // rk_tile_kernel reads two neighbouring row masks as one 64-bit scalar (the lane mask of a v_cndmask) and streams the
+            // column masks alone through LDS
+            DevBuf<unsigned long long> slot_start(ctx);
+            RK_HIP(ctx, slot_start.alloc(n_t + 1));
+            hipLaunchKernelGGL(k_tile_padded_counts, nb(n_t), dim3(tpb), 0, st, tile_start.p, n_t, slot_start.p);
+            RK_HIP(ctx, hipGetLastError());
+            RK_TILE_TRY(tile_scan_u64(ctx, slot_start.p, n_t, &n_slots, st));
+            RK_HIP(ctx, t_rows.alloc(n_slots + 256));
+            RK_HIP(ctx, t_cols.alloc(n_slots + 256));
+            RK_HIP(ctx, hipMemsetAsync(t_rows.p, 0, (n_slots + 256) * 4, st));
+            RK_HIP(ctx, hipMemsetAsync(t_cols.p, 0, (n_slots + 256) * 4, st));
+            hipLaunchKernelGGL(k_tile_split, dim3((unsigned)((n_t + 3) / 4)), dim3(256), 0, st, vals_out.p, tile_start.p, slot_start.p, n_t, t_rows.p, t_cols.p);
             RK_HIP(ctx, dir_j.alloc(2 * n_t));
             RK_HIP(ctx, dir_c.alloc(2 * n_t));
-            hipLaunchKernelGGL(k_tile_dir, nb(n_t), dim3(tpb), 0, st, order_j.p, tile_key.p, tile_start.p, blk_min.p, n_t, 0, dir_j.p);
-            hipLaunchKernelGGL(k_tile_dir, nb(n_t), dim3(tpb), 0, st, order_c.p, tile_key.p, tile_start.p, blk_min.p, n_t, 1, dir_c.p);
+            hipLaunchKernelGGL(k_tile_dir, nb(n_t), dim3(tpb), 0, st, order_j.p, tile_key.p, tile_start.p, slot_start.p, blk_min.p, n_t, 0, dir_j.p);
+            hipLaunchKernelGGL(k_tile_dir, nb(n_t), dim3(tpb), 0, st, order_c.p, tile_key.p, tile_start.p, slot_start.p, blk_min.p, n_t, 1, dir_c.p);
+            RK_HIP(ctx, hipGetLastError());
+            RK_HIP(ctx, hipStreamSynchronize(st));   // (slot_start leaves scope)
             RK_HIP(ctx, hipGetLastError());
             RK_HIP(ctx, hipMemcpyAsync(idx->tile_prefix, table.p, sizeof(idx->tile_prefix), hipMemcpyDeviceToHost, st));
+            RK_HIP(ctx, hipMemcpyAsync(&idx->tile_max_records, table.p + 2 * kTileTable, 8, hipMemcpyDeviceToHost, st));
             RK_HIP(ctx, hipStreamSynchronize(st));
         }
     }
     RK_HIP(ctx, hipStreamSynchronize(st));
     idx->d_tile_contrib = vals_out.release();
+    idx->d_tile_rows = t_rows.release();
+    idx->d_tile_cols = t_cols.release();
+    idx->n_tile_slots = n_slots;
     idx->d_tile_key = tile_key.release();
     idx->d_tile_start = tile_start.release();
     idx->d_blk_min = blk_min.release();
@@ -316,7 +368,7 @@ int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
     idx->n_tile_records = n_c;
     idx->tiles_ready = true;
     if (ctx->sw_dist_debug)
-        fprintf(stderr, "[rk] tiles: %llu tiles, %llu records (%u genomes), built in %.3f ms\n", n_t, n_c, idx->n_ref,
+        fprintf(stderr, "[rk] tiles: %llu tiles, %llu records, biggest tile %llu (%u genomes), built in %.3f ms\n", n_t, n_c, (unsigned long long)idx->tile_max_records, idx->n_ref,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     return RK_OK;
 }

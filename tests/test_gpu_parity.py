@@ -356,15 +356,19 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     idx = c.index_build(c.sketches_from_host(h, off), 26)
     assert c.dist_kernel_name(idx, None, 1, metric, 20, D) .startswith("rk_tile_kernel<")
     assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
-    assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
     other, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 1 - metric, 20, D * 0.5, threads=4)
-    assert_hits_equal(c.dist_rows(idx, None, 1, 1 - metric, 20, D * 0.5)[0], other)
-    for step, block in ((3, 16), (2, 64), (5, 1)):
-        parts = [c.dist_rows(idx, None, 1, metric, 20, D, row_first=r, row_step=step, row_block=block)[0] for r in range(step)]
-        for r, p in enumerate(parts):
-            assert np.all(idx.shard_of(p, step, block) == r)
-        merged = np.concatenate(parts)
-        assert_hits_equal(merged[np.lexsort((merged["col"], merged["row"]))], want)
+    for srow in ("0", "1"):   # both variants of the kernel (masks through LDS / row masks as 64-bit scalars), whatever the launch would pick
+        monkeypatch.setenv("RK_TILE_SROW", srow)
+        assert c.dist_kernel_name(idx, None, 1, metric, 20, D).endswith(", true>" if srow == "1" else ", false>")
+        assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+        assert_hits_equal(c.dist_rows(idx, None, 1, 1 - metric, 20, D * 0.5)[0], other)
+        for step, block in ((3, 16), (2, 64), (5, 1)):
+            parts = [c.dist_rows(idx, None, 1, metric, 20, D, row_first=r, row_step=step, row_block=block)[0] for r in range(step)]
+            for r, p in enumerate(parts):
+                assert np.all(idx.shard_of(p, step, block) == r)
+            merged = np.concatenate(parts)
+            assert_hits_equal(merged[np.lexsort((merged["col"], merged["row"]))], want)
+    monkeypatch.delenv("RK_TILE_SROW")
     # a dense report (-D 1.0 under `dist` semantics is not a self join; alldist with D > 1) stays with the counter rows
     assert c.dist_kernel_name(idx, None, 1, metric, 20, 1.5).startswith("rk_dist_kernel")
     # the default: the tile kernel for collections with clusters wider than the window of rk_near_kernel
@@ -400,11 +404,13 @@ def test_tile_kernel_heavy_tiles_move_their_planes_mid_tile(monkeypatch, threads
     monkeypatch.setenv("RK_TILE_THREADS", threads)
     c = capi.Context(0)
     idx = c.index_build(c.sketches_from_host(h, off), 26)
-    assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.2) == "rk_tile_kernel<%su>" % threads
     for metric, D in ((0, 0.2), (1, 0.02)):
         want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=8)
         assert len(want) > 500 and want["common"].max() > 25000
-        assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+        for srow in ("false", "true"):   # both variants of the kernel: masks through LDS / row masks as 64-bit scalars
+            monkeypatch.setenv("RK_TILE_SROW", "1" if srow == "true" else "0")
+            assert c.dist_kernel_name(idx, None, 1, metric, 20, D) == "rk_tile_kernel<%su, %s>" % (threads, srow)
+            assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
     del idx
     c.close()
 
@@ -435,7 +441,7 @@ def test_self_join_moves_to_the_tile_kernel_when_the_index_is_joined_again(monke
             seen.append(c.dist_kernel_name(idx, None, 1, 0, 20, 0.05).split("<")[0])
             assert_hits_equal(c.dist_rows(idx, None, 1, 0, 20, 0.05)[0], want)
         assert seen == (["rk_near_kernel"] * 3 if single_shot else ["rk_near_kernel", "rk_tile_kernel", "rk_tile_kernel"]), seen
-        assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.05, row_first=1, row_step=2, row_block=32).startswith("rk_near_kernel")
+        assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.05, row_first=1, row_step=4, row_block=32).startswith("rk_near_kernel")   # (a small shard)
         del idx
         c.close()
 
