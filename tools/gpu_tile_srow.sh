@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 drv() { timeout -k 10 300 python3 tools/prof_driver.py "$@" 2>&1 | grep -v amdgpu.ids | tail -1 | sed 's/ ms.step.*//;s/dist //'; }
-for cfg in "4000 60" "10000 60" "10000 60 1 0 0 100" "20000 40" "10000 60 8 32" "10000 60 2 32" "50000 20 2 32"; do
+for cfg in "4000 60" "10000 60" "10000 60 1 0 0 100" "20000 40" "10000 60 1 0 0 1000" "50000 20" "10000 60 8 32" "10000 60 2 32"; do
   a=""; b=""
   for rep in 1 2 3; do
     a="$a $(RK_TILE_SROW=1 RK_DIST_TILES=1 drv dist $cfg)"
