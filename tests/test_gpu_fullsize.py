@@ -131,6 +131,39 @@ def test_config3_alldist_50k_exact(ctx):
     assert np.array_equal(m2["common"][key], want["common"]) and np.array_equal(m2["dist"][key], want["dist"])
 
 
+def test_self_join_kernels_agree_at_full_size(monkeypatch):
+    """size-independent property: on 30,000 sketches with species of 10 and of 100 strains mixed, a tiny sketch among them,
+    the near-window kernel (with its fallback), the tile kernel in both variants (masks through LDS, row masks as 64-bit
+    scalars) and row shards of either report the same pairs with the same counts and distances -- for thresholds and metrics
+    the oracle would need minutes for at this size (the 10,000- and 50,000-genome tests above pin the oracle itself)."""
+    n1, h1, o1 = synth.clade_sketches(20000, 1220, 28, seed=901)
+    n2, h2, o2 = synth.clade_sketches(10000, 1220, 28, strains_per_clade=100, seed=902, tiny=1)
+    h = np.concatenate([h1, h2])
+    off = np.concatenate([o1, o2[1:] + o1[-1]]).astype(np.uint64)
+    monkeypatch.setenv("RK_DIST_TILES", "0")
+    near = capi.Context(0)
+    monkeypatch.setenv("RK_DIST_TILES", "1")
+    tiles = capi.Context(0)
+    monkeypatch.delenv("RK_DIST_TILES")
+    idx_n = near.index_build(near.sketches_from_host(h, off), 28)
+    idx_t = tiles.index_build(tiles.sketches_from_host(h, off), 28)
+    for metric, D in ((0, 0.05), (0, 0.12), (1, 0.03)):
+        assert not near.dist_kernel_name(idx_n, None, 1, metric, 20, D).startswith("rk_tile_kernel")
+        want = dev_hits(near, idx_n, 1, metric, 20, D, cap=1 << 22)
+        assert len(want) > 500000
+        for srow in ("0", "1"):
+            monkeypatch.setenv("RK_TILE_SROW", srow)
+            assert tiles.dist_kernel_name(idx_t, None, 1, metric, 20, D).startswith("rk_tile_kernel<")
+            check_dev_hits(dev_hits(tiles, idx_t, 1, metric, 20, D, cap=1 << 22), want)
+        monkeypatch.delenv("RK_TILE_SROW")
+        parts = [dev_hits(tiles, idx_t, 1, metric, 20, D, cap=1 << 22, row_first=r, row_step=4, row_block=32) for r in range(4)]
+        merged = np.concatenate(parts)
+        check_dev_hits(merged[np.lexsort((merged["col"], merged["row"]))], want)
+    del idx_n, idx_t
+    near.close()
+    tiles.close()
+
+
 def test_dense_output_ordered_on_the_device(ctx):
     """-D 1.5 reports every pair: 2,000 genomes -> 1,999,000 hits, more than the 2^20 above which the
     result is ordered on the device; order and content equal the oracle's"""
