@@ -230,13 +230,20 @@ int rk_index_hash_bits(const rk_index *idx);
 /* 1 when rk_index_build took its bucket-sort path (set sketches with 32-bit hashes whose buckets fit the LDS sort),
  * 0 for the general path (device-wide radix sort) or an imported index: lets a harness say which build it timed. */
 int rk_index_built_fast(const rk_index *idx);
+/* Which structures of the all-vs-all join the index carries right now, as a bit mask: 1 = slice records (one per (genome,
+ * hash) element: rk_near_kernel, rk_dist_kernel), 2 = tile records (one per posting list and pair of 32-genome blocks it
+ * touches: rk_tile_kernel), 4 = the tile records came with rk_index_build itself (collections of RK_DIST_TILES_MIN_GENOMES =
+ * 4,000 genomes and more: the FIRST self join already runs on the tile kernel; slice records are then made on first use --
+ * a dense report, RK_DIST_TILES=0).  Which kernel a self join takes depends on this, the index's size and the options --
+ * never on how often the index was joined before.  (The reference has one loop for every collection, src/dist.cpp:174-258.) */
+int rk_index_products(const rk_index *idx);
 /* sum over all reference hashes h of c_h^2 = postings streamed by a full alldist
  * (the T of the roofline formula) */
 uint64_t rk_index_sum_sq(const rk_index *idx);
 /* The all-vs-all join reads one 8-byte slice record per (genome, hash) pair with later sharers.  out[0] = records,
  * out[1] = of which in compact form (first genome + bitmask: the record IS the posting list, no posting is gathered),
  * out[2] = records the row-pair kernel walks (the rest are covered by the pair partner), out[3] = the 8-byte tile records of
- * the tile kernel (one per posting list and pair of 32-genome blocks it touches; 0 until a self join has built them).
+ * the tile kernel (one per posting list and pair of 32-genome blocks it touches; 0 while the index has none: rk_index_products).
  * Computed on first request (one small kernel) and cached; 0s for an imported index. */
 int rk_index_self_stats(const rk_index *idx, uint64_t out[4]);
 /* Multi-GPU: the whole index as ONE contiguous device blob, so that the owner can hand it

@@ -210,7 +210,6 @@ int rk_ctx_create(int device, rk_ctx **out)
     if (getenv("RK_DIST_BAND_MIN_ROWS")) ctx->sw_dist_band_min_rows = std::max(1, atoi(getenv("RK_DIST_BAND_MIN_ROWS")));
     ctx->sw_dist_near = getenv("RK_DIST_NEAR") ? atoi(getenv("RK_DIST_NEAR")) != 0 : 1;
     if (getenv("RK_DIST_TILES")) ctx->sw_dist_tiles = atoi(getenv("RK_DIST_TILES"));
-    if (getenv("RK_DIST_TILES_AFTER")) ctx->sw_dist_tiles_after = atoi(getenv("RK_DIST_TILES_AFTER"));
     if (getenv("RK_DIST_TILES_MIN_GENOMES")) ctx->sw_dist_tiles_min_genomes = atoi(getenv("RK_DIST_TILES_MIN_GENOMES"));
     if (getenv("RK_DIST_TILES_MIN_SHARD_ROWS")) ctx->sw_dist_tiles_min_shard_rows = atoi(getenv("RK_DIST_TILES_MIN_SHARD_ROWS"));
     if (getenv("RK_DIST_NEAR_UW")) ctx->sw_dist_near_uw = atoi(getenv("RK_DIST_NEAR_UW"));
@@ -222,6 +221,8 @@ int rk_ctx_create(int device, rk_ctx **out)
     ctx->sw_index_fast = getenv("RK_INDEX_FAST") ? atoi(getenv("RK_INDEX_FAST")) != 0 : 1;
     ctx->sw_index_relabel = getenv("RK_INDEX_RELABEL") ? atoi(getenv("RK_INDEX_RELABEL")) != 0 : 1;
     ctx->sw_index_no_self = getenv("RK_INDEX_NO_SELF") ? atoi(getenv("RK_INDEX_NO_SELF")) != 0 : 0;
+    if (getenv("RK_INDEX_TILES")) ctx->sw_index_tiles = atoi(getenv("RK_INDEX_TILES"));
+    if (getenv("RK_TILE_REC_CAP")) ctx->sw_tile_rec_cap = strtoull(getenv("RK_TILE_REC_CAP"), nullptr, 10);
     *out = ctx;
     return RK_OK;
 }

@@ -1123,18 +1123,34 @@ __global__ void k_count_flagged(const uint2 *selfrange, uint64_t n_self, unsigne
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(acc, mine);
 }
 
-// Which kernel takes a sparse self join over set sketches: the tile kernel when the collection has clusters wider than
-// the window of rk_near_kernel (decided once per index from its slice records: one pass, one 8-byte read-back), when a
-// sketch is so small -- or the threshold so loose -- that rk_near_kernel's bound on the cells beyond its window cannot hold,
-// or when RK_DIST_TILES=1 asks for it; RK_DIST_TILES=0 never.
-int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bool dense_mode, hipStream_t stream, bool *use, bool launching = false)
+// Which kernel takes a sparse self join over set sketches -- decided by the index's SIZE AND SHAPE and the options alone, never
+// by how often the index was joined before (until round 4 a resident index moved to the tile kernel at its second join: a
+// benchmark loop and a user got different kernels):
+//   * the index carries tile records (rk_index_build emits them from RK_DIST_TILES_MIN_GENOMES genomes on, rk_index_tiles.inc;
+//     or an earlier launch built them lazily): the tile kernel -- except for small row shards of an index that ALSO has slice
+//     records (a tile costs the same whatever the shard: the near-window kernel is the faster one below ~12,000 rows);
+//   * no slice records (2^31 postings and more): the tile kernel, records built lazily;
+//   * a sketch so small -- or a threshold so loose -- that rk_near_kernel's bound on the cells beyond its window cannot hold, or
+//     clusters wider than its window (known from the build's slice records): the tile kernel, records built lazily;
+//   * a completed launch of rk_near_kernel found rows in its fallback list (clusters a little wider than the window, which the
+//     build cannot see): the tile kernel from then on -- the one rule that looks at an earlier launch, and only at its RESULT;
+//   * RK_DIST_TILES=1 always, RK_DIST_TILES=0 never.
+int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bool dense_mode, hipStream_t stream, bool *use)
 {
     *use = false;
-    if ((!ctx->sw_dist_tiles && cidx->d_selfrange) || dense_mode || !cidx->ref_sets || !cidx->d_postings || !cidx->d_upos || !cidx->d_src_off || !cidx->n_ref ||
-        o->kmer_size <= 0 || o->row_block < 0 || !(o->max_dist > 0.0))
+    if (dense_mode || !cidx->ref_sets || !cidx->d_postings || !cidx->d_upos || !cidx->d_src_off || !cidx->n_ref || o->kmer_size <= 0 || o->row_block < 0 ||
+        !(o->max_dist > 0.0) || cidx->tiles_unusable)
         return RK_OK;
-    if (ctx->sw_dist_tiles == 1 || !cidx->d_selfrange) { *use = true; return RK_OK; }   // (no slice records: an index of 2^31 postings and more)
+    const bool can_rows = cidx->d_selfrange || (!cidx->slices_refused && cidx->H < (1ULL << 30));   // (slice records exist or can be made: rk_index_ensure_slices)
+    if (!ctx->sw_dist_tiles && can_rows) return RK_OK;
+    if (ctx->sw_dist_tiles == 1 || !can_rows) { *use = true; return RK_OK; }
     if (!ctx->sw_dist_near) return RK_OK;   // (RK_DIST_NEAR=0 asks for the kernels with counter rows)
+    if (cidx->tiles_ready) {
+        const uint32_t step = o->row_step > 1 ? o->row_step : 1;
+        const bool small_shard = step > 2 && cidx->n_ref / step < (uint32_t)ctx->sw_dist_tiles_min_shard_rows;
+        *use = !(small_shard && cidx->d_selfrange);
+        return RK_OK;
+    }
     {   // a sketch so small that the chance hashes of a row reach its threshold: rk_near_kernel would send every row to its fallback
         const double t = exp(-(double)o->kmer_size * o->max_dist);
         const double min_jorc = ((o->metric != 0) ? t : t / (2.0 - t)) * (1.0 - 1e-6);
@@ -1157,24 +1173,7 @@ int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bo
         idx->spread = flagged * 8 > idx->n_self;
         idx->spread_known = 1;
     }
-    // ... or a completed launch of the near-window kernel over this index found rows in its fallback list (fb_state 3: clusters
-    // a little wider than the window, an order that does not cluster): the tile kernel takes the later launches
     *use = idx->spread || idx->fb_state == 3;
-    // ... or the index is joined again and again (a resident index behind a service; not the command-line tool, whose context
-    // is single-shot): the tile kernel is the faster one on a whole matrix of 4,000 genomes and more -- 0.0175 against 0.0179 ms
-    // at 4,000, 0.025 against 0.032 at 10,000, 0.075 against 0.115 at 50,000 -- once its records exist (1-2 ms, built by the launch
-    // that follows the first join); below, a launch is a handful of tiles, each a 15 us chain, and the near-window kernel wins
-    // (500 genomes: 0.010 against 0.016 ms).  Row shards: a tile costs the same whatever the shard, so only halves and big
-    // shards move (12,000 rows and more: 1/4 of 50,000 genomes 0.037 against 0.047 ms; 1/8: 0.034 against 0.028; 1/4 and 1/8 of
-    // 10,000: 0.0175 / 0.0127 against 0.0157 / 0.0121).
-    const uint32_t step = o->row_step > 1 ? o->row_step : 1;
-    // (half a matrix still holds enough tiles per round: 1/2 of 10,000 genomes 0.0172 against 0.0207 ms with the scalar row masks)
-    const bool worth = step <= 2 ? idx->n_ref >= (uint32_t)ctx->sw_dist_tiles_min_genomes
-                                 : idx->n_ref / step >= (uint32_t)ctx->sw_dist_tiles_min_shard_rows;
-    if (worth && !ctx->single_shot) {
-        if (idx->tiles_ready || idx->self_joins >= ctx->sw_dist_tiles_after) *use = true;
-        if (launching) idx->self_joins++;
-    }
     return RK_OK;
 }
 
@@ -1199,18 +1198,25 @@ int launch_self(rk_ctx *ctx, const rk_index *idx, const rk_dist_opts *o, bool de
 {
     bool tiles = false;
     {
-        int rc = self_uses_tiles(ctx, idx, o, dense_mode, stream, &tiles, true);
+        int rc = self_uses_tiles(ctx, idx, o, dense_mode, stream, &tiles);
         if (rc) return rc;
     }
-    if (!tiles && !idx->d_selfrange)
-        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "this index has no slice records (2^31 postings or more, or RK_INDEX_NO_SELF): only sparse self "
-                                                "joins (a threshold below distance 1.0) run on it");
     if (tiles) {
-        int rc = rk_tiles_build(ctx, const_cast<rk_index *>(idx), stream);
+        int rc = rk_tiles_build(ctx, const_cast<rk_index *>(idx), stream);   // (a no-op for an index whose build emitted them)
         if (rc) return rc;
-        const double t = exp(-(double)o->kmer_size * o->max_dist);
-        const double min_jorc = ((o->metric != 0) ? t : t / (2.0 - t)) * (1.0 - 1e-6);
-        return launch_tiles(ctx, idx, o, min_jorc, hits_dev, cap, n_hits_dev, stream);
+        if (!idx->tiles_unusable) {
+            const double t = exp(-(double)o->kmer_size * o->max_dist);
+            const double min_jorc = ((o->metric != 0) ? t : t / (2.0 - t)) * (1.0 - 1e-6);
+            return launch_tiles(ctx, idx, o, min_jorc, hits_dev, cap, n_hits_dev, stream);
+        }
+    }
+    if (!idx->d_selfrange) {   // the row kernels read slice records: an index built with tile records gets them on first use
+        if (idx->slices_refused || idx->H >= (1ULL << 30))
+            return rk_fail(ctx, RK_ERR_UNSUPPORTED, "this index has no slice records (2^31 postings or more): only sparse self joins (a threshold "
+                                                    "below distance 1.0) over set sketches run on it%s", idx->tiles_unusable ? ", and its tile records "
+                                                    "exceed the memory budget (lists scattered over thousands of genomes)" : "");
+        int rc = rk_index_ensure_slices(ctx, const_cast<rk_index *>(idx), stream);
+        if (rc) return rc;
     }
     const NearPlan np = plan_near(ctx, idx, o, dense_mode);
     if (np.use) {
@@ -1371,9 +1377,11 @@ int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *que
     bool tiles = false;
     int trc = self_uses_tiles(ctx, idx, opts, rk_dense_mode(opts), ctx->stream, &tiles);
     if (trc) return trc;
-    if (tiles) {   // (the variant follows the launch size, which needs the tile directory: built here if it is not there yet)
-        trc = rk_tiles_build(ctx, const_cast<rk_index *>(idx), ctx->stream);
-        if (trc) return trc;
+    if (tiles && !idx->tiles_ready) {   // (the variant follows the launch size, which needs the tile directory: not built here -- this call changes nothing)
+        snprintf(buf, cap, "rk_tile_kernel");
+        return RK_OK;
+    }
+    if (tiles) {
         const double t = exp(-(double)opts->kmer_size * opts->max_dist);
         unsigned long long grid = 0;
         int threads = 256;

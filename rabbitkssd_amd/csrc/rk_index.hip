@@ -581,6 +581,7 @@ int postings_in_caller_ids(rk_ctx *ctx, const rk_index *idx, hipStream_t st, uin
 }
 
 #include "rk_index_fast.inc"
+#include "rk_index_tiles.inc"
 
 template <class T> int pool_array(rk_ctx *ctx, T **out, size_t n)
 {
@@ -615,6 +616,100 @@ int classify_lists(rk_ctx *ctx, rk_index *idx, hipStream_t st)
 }  // namespace
 
 // prefix directory into the sorted distinct hashes: built on first use (64-bit hashes, hash spaces above 2^30)
+// ---- slice records on first use (an index built with tile records has none) ------------------------------------------
+// one thread per posting list: the slice record of every member, by posting position, as the bucket emission writes them
+// (class carried by the record: slice_class2).  A list longer than a compact record walks once; the compact ones are short.
+__global__ void k_slices_from_lists(const uint32_t *postings, const uint32_t *upos, uint64_t U, uint2 *raw, uint32_t *pos)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    const uint32_t s = upos[u], e = upos[u + 1];
+    const uint32_t last = e > s ? postings[e - 1] : 0u;
+    uint32_t prev = 0xFFFFFFFFu;
+    for (uint32_t k = s; k < e; k++) {
+        const uint32_t g = postings[k];
+        uint2 rec = make_uint2(0, 0);
+        if (k + 1 < e) {
+            const uint32_t first = postings[k + 1];
+            const bool covered = (g & 1u) && prev == g - 1;
+            if (last - first <= 31u) {
+                uint32_t mask = 0;
+                for (uint32_t m = k + 1; m < e; m++) mask |= 1u << (postings[m] - first);
+                rec = make_uint2(0x80000000u | first, covered ? mask & ~1u : mask);
+            } else {
+                rec = make_uint2((k + 1) | (covered ? 0x40000000u : 0u), e | (first - g <= 32u ? 0x80000000u : 0u));
+            }
+        }
+        raw[k] = rec;
+        pos[k] = k;
+        prev = g;
+    }
+}
+__global__ void k_gather_slices(const uint2 *raw, const uint32_t *sorted_pos, uint64_t H, uint2 *out)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < H) out[e] = raw[sorted_pos[e]];
+}
+
+int rk_index_ensure_slices(rk_ctx *ctx, rk_index *idx, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(idx->lazy_mu);
+    if (idx->d_selfrange) return RK_OK;
+    // (the raw record keeps its class in bit 30 of a posting offset: as in the fast build, H < 2^30 -- every index that was built
+    // with tile records is)
+    if (idx->slices_refused || idx->H >= (1ULL << 30) || !idx->ref_sets || !idx->d_src_off || idx->wide != (idx->d_uhash64 != nullptr))
+        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "this index has no slice records (2^31 postings or more, or RK_INDEX_NO_SELF): only sparse self "
+                                                "joins (a threshold below distance 1.0) run on it");
+    const auto t_begin = std::chrono::steady_clock::now();
+    const uint64_t H = idx->H, U = idx->U;
+    const uint32_t N = idx->n_ref;
+    DevBuf<uint2> raw(ctx), self_raw(ctx), out(ctx);
+    DevBuf<uint32_t> pos(ctx), keys_sorted(ctx), pos_sorted(ctx), n_open(ctx), n_cov(ctx);
+    DevBuf<uint64_t> self_off(ctx), self_split(ctx);
+    DevBuf<BuildResult> res(ctx);
+    RK_HIP(ctx, raw.alloc(H));
+    RK_HIP(ctx, self_raw.alloc(H));
+    RK_HIP(ctx, out.alloc(H + 1));
+    RK_HIP(ctx, pos.alloc(H));
+    RK_HIP(ctx, keys_sorted.alloc(H));
+    RK_HIP(ctx, pos_sorted.alloc(H));
+    RK_HIP(ctx, n_open.alloc((size_t)N + 1));
+    RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
+    RK_HIP(ctx, self_off.alloc((size_t)N + 1));
+    RK_HIP(ctx, self_split.alloc((size_t)N + 1));
+    RK_HIP(ctx, res.alloc(1));
+    RK_HIP(ctx, hipMemsetAsync(res.p, 0, sizeof(BuildResult), st));
+    BuildResult r{0, 0, 0, 0, 0};
+    if (H) {
+        hipLaunchKernelGGL(k_slices_from_lists, dim3(blocks_for(U)), dim3(kThreads), 0, st, idx->d_postings, idx->d_upos, U, raw.p, pos.p);
+        RK_HIP(ctx, hipGetLastError());
+        // a genome's elements in ascending hash order = its row (the sketches are sets, sorted): a STABLE sort of the posting
+        // positions by genome
+        int gbits = 1;
+        while ((1ULL << gbits) < N) gbits++;
+        RK_TRY(rk_prim_sort_pairs_u32_u32(ctx, idx->d_postings, keys_sorted.p, pos.p, pos_sorted.p, H, (unsigned)gbits, st));
+        hipLaunchKernelGGL(k_gather_slices, dim3(blocks_for(H)), dim3(kThreads), 0, st, raw.p, pos_sorted.p, H, self_raw.p);
+        const unsigned wave_blocks = (N + 3) / 4;
+        hipLaunchKernelGGL(k_row_counts2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, n_open.p, n_cov.p);
+        hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, self_off.p, self_split.p, res.p);
+        hipLaunchKernelGGL(k_row_place2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, self_off.p, self_split.p, out.p);
+        RK_HIP(ctx, hipGetLastError());
+        RK_TRY(rk_read_back(ctx, &r, res.p, sizeof(r), st));
+    } else {
+        RK_HIP(ctx, hipMemsetAsync(self_off.p, 0, ((size_t)N + 1) * 8, st));
+        RK_HIP(ctx, hipMemsetAsync(self_split.p, 0, ((size_t)N + 1) * 8, st));
+        RK_HIP(ctx, hipStreamSynchronize(st));
+    }
+    idx->n_self = r.n_self;
+    idx->d_self_off = self_off.release();
+    idx->d_self_split = self_split.release();
+    idx->d_selfrange = out.release();   // (last: the other threads test this pointer)
+    if (ctx->sw_dist_debug)
+        fprintf(stderr, "[rk] slice records built on first use: %llu records in %.3f ms\n", (unsigned long long)r.n_self,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    return RK_OK;
+}
+
 int rk_index_ensure_dir(rk_ctx *ctx, rk_index *idx, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(idx->lazy_mu);
@@ -689,6 +784,11 @@ uint64_t rk_index_distinct(const rk_index *idx) { return idx ? idx->U : 0; }
 uint32_t rk_index_genomes(const rk_index *idx) { return idx ? idx->n_ref : 0; }
 int rk_index_hash_bits(const rk_index *idx) { return idx ? idx->hash_bits : 0; }
 int rk_index_built_fast(const rk_index *idx) { return idx && idx->built_fast ? 1 : 0; }
+int rk_index_products(const rk_index *idx)
+{
+    if (!idx) return 0;
+    return (idx->d_selfrange ? 1 : 0) | (idx->tiles_ready ? 2 : 0) | (idx->tiles_ready && idx->tiles_from_build ? 4 : 0);
+}
 
 uint64_t rk_index_sum_sq(const rk_index *cidx)
 {
@@ -779,12 +879,31 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     if (idx->wide) RK_TRY(pool_array(ctx, &idx->d_uhash64, Ucap + 1));
     else RK_TRY(pool_array(ctx, &idx->d_uhash, Ucap + 1));
     RK_TRY(pool_array(ctx, &idx->d_upos, Ucap + 2));
-    if (!no_self) {
+    auto alloc_slices = [&]() -> int {   // (not for an index whose build emits tile records: rk_index_ensure_slices, on first use)
+        if (no_self || idx->d_selfrange) return RK_OK;
         RK_TRY(pool_array(ctx, &idx->d_selfrange, H + 1));
         RK_TRY(pool_array(ctx, &idx->d_self_off, (size_t)N + 1));
         RK_TRY(pool_array(ctx, &idx->d_self_split, (size_t)N + 1));
-    }
+        return RK_OK;
+    };
     RK_TRY(pool_array(ctx, &idx->d_orig, (size_t)N + 1));
+    // ---- which build: the bucket sort (rk_index_fast.inc) when the key fields fit, and then with TILE records as its product
+    // (rk_index_tiles.inc) from RK_DIST_TILES_MIN_GENOMES genomes on -- the self join runs on rk_tile_kernel from its first launch --,
+    // with slice records (rk_near_kernel, rk_dist_kernel) below
+    int B = 1, gb = 1, rb = 1;
+    // (at most kMaxBucketBits: a bigger collection gets fuller buckets, up to the LDS capacity -- beyond it the kernels raise the overflow flag)
+    while (B < hash_bits && B < kMaxBucketBits && ((H + kBucketTarget - 1) / kBucketTarget) > (1ULL << B)) B++;
+    while ((1ULL << gb) < N) gb++;
+    while ((1ULL << rb) < s->max_size) rb++;
+    const int low_bits = hash_bits - B;
+    // (64-bit hashes -- use64, e.g. K12 L3: 36 bits -- take the same path as long as the key fields fit: the kernels that read
+    // the sketches are templated on the hash type, the bucket sort itself only ever sees the low bits)
+    const bool fast_ok = ctx->sw_index_fast && !no_self && H && H < (1ULL << 30) && s->is_set && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 &&
+                         low_bits + gb + rb <= 63 && gb <= 31 && rb <= 31;
+    const uint32_t n_blocks = (N + 31) / 32;
+    bool tiles_mode = fast_ok && N >= 2 && n_blocks <= kTileMaxBlocks &&
+                      (ctx->sw_index_tiles == 1 || (ctx->sw_index_tiles == 2 && N >= (uint32_t)ctx->sw_dist_tiles_min_genomes));
+    if (tiles_mode) RK_TRY(pool_array(ctx, &idx->d_blk_min, (size_t)n_blocks));
     const unsigned wave_blocks = (N + 3) / 4;  // 4 waves (genomes) per 256-thread workgroup
 
     // ---- internal genome order: relatives next to each other (see k_minhash_insert) ---------------------------------
@@ -872,6 +991,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             RK_HIP(ctx, rl_tab.alloc(N));
             hipLaunchKernelGGL(k_emit_table, dim3(nb_n), dim3(kThreads), 0, s2, inv, idx->d_src_off, N, rl_tab.p);
         }
+        if (idx->d_blk_min) hipLaunchKernelGGL(k_blk_min_sizes, dim3(blocks_for(n_blocks)), dim3(kThreads), 0, s2, idx->d_sizes, N, n_blocks, idx->d_blk_min);
         idx->relabeled = true;
         RK_HIP(ctx, hipGetLastError());
         if (forked) {
@@ -881,6 +1001,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
       } else {
         hipLaunchKernelGGL(k_iota, dim3(blocks_for((uint64_t)N + 1)), dim3(kThreads), 0, st, N, idx->d_orig);
         hipLaunchKernelGGL(k_sizes, dim3(blocks_for((uint64_t)N + 1)), dim3(kThreads), 0, st, s->d_off, N, idx->d_sizes, idx->d_src_off);
+        if (idx->d_blk_min) hipLaunchKernelGGL(k_blk_min_sizes, dim3(blocks_for(n_blocks)), dim3(kThreads), 0, st, idx->d_sizes, N, n_blocks, idx->d_blk_min);
       }
       return RK_OK;
     };
@@ -891,20 +1012,25 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     bool built = false;
 
     // ---- fast path: two-level bucket sort, second level and all emission in LDS (rk_index_fast.inc) -----------------
-    int B = 1, gb = 1, rb = 1;
-    // (at most kMaxBucketBits: a bigger collection gets fuller buckets, up to the LDS capacity -- beyond it the kernels raise the overflow flag)
-    while (B < hash_bits && B < kMaxBucketBits && ((H + kBucketTarget - 1) / kBucketTarget) > (1ULL << B)) B++;
-    while ((1ULL << gb) < N) gb++;
-    while ((1ULL << rb) < s->max_size) rb++;
-    const int low_bits = hash_bits - B;
-    // (64-bit hashes -- use64, e.g. K12 L3: 36 bits -- take the same path as long as the key fields fit: the kernels that read
-    // the sketches are templated on the hash type, the bucket sort itself only ever sees the low bits)
-    const bool fast_ok = ctx->sw_index_fast && !no_self && H && H < (1ULL << 30) && s->is_set && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 &&
-                         low_bits + gb + rb <= 63 && gb <= 31 && rb <= 31;
     if (ctx->sw_dist_debug && !fast_ok)
         fprintf(stderr, "[rk] index build: general path (H %llu, wide %d, sets %d, B %d, low bits %d, genome bits %d, position bits %d)\n",
                 (unsigned long long)H, (int)idx->wide, (int)s->is_set, B, low_bits, gb, rb);
-    if (fast_ok) {
+    TileResult tr;
+    memset(&tr, 0, sizeof tr);
+    bool fast_refused = false;
+    DevBuf<uint2> t_contrib(ctx);
+    DevBuf<uint32_t> t_rows(ctx), t_cols(ctx);
+    DevBuf<uint4> t_dir_j(ctx), t_dir_c(ctx);
+    for (int attempt = 0; fast_ok && !built && attempt < 2; attempt++) {
+        // (second attempt: the tile records of the first did not fit their buffer -- lists scattered over many blocks -- and the
+        // index is built with slice records after all)
+        if (attempt == 1 && (fast_refused || !tr.overflow)) break;
+        if (attempt == 1) {
+            tiles_mode = false;
+            rk_pool_free(ctx, idx->d_blk_min);
+            idx->d_blk_min = nullptr;
+        }
+        if (!tiles_mode) RK_TRY(alloc_slices());
         FastArgs fa;
         fa.hashes = idx->wide ? (const void *)s->d_hashes64 : (const void *)s->d_hashes;
         fa.off = s->d_off;
@@ -915,13 +1041,18 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         fa.hash_bits = hash_bits;
         fa.low_bits = low_bits;
         fa.gb = gb;
-        fa.rb = rb;
+        fa.rb = tiles_mode ? 0 : rb;   // (tile records: nobody needs an element's position inside its sketch)
         fa.xcd_map = getenv("RK_INDEX_XCD") ? atoi(getenv("RK_INDEX_XCD")) : 1;
         fa.nb = 1u << B;
         fa.n_chunks = (uint32_t)((H + kPartChunk - 1) / kPartChunk);
         DevBuf<uint32_t> chunk_first(ctx), matrix(ctx), total(ctx), bstart(ctx), ucount(ctx), ubase(ctx), tmp_uhash(ctx), tmp_upos(ctx), n_open(ctx), n_cov(ctx);
         DevBuf<unsigned long long> keys(ctx), tmp_uhash64(ctx), zeroed(ctx);
         DevBuf<uint2> self_raw(ctx);
+        // tile records: unsorted (64 regions), binned by row block, the directory's proto entries
+        DevBuf<uint32_t> rec_key(ctx), bkey(ctx), bins(ctx), tb(ctx);
+        DevBuf<uint2> rec_val(ctx), bval(ctx);
+        DevBuf<uint4> proto(ctx);
+        DevBuf<unsigned long long> level_start(ctx);
         const bool wide = idx->wide;
         RK_HIP(ctx, chunk_first.alloc((size_t)fa.n_chunks + 1));
         RK_HIP(ctx, matrix.alloc((size_t)fa.n_chunks * fa.nb));
@@ -933,18 +1064,45 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         else RK_HIP(ctx, tmp_uhash.alloc(H));
         RK_HIP(ctx, tmp_upos.alloc(H));
         RK_HIP(ctx, keys.alloc(H));
-        RK_HIP(ctx, self_raw.alloc(H));
-        RK_HIP(ctx, n_open.alloc((size_t)N + 1));
-        RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
+        uint64_t rec_cap = 0, tile_cap = 0, slot_cap = 0;
+        uint32_t region_cap = 0;
+        if (tiles_mode) {
+            rec_cap = ctx->sw_tile_rec_cap ? ctx->sw_tile_rec_cap : H / 2 + 65536;
+            rec_cap = std::min<uint64_t>(rec_cap, 0x7FFF0000ULL);
+            region_cap = (uint32_t)((rec_cap + kRecRegions - 1) / kRecRegions);
+            rec_cap = (uint64_t)region_cap * kRecRegions;
+            tile_cap = std::min<uint64_t>(rec_cap, (uint64_t)n_blocks * (n_blocks + 1) / 2);
+            slot_cap = rec_cap + tile_cap;   // (every tile from an even slot on)
+            RK_HIP(ctx, rec_key.alloc(rec_cap));
+            RK_HIP(ctx, rec_val.alloc(rec_cap));
+            RK_HIP(ctx, bkey.alloc(rec_cap));
+            RK_HIP(ctx, bval.alloc(rec_cap));
+            RK_HIP(ctx, tb.alloc(2 * (size_t)n_blocks));
+            RK_HIP(ctx, bins.alloc((size_t)n_blocks + 1));   // bin starts (the counts and cursors are in `zeroed`)
+            RK_HIP(ctx, proto.alloc(2 * tile_cap));
+            RK_HIP(ctx, level_start.alloc(2 * (kTileTable + 1)));
+            RK_HIP(ctx, t_contrib.alloc(slot_cap + 256));
+            RK_HIP(ctx, t_rows.alloc(slot_cap + 256));
+            RK_HIP(ctx, t_cols.alloc(slot_cap + 256));
+            RK_HIP(ctx, t_dir_j.alloc(2 * tile_cap));
+            RK_HIP(ctx, t_dir_c.alloc(2 * tile_cap));
+        } else {
+            RK_HIP(ctx, self_raw.alloc(H));
+            RK_HIP(ctx, n_open.alloc((size_t)N + 1));
+            RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
+        }
         // everything the kernels expect zeroed, in one buffer and one fill (each fill is ~5 us on the stream): the result
-        // record and the cursors of the two-pass partition
-        const bool part2 = (getenv("RK_INDEX_PART2") ? atoi(getenv("RK_INDEX_PART2")) != 0 : true) && B >= 7 && low_bits + gb + rb <= 64 - (int)kFineBits;
+        // records, the cursors of the two-pass partition and of the tile sort
+        const bool part2 = (getenv("RK_INDEX_PART2") ? atoi(getenv("RK_INDEX_PART2")) != 0 : true) && B >= 7 && low_bits + gb + fa.rb <= 64 - (int)kFineBits;
         const bool small_wgs = (fa.nb >> kFineBits) <= 128;   // several workgroups per chunk: they share its stretch through counters
-        const size_t z_res = 0, z_cursor = z_res + (sizeof(BuildResult) + 7) / 8,
+        const size_t z_res = 0, z_tres = z_res + (sizeof(BuildResult) + 7) / 8, z_cursor = z_tres + (sizeof(TileResult) + 7) / 8,
                      z_taken = z_cursor + (part2 ? (fa.nb + 1) / 2 : 0),
-                     z_end = z_taken + (part2 && small_wgs ? ((size_t)fa.n_chunks * (fa.nb >> kFineBits) + 1) / 2 : 0);
+                     z_tcur = z_taken + (part2 && small_wgs ? ((size_t)fa.n_chunks * (fa.nb >> kFineBits) + 1) / 2 : 0),
+                     z_bins = z_tcur + (tiles_mode ? (sizeof(TileCursors) + 7) / 8 : 0),
+                     z_end = z_bins + (tiles_mode ? (size_t)n_blocks + 1 : 0);   // bin counts (u32[n_blocks + 1]) + bin cursors (u32[n_blocks])
         RK_HIP(ctx, zeroed.alloc(z_end));   // (zeroed by k_chunk_first, the first launch)
         BuildResult *const fres = reinterpret_cast<BuildResult *>(zeroed.p + z_res);
+        TileResult *const tres = reinterpret_cast<TileResult *>(zeroed.p + z_tres);
         uint32_t *const fine_cursor = reinterpret_cast<uint32_t *>(zeroed.p + z_cursor);
         uint32_t *const seg_taken = reinterpret_cast<uint32_t *>(zeroed.p + z_taken);
         const size_t part_lds = (size_t)fa.nb * 4 + 2 * kStageGenomes * 8;   // bucket counters + the chunk's genome bounds
@@ -978,36 +1136,89 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         } else {
             hipLaunchKernelGGL(k_part_scatter<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
         }
-        want_tab = true;
+        want_tab = !tiles_mode;
         RK_TRY(enqueue_renumbering());   // (behind the partition's launches in the host's queue, beside them on the device)
-        EmitArgs ea;
-        ea.keys = keys.p;
-        ea.bstart = bstart.p;
-        ea.off_new = idx->d_src_off;
-        ea.inv = inv;
-        ea.tab = inv ? rl_tab.p : nullptr;
-        ea.low_bits = low_bits;
-        ea.gb = gb;
-        ea.rb = rb;
-        ea.nb = fa.nb;
-        ea.postings = idx->d_postings;
-        ea.tmp_uhash = tmp_uhash.p;
-        ea.tmp_uhash64 = wide ? tmp_uhash64.p : nullptr;
-        ea.tmp_upos = tmp_upos.p;
-        ea.ucount = ucount.p;
-        ea.self_raw = self_raw.p;
-        ea.res = fres;
-        ea.xcd_map = fa.xcd_map;
-        ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
-        if (ea.debug) {  // developer ablations leave stages out: whatever they do not write must still be harmless downstream
-            RK_HIP(ctx, hipMemsetAsync(ucount.p, 0, (size_t)fa.nb * 4, st));
-            RK_HIP(ctx, hipMemsetAsync(self_raw.p, 0, H * sizeof(uint2), st));
-            RK_HIP(ctx, hipMemsetAsync(tmp_upos.p, 0, H * 4, st));
-        }
         RK_TRY(join());   // the internal order (inv, the offsets in internal order) is needed from here on
-        {
-            const int emit_t = getenv("RK_INDEX_EMIT_T") ? atoi(getenv("RK_INDEX_EMIT_T")) : 512;
-            const bool narrow = low_bits + gb <= 32;  // (hash_low, genome) fits 32 bits
+        if (!tiles_mode && inv && !rl_tab.p) {   // (second attempt: the renumbering ran for tile records, without the table)
+            RK_HIP(ctx, rl_tab.alloc(N));
+            hipLaunchKernelGGL(k_emit_table, dim3(blocks_for(N)), dim3(kThreads), 0, st, inv, idx->d_src_off, N, rl_tab.p);
+        }
+        const int emit_t = getenv("RK_INDEX_EMIT_T") ? atoi(getenv("RK_INDEX_EMIT_T")) : 512;
+        const bool narrow = low_bits + gb <= 32;  // (hash_low, genome) fits 32 bits
+        TileSortArgs ta;
+        memset(&ta, 0, sizeof ta);
+        if (tiles_mode) {
+            TileEmitArgs ea;
+            ea.keys = keys.p;
+            ea.bstart = bstart.p;
+            ea.inv = inv;
+            ea.low_bits = low_bits;
+            ea.gb = gb;
+            ea.rb = 0;
+            ea.nb = fa.nb;
+            ea.postings = idx->d_postings;
+            ea.tmp_uhash = tmp_uhash.p;
+            ea.tmp_uhash64 = wide ? tmp_uhash64.p : nullptr;
+            ea.tmp_upos = tmp_upos.p;
+            ea.ucount = ucount.p;
+            ea.rec_key = rec_key.p;
+            ea.rec_val = rec_val.p;
+            ea.cur = reinterpret_cast<TileCursors *>(zeroed.p + z_tcur);
+            ea.region_cap = region_cap;
+            ea.tres = tres;
+            ea.xcd_map = fa.xcd_map;
+#define RK_EMIT(TT) do { if (narrow) hipLaunchKernelGGL((k_bucket_emit_tiles<TT, uint32_t>), dim3(fa.nb), dim3(TT), 0, st, ea); \
+                         else hipLaunchKernelGGL((k_bucket_emit_tiles<TT, unsigned long long>), dim3(fa.nb), dim3(TT), 0, st, ea); } while (0)
+            if (emit_t == 256) RK_EMIT(256);
+            else if (emit_t == 1024) RK_EMIT(1024);
+            else RK_EMIT(512);
+#undef RK_EMIT
+            ta.rec_key = rec_key.p;
+            ta.rec_val = rec_val.p;
+            ta.cur = ea.cur;
+            ta.region_cap = region_cap;
+            ta.n_blocks = n_blocks;
+            ta.bin_count = reinterpret_cast<uint32_t *>(zeroed.p + z_bins);
+            ta.bin_cursor = ta.bin_count + n_blocks + 1;
+            ta.bin_start = bins.p;
+            ta.bkey = bkey.p;
+            ta.bval = bval.p;
+            ta.blk_min = idx->d_blk_min;
+            ta.contrib = t_contrib.p;
+            ta.rows = t_rows.p;
+            ta.cols = t_cols.p;
+            ta.tb_base = tb.p;
+            ta.tb_cnt = tb.p + n_blocks;
+            ta.proto = proto.p;
+            ta.level_start = level_start.p;
+            ta.dir[0] = t_dir_j.p;
+            ta.dir[1] = t_dir_c.p;
+            ta.tres = tres;
+        } else {
+            EmitArgs ea;
+            ea.keys = keys.p;
+            ea.bstart = bstart.p;
+            ea.off_new = idx->d_src_off;
+            ea.inv = inv;
+            ea.tab = inv ? rl_tab.p : nullptr;
+            ea.low_bits = low_bits;
+            ea.gb = gb;
+            ea.rb = rb;
+            ea.nb = fa.nb;
+            ea.postings = idx->d_postings;
+            ea.tmp_uhash = tmp_uhash.p;
+            ea.tmp_uhash64 = wide ? tmp_uhash64.p : nullptr;
+            ea.tmp_upos = tmp_upos.p;
+            ea.ucount = ucount.p;
+            ea.self_raw = self_raw.p;
+            ea.res = fres;
+            ea.xcd_map = fa.xcd_map;
+            ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
+            if (ea.debug) {  // developer ablations leave stages out: whatever they do not write must still be harmless downstream
+                RK_HIP(ctx, hipMemsetAsync(ucount.p, 0, (size_t)fa.nb * 4, st));
+                RK_HIP(ctx, hipMemsetAsync(self_raw.p, 0, H * sizeof(uint2), st));
+                RK_HIP(ctx, hipMemsetAsync(tmp_upos.p, 0, H * 4, st));
+            }
 #define RK_EMIT(TT) do { if (narrow) hipLaunchKernelGGL((k_bucket_emit<TT, uint32_t>), dim3(fa.nb), dim3(TT), 0, st, ea); \
                          else hipLaunchKernelGGL((k_bucket_emit<TT, unsigned long long>), dim3(fa.nb), dim3(TT), 0, st, ea); } while (0)
             if (emit_t == 256) RK_EMIT(256);
@@ -1015,8 +1226,8 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             else RK_EMIT(512);
 #undef RK_EMIT
         }
-        // the list heads (scan + placement) and the rows (counts, scan, placement) both hang on the emission alone: the heads go
-        // to the second stream, the rows stay here
+        // the list heads (scan + placement) and the rows / tile records both hang on the emission alone: the heads go to the
+        // second stream, the rest stays here
         hipStream_t sh = st;
         if (forked) {
             RK_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
@@ -1034,16 +1245,66 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             RK_HIP(ctx, hipEventRecord(ctx->ev_join, sh));
             joined = false;
         }
-        hipLaunchKernelGGL(k_row_counts2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, n_open.p, n_cov.p);
-        hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, fres);
-        hipLaunchKernelGGL(k_row_place2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, idx->d_self_off,
-                           idx->d_self_split, idx->d_selfrange);
+        if (tiles_mode) {
+            const size_t hist_lds = (size_t)n_blocks * 4;
+            hipLaunchKernelGGL(k_trec_count, dim3(kRecRegions, kRecParts), dim3(512), hist_lds, st, ta);
+            hipLaunchKernelGGL(k_trec_starts, dim3(1), dim3(1024), 0, st, ta);
+            hipLaunchKernelGGL(k_trec_scatter, dim3(kRecRegions, kRecParts), dim3(512), hist_lds, st, ta);
+            if (2 * hist_lds > 48 * 1024)
+                RK_HIP(ctx, hipFuncSetAttribute((const void *)k_trec_rowsort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * hist_lds)));
+            hipLaunchKernelGGL(k_trec_rowsort, dim3(n_blocks), dim3(512), 2 * hist_lds, st, ta);
+            hipLaunchKernelGGL(k_tdir_scan, dim3(1), dim3(1024), 0, st, ta);
+            hipLaunchKernelGGL(k_tdir_place, dim3(n_blocks), dim3(256), 0, st, ta);
+        } else {
+            hipLaunchKernelGGL(k_row_counts2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, n_open.p, n_cov.p);
+            hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, fres);
+            hipLaunchKernelGGL(k_row_place2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, idx->d_self_off,
+                               idx->d_self_split, idx->d_selfrange);
+        }
         RK_HIP(ctx, hipGetLastError());
         RK_TRY(join());
-        RK_TRY(rk_read_back(ctx, &r, fres, sizeof(r), st));  // the one synchronisation of the build
-        if (ctx->sw_dist_debug) fprintf(stderr, "[rk] index build: fast path flags %llu (B %d, low bits %d, genome bits %d, position bits %d)\n", r.flags, B, low_bits, gb, rb);
-        if (r.flags == 0) built = true;
-        else r = BuildResult{0, 0, 0, 0, 0};  // a bucket beyond the LDS sort, or a hash outside the hash space: the general path decides
+        {   // the one synchronisation of the build: both result records in one read-back
+            struct { BuildResult r; TileResult t; } both;
+            static_assert(sizeof(BuildResult) % 8 == 0 && sizeof(both) == sizeof(BuildResult) + sizeof(TileResult), "the two records lie back to back");
+            RK_TRY(rk_read_back(ctx, &both, fres, sizeof(both), st));
+            r = both.r;
+            tr = both.t;
+        }
+        if (ctx->sw_dist_debug)
+            fprintf(stderr, "[rk] index build: fast path flags %llu (B %d, low bits %d, genome bits %d, position bits %d)%s\n", r.flags, B, low_bits, gb, rb,
+                    tiles_mode ? (tr.overflow ? ", tile records overflowed" : ", tile records") : "");
+        if (r.flags == 0 && !(tiles_mode && tr.overflow)) built = true;
+        else if (r.flags) {   // a bucket beyond the LDS sort, or a hash outside the hash space: the general path decides
+            fast_refused = true;
+            r = BuildResult{0, 0, 0, 0, 0};
+        }
+        if (built && tiles_mode) {
+            idx->d_tile_contrib = t_contrib.release();
+            idx->d_tile_rows = t_rows.release();
+            idx->d_tile_cols = t_cols.release();
+            idx->d_tile_dir[0] = t_dir_j.release();
+            idx->d_tile_dir[1] = t_dir_c.release();
+            idx->n_tile_slots = tr.n_slots;
+            idx->n_tiles = tr.n_tiles;
+            idx->n_tile_records = tr.n_records;
+            idx->tile_max_records = tr.max_records;
+            for (int m = 0; m < 2; m++)
+                for (int k = 0; k < kTileTable; k++) idx->tile_prefix[m][k] = tr.level_count[m][k];
+            idx->tiles_ready = true;
+            idx->tiles_from_build = true;
+            if (ctx->sw_dist_debug)
+                fprintf(stderr, "[rk] tiles from the build: %llu tiles, %llu records in %llu slots (capacity %llu), biggest tile %llu\n", tr.n_tiles, tr.n_records,
+                        tr.n_slots, (unsigned long long)rec_cap, tr.max_records);
+        }
+    }
+    if (!built) {   // (no tile records after all)
+        t_contrib.reset();
+        t_rows.reset();
+        t_cols.reset();
+        t_dir_j.reset();
+        t_dir_c.reset();
+        if (idx->d_blk_min) { rk_pool_free(ctx, idx->d_blk_min); idx->d_blk_min = nullptr; }
+        RK_TRY(alloc_slices());
     }
 
     RK_TRY(enqueue_renumbering());
@@ -1129,6 +1390,7 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     }
     idx->U = r.U;
     idx->n_self = r.n_self;
+    idx->slices_refused = no_self;
     idx->ref_sets = s->is_set || r.dups == 0;
     idx->built_fast = built;
     if (built) {   // (the same rule as rk_dist.hip self_uses_tiles, which counts the records itself for an index built the general way)
@@ -1244,11 +1506,12 @@ namespace {
 // genome order and every slice record must point inside the index (a corrupt record would index LDS out of range)
 __global__ void k_validate_blob(const uint32_t *postings, uint64_t H, const uint32_t *upos, uint64_t U, const uint32_t *orig,
                                 const uint2 *selfrange, uint64_t n_self, const uint64_t *self_off, const uint64_t *self_split,
-                                uint32_t n_ref, uint32_t *bad)
+                                uint32_t n_ref, const uint64_t *src_off, uint32_t *bad)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool ok = true;
     if (i < H) ok = ok && postings[i] < n_ref;
+    if (src_off && i < n_ref) ok = ok && src_off[i] <= src_off[i + 1] && src_off[i + 1] <= H && (i != 0 || src_off[0] == 0);
     if (i < U) ok = ok && upos[i] < upos[i + 1] && upos[i + 1] <= H;
     if (orig && i < n_ref) ok = ok && orig[i] < n_ref;
     if (selfrange) {
@@ -1268,10 +1531,10 @@ struct BlobHeader {
     uint64_t magic, bytes;
     uint64_t H, U, max_src_size, max_ref_size, min_ref_size, n_self;
     uint32_t n_ref, has_self, ref_sets, relabeled;
-    int32_t hash_bits, wide, pad_;
+    int32_t hash_bits, wide, has_src;   // has_src: the CSR offsets of the source sketches travel (an index built here: it can self join)
     uint64_t off_postings, off_uhash, off_upos, off_sizes, off_self, off_selfoff, off_src, off_split, off_orig;
 };
-constexpr uint64_t kBlobMagic = 0x36584449444b5352ULL;  // "RSKDIDX6"
+constexpr uint64_t kBlobMagic = 0x37584449444b5352ULL;  // "RSKDIDX7"
 inline uint64_t al256(uint64_t x) { return (x + 255) & ~255ULL; }
 
 // the layout this library produces for an index of these dimensions (derived arrays -- prefix directory, rank
@@ -1286,10 +1549,10 @@ void blob_layout(BlobHeader *h)
     h->off_sizes = p;    p = al256(p + ((uint64_t)h->n_ref + 1) * 4);
     h->off_self = h->off_selfoff = h->off_src = h->off_split = h->off_orig = 0;
     if (h->relabeled) { h->off_orig = p; p = al256(p + ((uint64_t)h->n_ref + 1) * 4); }
+    if (h->has_src) { h->off_src = p; p = al256(p + ((uint64_t)h->n_ref + 1) * 8); }
     if (h->has_self) {
         h->off_self = p;    p = al256(p + (h->n_self + 1) * sizeof(uint2));
         h->off_selfoff = p; p = al256(p + ((uint64_t)h->n_ref + 1) * 8);
-        h->off_src = p;     p = al256(p + ((uint64_t)h->n_ref + 1) * 8);
         h->off_split = p;   p = al256(p + ((uint64_t)h->n_ref + 1) * 8);
     }
     h->bytes = p;
@@ -1307,6 +1570,7 @@ void blob_header(const rk_index *idx, BlobHeader *h)
     h->n_self = idx->n_self;
     h->n_ref = idx->n_ref;
     h->has_self = idx->d_selfrange ? 1 : 0;
+    h->has_src = idx->d_src_off ? 1 : 0;
     h->ref_sets = idx->ref_sets ? 1 : 0;
     h->relabeled = idx->relabeled && idx->d_orig ? 1 : 0;
     h->hash_bits = idx->hash_bits;
@@ -1345,9 +1609,9 @@ int rk_index_pack_dev(const rk_index *idx, void *blob_dev, uint64_t blob_cap, vo
     if (h.has_self) {
         RK_HIP(ctx, hipMemcpyAsync(b + h.off_self, idx->d_selfrange, idx->n_self * sizeof(uint2), hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(b + h.off_selfoff, idx->d_self_off, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
-        RK_HIP(ctx, hipMemcpyAsync(b + h.off_src, idx->d_src_off, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(b + h.off_split, idx->d_self_split, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
     }
+    if (h.has_src) RK_HIP(ctx, hipMemcpyAsync(b + h.off_src, idx->d_src_off, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
     RK_HIP(ctx, hipStreamSynchronize(st));
     return RK_OK;
 }
@@ -1403,12 +1667,14 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
     if (h.has_self) {
         RK_TRY(pool_array(ctx, &idx->d_selfrange, idx->n_self + 1));
         RK_TRY(pool_array(ctx, &idx->d_self_off, (size_t)idx->n_ref + 1));
-        RK_TRY(pool_array(ctx, &idx->d_src_off, (size_t)idx->n_ref + 1));
         RK_TRY(pool_array(ctx, &idx->d_self_split, (size_t)idx->n_ref + 1));
         RK_HIP(ctx, hipMemcpyAsync(idx->d_selfrange, b + h.off_self, idx->n_self * sizeof(uint2), hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(idx->d_self_off, b + h.off_selfoff, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
-        RK_HIP(ctx, hipMemcpyAsync(idx->d_src_off, b + h.off_src, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
         RK_HIP(ctx, hipMemcpyAsync(idx->d_self_split, b + h.off_split, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
+    }
+    if (h.has_src) {   // (an index without slice records -- built with tile records -- still self joins: its tile records are rebuilt on first use)
+        RK_TRY(pool_array(ctx, &idx->d_src_off, (size_t)idx->n_ref + 1));
+        RK_HIP(ctx, hipMemcpyAsync(idx->d_src_off, b + h.off_src, ((uint64_t)idx->n_ref + 1) * 8, hipMemcpyDeviceToDevice, st));
     }
     {
         DevBuf<uint32_t> bad(ctx);
@@ -1418,7 +1684,7 @@ int rk_index_unpack_dev(rk_ctx *ctx, const void *blob_dev, uint64_t blob_bytes, 
         if (span)
             hipLaunchKernelGGL(k_validate_blob, dim3(blocks_for(span)), dim3(kThreads), 0, st, idx->d_postings, idx->H, idx->d_upos, idx->U,
                                idx->relabeled ? idx->d_orig : nullptr, idx->d_selfrange, idx->n_self, idx->d_self_off, idx->d_self_split,
-                               idx->n_ref, bad.p);
+                               idx->n_ref, idx->d_src_off, bad.p);
         RK_HIP(ctx, hipGetLastError());
         uint32_t b = 0;
         RK_TRY(rk_read_back(ctx, &b, bad.p, 4, st));  // synchronises: the copies above are complete

@@ -53,9 +53,11 @@ struct rk_ctx {
     int sw_dist_near = 1;   // RK_DIST_NEAR=0: the self join always with full counter rows (rk_dist_kernel)
     int sw_dist_near_uw = 0;    // RK_DIST_NEAR_UW=1|2|4: waves that share a unit of the near-window kernel (default: by the launch's size)
     int sw_dist_fb_skip = 1;   // RK_DIST_FB_SKIP=0: always launch the fallback pass of the near-window self join
-    int sw_dist_tiles = 2;      // RK_DIST_TILES: 0 never the tile kernel (rk_dist_tile.inc), 1 for every sparse self join over sets, 2 when the index is wide or joined repeatedly
-    int sw_dist_tiles_min_genomes = 4000, sw_dist_tiles_min_shard_rows = 12000;   // RK_DIST_TILES_MIN_GENOMES / _MIN_SHARD_ROWS: below, a repeatedly joined index stays on the near-window kernel
-    int sw_dist_tiles_after = 1; // RK_DIST_TILES_AFTER: unsharded self joins over one index after which the tile kernel takes over (a context that is not single-shot)
+    int sw_dist_tiles = 2;      // RK_DIST_TILES: 0 never the tile kernel (rk_dist_tile.inc), 1 for every sparse self join over sets, 2 by the index's size and shape (rk_dist.hip self_uses_tiles)
+    // RK_DIST_TILES_MIN_GENOMES: from this many genomes on rk_index_build emits tile records (not slice records) and the self join
+    // runs on the tile kernel from its first launch; _MIN_SHARD_ROWS: row shards smaller than this prefer the near-window kernel
+    // when the index HAS slice records (a tile costs the same whatever the shard)
+    int sw_dist_tiles_min_genomes = 4000, sw_dist_tiles_min_shard_rows = 12000;
     int sw_dist_near_min = 16;  // RK_DIST_NEAR_MIN: the near-window kernel is used when a reportable pair of the smallest sketch needs at least this count
     int sw_dist_debug = 0;  // RK_DIST_DEBUG=1: the bands of every self join on stderr
     int sw_dist_lds_kb = 0;  // RK_DIST_LDS_KB: plan as if a CU had this much LDS (tests: tiled bands at small sizes)
@@ -65,6 +67,8 @@ struct rk_ctx {
     int sw_index_fast = 1;     // RK_INDEX_FAST=0: always the general (device-wide radix sort) build
     int sw_index_relabel = 1;  // RK_INDEX_RELABEL=0: keep the caller's genome order inside the index
     int sw_index_no_self = 0;  // RK_INDEX_NO_SELF=1: build every index without slice records (as one of 2^31 postings and more is)
+    int sw_index_tiles = 2;    // RK_INDEX_TILES: 0 the fast build always emits slice records, 1 tile records whenever it can, 2 from RK_DIST_TILES_MIN_GENOMES genomes on
+    unsigned long long sw_tile_rec_cap = 0;   // RK_TILE_REC_CAP: capacity of the build's unsorted tile records (default H / 2 + 64 K; tests force the overflow)
 };
 constexpr size_t kPinnedBytes = 1 << 16;
 
@@ -197,7 +201,6 @@ struct rk_index {
     // 2 known empty, 3 known non-empty.  Guarded by lazy_mu.
     unsigned char fb_key[40] = {0};
     int fb_state = 0;
-    int self_joins = 0;              // sparse unsharded self joins launched over this index so far (guarded by lazy_mu): see self_uses_tiles
     void *fb_event = nullptr;        // hipEvent_t
     // Tile records of the self join over 32 x 32 tiles (rk_dist_tile.inc), built on first use: per tile (block b of rows,
     // block w >= b of columns) the (row mask, column mask) pairs of the posting lists that touch both blocks, sorted by tile
@@ -212,6 +215,9 @@ struct rk_index {
     unsigned long long tile_prefix[2][256] = {};     // (kTileTable entries each)     // [metric][k]: tiles with at least 2^(-k/8) records per smallest sketch
     uint64_t n_tiles = 0, n_tile_records = 0;
     bool tiles_ready = false;
+    bool tiles_from_build = false;   // the tile records came with rk_index_build (rk_index_tiles.inc), not from the lazy rk_tiles_build
+    bool slices_refused = false;     // built without slice records on purpose (2^31 postings and more, RK_INDEX_NO_SELF): none on first use either
+    bool tiles_unusable = false;     // rk_tiles_build found more records than its budget: the self join stays with the row kernels
     int spread_known = 0;            // 1: `spread` below is valid (rk_dist.hip self_uses_tiles)
     bool spread = false;             // many related lists span more than the 32-column window of rk_near_kernel
     std::mutex lazy_mu;              // serialises the lazy builders (prefix directory, rank bitmap, list records, sum of
@@ -241,6 +247,9 @@ int rk_prim_sort_hits(rk_ctx *ctx, const unsigned long long *keys, unsigned long
 // tile records of the self join over 32 x 32 tiles, built on first use and cached in the index (rk_tiles.hip)
 constexpr int kTileTable = 256;   // entries of rk_index::tile_prefix per metric
 int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t stream);
+// slice records of an index that was built without them (tile records instead), on first use: rk_near_kernel on small row
+// shards, dense reports (rk_index.hip)
+int rk_index_ensure_slices(rk_ctx *ctx, rk_index *idx, hipStream_t stream);
 // prefix directory into the sorted distinct hashes, built on first use (rk_index.hip)
 int rk_index_ensure_dir(rk_ctx *ctx, rk_index *idx, hipStream_t stream);
 // explicit queries (index_dist): lookup + counting + epilogue in one kernel (rk_distq.hip).  Enqueues on `stream`,

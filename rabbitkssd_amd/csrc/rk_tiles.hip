@@ -218,7 +218,7 @@ int tile_scan_u64(rk_ctx *ctx, unsigned long long *v, uint64_t n, unsigned long 
 int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(idx->lazy_mu);
-    if (idx->tiles_ready) return RK_OK;
+    if (idx->tiles_ready || idx->tiles_unusable) return RK_OK;
     const auto t_begin = std::chrono::steady_clock::now();
     const uint64_t H = idx->H, U = idx->U;
     const uint32_t n_blocks = (idx->n_ref + 31) / 32;
@@ -266,6 +266,19 @@ int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
         hipLaunchKernelGGL(k_widen_u32, nb(n_runs), dim3(tpb), 0, st, run_records.p, n_runs, run_at.p);
         RK_HIP(ctx, hipGetLastError());
         RK_TILE_TRY(tile_scan_u64(ctx, run_at.p, n_runs, &n_c, st));
+        // A list that touches B blocks of 32 ids writes B (B + 1) / 2 records: a few hundred hashes shared by thousands of scattered
+        // genomes are hundreds of millions of records (32 bytes each here, and the sort's scratch).  Beyond a multiple of the
+        // postings the tile kernel is the wrong tool: the index is marked, and the self join stays with the row kernels.
+        {
+            const char *env = getenv("RK_TILE_BUDGET");
+            const unsigned long long budget = env ? strtoull(env, nullptr, 10) : 4ULL * H + (1ULL << 22);
+            if (n_c > budget) {
+                idx->tiles_unusable = true;
+                if (ctx->sw_dist_debug) fprintf(stderr, "[rk] tiles: %llu records for %llu postings exceed the budget of %llu: not built\n", n_c, (unsigned long long)H, budget);
+                RK_HIP(ctx, hipStreamSynchronize(st));
+                return RK_OK;
+            }
+        }
         if (n_c) {
             DevBuf<unsigned long long> keys(ctx);
             DevBuf<uint2> vals(ctx);

@@ -32,6 +32,9 @@ def test_config2_alldist_10k_exact(ctx):
     names, h, off = synth.clade_sketches(10000, 1220, 28)
     idx = ctx.index_build(ctx.sketches_from_host(h, off), 28)
     assert (idx.total, idx.distinct, idx.sum_sq) == (12199994, 3153593, 90120058)
+    # (round 5) the tile records come with the build: the FIRST join over the index runs on the headline's kernel, and it is this
+    # launch -- metric 0, -D 0.05, 10,000 genomes -- that is compared with the oracle below
+    assert idx.products == 6 and ctx.dist_kernel_name(idx, None, 1, 0, 20, 0.05).startswith("rk_tile_kernel<512u")
     mine, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05)
     postings, counts = ok.index_build32(h, off, 28)
     assert np.array_equal(idx.export(want_counts=False)[0], postings)
@@ -39,6 +42,7 @@ def test_config2_alldist_10k_exact(ctx):
                               threads=CORES)
     assert len(want) == 45000          # 45 pairs per 10-strain clade
     check_hits(mine, want)
+    want_j = want
     # containment metric and a looser threshold on the same index
     want, _ = ok.index_dist32(counts, 28, postings, np.diff(off).astype(np.uint32), h, off, 1, 1, 20, 0.2,
                               threads=CORES)
@@ -53,6 +57,8 @@ def test_config2_alldist_10k_exact(ctx):
     merged = np.concatenate(parts)
     merged = merged[np.lexsort((merged["col"], merged["row"]))]
     full, _ = ctx.dist_rows(idx, None, 1, 0, 20, 0.05)
+    assert ctx.dist_kernel_name(idx, None, 1, 0, 20, 0.05).startswith("rk_tile_kernel<512u")
+    check_hits(full, want_j)
     assert merged.tobytes() == full.tobytes()
     # device-resident asynchronous entry point used by bench.py
     hits = torch.empty((1 << 17) * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
@@ -99,7 +105,7 @@ def test_config3_alldist_50k_exact(ctx):
     1/8 block-cyclic shard (what a GPU of the 8-GPU run computes)."""
     names, h, off = synth.clade_sketches(50000, 1220, 28)
     idx = ctx.index_build(ctx.sketches_from_host(h, off), 28)
-    assert idx.built_fast and ctx.dist_kernel_name(idx, None, 1, 0, 20, 0.05).startswith("rk_near_kernel<true, ")
+    assert idx.built_fast and idx.products == 6 and ctx.dist_kernel_name(idx, None, 1, 0, 20, 0.05).startswith("rk_tile_kernel<")
     postings, counts = ok.index_build32(h, off, 28)
     want, _ = ok.index_dist32(counts, 28, postings, np.diff(off).astype(np.uint32), h, off, 1, 0, 20, 0.05, threads=CORES)
     del counts
@@ -120,8 +126,8 @@ def test_config3_alldist_50k_exact(ctx):
     order = synth.genome_order(50000, "shuffled", seed=11)
     _, h2, off2 = synth.permute_genomes(names, h, off, order)
     idx2 = ctx.index_build(ctx.sketches_from_host(h2, off2), 28)
-    # (a fresh index: the near-window kernel, as for the sorted collection above; `idx` has been joined before and is on the tile kernel by now)
-    assert ctx.dist_kernel_name(idx2, None, 1, 0, 20, 0.05).startswith("rk_near_kernel<true, ")
+    # (a fresh index and one that has been joined several times take the same kernel: the choice follows size and shape)
+    assert ctx.dist_kernel_name(idx2, None, 1, 0, 20, 0.05) == ctx.dist_kernel_name(idx, None, 1, 0, 20, 0.05)
     assert ctx.dist_kernel_name(idx, None, 1, 0, 20, 0.05).startswith("rk_tile_kernel<")
     m2, _ = ctx.dist_rows(idx2, None, 1, 0, 20, 0.05)
     a, b = order[m2["row"].astype(np.int64)], order[m2["col"].astype(np.int64)]
@@ -141,12 +147,15 @@ def test_self_join_kernels_agree_at_full_size(monkeypatch):
     h = np.concatenate([h1, h2])
     off = np.concatenate([o1, o2[1:] + o1[-1]]).astype(np.uint64)
     monkeypatch.setenv("RK_DIST_TILES", "0")
+    monkeypatch.setenv("RK_INDEX_TILES", "0")   # (the build with slice records, as below 4,000 genomes)
     near = capi.Context(0)
+    monkeypatch.delenv("RK_INDEX_TILES")
     monkeypatch.setenv("RK_DIST_TILES", "1")
     tiles = capi.Context(0)
     monkeypatch.delenv("RK_DIST_TILES")
     idx_n = near.index_build(near.sketches_from_host(h, off), 28)
     idx_t = tiles.index_build(tiles.sketches_from_host(h, off), 28)
+    assert idx_n.products == 1 and idx_t.products == 6
     for metric, D in ((0, 0.05), (0, 0.12), (1, 0.03)):
         assert not near.dist_kernel_name(idx_n, None, 1, metric, 20, D).startswith("rk_tile_kernel")
         want = dev_hits(near, idx_n, 1, metric, 20, D, cap=1 << 22)

@@ -354,8 +354,9 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     monkeypatch.delenv("RK_DIST_TILES")
     auto = capi.Context(0)
     idx = c.index_build(c.sketches_from_host(h, off), 26)
-    assert c.dist_kernel_name(idx, None, 1, metric, 20, D) .startswith("rk_tile_kernel<")
+    assert c.dist_kernel_name(idx, None, 1, metric, 20, D).startswith("rk_tile_kernel")   # (asking changes nothing: the records are built by the first launch)
     assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+    assert c.dist_kernel_name(idx, None, 1, metric, 20, D).startswith("rk_tile_kernel<")
     other, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 1 - metric, 20, D * 0.5, threads=4)
     for srow in ("0", "1"):   # both variants of the kernel (masks through LDS / row masks as 64-bit scalars), whatever the launch would pick
         monkeypatch.setenv("RK_TILE_SROW", srow)
@@ -374,7 +375,7 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     # the default: the tile kernel for collections with clusters wider than the window of rk_near_kernel
     idx2 = auto.index_build(auto.sketches_from_host(h, off), 26)
     name = auto.dist_kernel_name(idx2, None, 1, metric, 20, D)
-    assert strains < 70 or name.startswith("rk_tile_kernel<")
+    assert strains < 70 or name.startswith("rk_tile_kernel")
     if strains == 10 and D < 0.1:
         assert name.startswith("rk_near_kernel")
     assert_hits_equal(auto.dist_rows(idx2, None, 1, metric, 20, D)[0], want)
@@ -383,8 +384,8 @@ def test_tile_self_join(monkeypatch, strains, n, m, D, metric, tiny):
     auto.close()
 
 
-@pytest.mark.parametrize("threads", ["256", "512", "1024"])
-def test_tile_kernel_heavy_tiles_move_their_planes_mid_tile(monkeypatch, threads):
+@pytest.mark.parametrize("threads,from_build", [("256", "0"), ("512", "1"), ("1024", "0"), ("256", "1")])
+def test_tile_kernel_heavy_tiles_move_their_planes_mid_tile(monkeypatch, threads, from_build):
     # 96 genomes (three blocks of 32) sharing up to 30,000 hashes: tiles of 30,000+ records, more than eleven bit planes
     # hold for a lane of a four-wave workgroup (2 half-waves x 4 waves x 1,984) -- the planes move to the LDS counts in the
     # middle of the tile (before the end-of-tile merge of the waves' planes adds the rest) -- and sketch sizes that leave
@@ -402,32 +403,37 @@ def test_tile_kernel_heavy_tiles_move_their_planes_mid_tile(monkeypatch, threads
     sizes = np.diff(off).astype(np.uint32)
     monkeypatch.setenv("RK_DIST_TILES", "1")
     monkeypatch.setenv("RK_TILE_THREADS", threads)
+    monkeypatch.setenv("RK_INDEX_TILES", from_build)   # the records from the build's bucket emission / from the postings, on first use
     c = capi.Context(0)
     idx = c.index_build(c.sketches_from_host(h, off), 26)
+    assert idx.products == (6 if from_build == "1" else 1)
     for metric, D in ((0, 0.2), (1, 0.02)):
         want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=8)
         assert len(want) > 500 and want["common"].max() > 25000
         for srow in ("false", "true"):   # both variants of the kernel: masks through LDS / row masks as 64-bit scalars
             monkeypatch.setenv("RK_TILE_SROW", "1" if srow == "true" else "0")
-            assert c.dist_kernel_name(idx, None, 1, metric, 20, D) == "rk_tile_kernel<%su, %s>" % (threads, srow)
             assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+            assert c.dist_kernel_name(idx, None, 1, metric, 20, D) == "rk_tile_kernel<%su, %s>" % (threads, srow)
     del idx
     c.close()
 
 
-def test_self_join_moves_to_the_tile_kernel_when_the_index_is_joined_again(monkeypatch):
-    # a context that is not single-shot (a resident index queried repeatedly): the first unsharded self join runs on
-    # rk_near_kernel, the following ones on the tile kernel (its records are built by the second); a row shard keeps the
-    # near-window kernel; a single-shot context (the command-line tool) never switches.  Same hits every time.
+def test_self_join_kernel_follows_size_and_shape_not_call_history(monkeypatch):
+    # (round 5) which kernel a self join takes is decided by the index's size / shape and the options, never by how often the
+    # index was joined before: below RK_DIST_TILES_MIN_GENOMES the build emits slice records and every join runs on
+    # rk_near_kernel; from there on the build emits TILE records and the first join already runs on rk_tile_kernel -- in a
+    # single-shot context (the command-line tool) too.  rk_dist_kernel_name changes nothing.  Same hits every time.
     names, h, off = synth.clade_sketches(2000, 600, 26, seed=91)
     postings, counts = ok.index_build32(h, off, 26)
     sizes = np.diff(off).astype(np.uint32)
     want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 0, 20, 0.05, threads=4)
-    c = capi.Context(0)   # (default switches: 2,000 genomes are below the size from which the move pays, 4,000)
+    c = capi.Context(0)   # (default switches: 2,000 genomes are below the size from which tile records pay, 4,000)
     idx = c.index_build(c.sketches_from_host(h, off), 26)
+    assert idx.products == 1
     for _ in range(3):
         assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.05).startswith("rk_near_kernel")
         assert_hits_equal(c.dist_rows(idx, None, 1, 0, 20, 0.05)[0], want)
+    assert idx.products == 1
     del idx
     c.close()
     monkeypatch.setenv("RK_DIST_TILES_MIN_GENOMES", "1000")
@@ -436,18 +442,93 @@ def test_self_join_moves_to_the_tile_kernel_when_the_index_is_joined_again(monke
         if single_shot:
             c.set_single_shot(True)
         idx = c.index_build(c.sketches_from_host(h, off), 26)
+        assert idx.products == 2 | 4 and idx.self_stats[3] > 0
+        p2, c2 = idx.export()
+        assert np.array_equal(p2, postings) and np.array_equal(c2, counts)
         seen = []
         for _ in range(3):
             seen.append(c.dist_kernel_name(idx, None, 1, 0, 20, 0.05).split("<")[0])
             assert_hits_equal(c.dist_rows(idx, None, 1, 0, 20, 0.05)[0], want)
-        assert seen == (["rk_near_kernel"] * 3 if single_shot else ["rk_near_kernel", "rk_tile_kernel", "rk_tile_kernel"]), seen
-        assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.05, row_first=1, row_step=4, row_block=32).startswith("rk_near_kernel")   # (a small shard)
+        assert seen == ["rk_tile_kernel"] * 3, seen
+        # a small row shard: the tile kernel as well while the index has no slice records ...
+        assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.05, row_first=1, row_step=4, row_block=32).startswith("rk_tile_kernel<")
+        parts = [c.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=r, row_step=4, row_block=32)[0] for r in range(4)]
+        merged = np.concatenate(parts)
+        assert_hits_equal(merged[np.lexsort((merged["col"], merged["row"]))], want)
+        # ... a dense report makes them on first use (every pair, counter rows), and small shards then prefer the near-window kernel
+        dense_want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 0, 20, 1.5, threads=4)
+        assert_hits_equal(c.dist_rows(idx, None, 1, 0, 20, 1.5)[0], dense_want)
+        assert idx.products == 1 | 2 | 4
+        assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.05, row_first=1, row_step=4, row_block=32).startswith("rk_near_kernel")
+        assert c.dist_kernel_name(idx, None, 1, 0, 20, 0.05).startswith("rk_tile_kernel<")
+        parts = [c.dist_rows(idx, None, 1, 0, 20, 0.05, row_first=r, row_step=4, row_block=32)[0] for r in range(4)]
+        merged = np.concatenate(parts)
+        assert_hits_equal(merged[np.lexsort((merged["col"], merged["row"]))], want)
         del idx
         c.close()
 
 
+@pytest.mark.parametrize("strains,n,m,tiny", [(10, 3000, 300, 0), (100, 3000, 200, 0), (1000, 3000, 120, 0), (10, 2500, 300, 2), (36, 1296, 500, 0)])
+def test_tile_records_from_the_build_equal_the_lazily_built_ones(monkeypatch, strains, n, m, tiny):
+    # RK_INDEX_TILES=1: the bucket emission writes tile records (rk_index_tiles.inc); RK_INDEX_TILES=0 + RK_DIST_TILES=1: slice
+    # records, and the tile records derived from the postings on the first join (rk_tiles.hip).  Same postings, same number of
+    # tile records, and for tight, loose and default thresholds and both metrics the oracle's hits from both.
+    names, h, off = synth.clade_sketches(n, m, 26, strains_per_clade=strains, seed=500 + strains, tiny=tiny)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    monkeypatch.setenv("RK_DIST_TILES", "1")
+    monkeypatch.setenv("RK_INDEX_TILES", "1")
+    a = capi.Context(0)
+    monkeypatch.setenv("RK_INDEX_TILES", "0")
+    b = capi.Context(0)
+    ia = a.index_build(a.sketches_from_host(h, off), 26)
+    ib = b.index_build(b.sketches_from_host(h, off), 26)
+    assert ia.products == 6 and ib.products == 1
+    pa, ca = ia.export()
+    assert np.array_equal(pa, postings) and np.array_equal(ca, counts)
+    assert np.array_equal(ia.order(), ib.order())
+    for metric, D in ((0, 0.05), (1, 0.05), (0, 0.3), (0, 1.0)):
+        want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=8)
+        assert a.dist_kernel_name(ia, None, 1, metric, 20, D).startswith("rk_tile_kernel<")
+        assert_hits_equal(a.dist_rows(ia, None, 1, metric, 20, D)[0], want)
+        assert_hits_equal(b.dist_rows(ib, None, 1, metric, 20, D)[0], want)
+    assert ib.products == 3 and ia.self_stats[3] == ib.self_stats[3]
+    del ia, ib
+    a.close()
+    b.close()
+
+
+def test_tile_records_that_do_not_fit_fall_back_to_slice_records(monkeypatch):
+    # the build's unsorted tile records have a fixed capacity (H / 2 + 64 K); a collection whose lists scatter over many blocks
+    # overflows it: the index is then built with slice records after all (RK_TILE_REC_CAP forces it), same results; and the
+    # lazy builder has a budget too (RK_TILE_BUDGET): beyond it the self join stays with the row kernels
+    names, h, off = synth.clade_sketches(2000, 300, 26, seed=17)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 0, 20, 0.05, threads=4)
+    monkeypatch.setenv("RK_INDEX_TILES", "1")
+    monkeypatch.setenv("RK_TILE_REC_CAP", "4096")
+    c = capi.Context(0)
+    idx = c.index_build(c.sketches_from_host(h, off), 26)
+    assert idx.products == 1 and idx.built_fast
+    p2, c2 = idx.export()
+    assert np.array_equal(p2, postings) and np.array_equal(c2, counts)
+    assert_hits_equal(c.dist_rows(idx, None, 1, 0, 20, 0.05)[0], want)
+    del idx
+    c.close()
+    monkeypatch.delenv("RK_TILE_REC_CAP")
+    monkeypatch.setenv("RK_INDEX_TILES", "0")
+    monkeypatch.setenv("RK_DIST_TILES", "1")
+    monkeypatch.setenv("RK_TILE_BUDGET", "1000")
+    c = capi.Context(0)
+    idx = c.index_build(c.sketches_from_host(h, off), 26)
+    assert_hits_equal(c.dist_rows(idx, None, 1, 0, 20, 0.05)[0], want)
+    assert idx.products == 1 and not c.dist_kernel_name(idx, None, 1, 0, 20, 0.05).startswith("rk_tile_kernel")
+    del idx
+    c.close()
+
+
 def test_self_join_moves_to_the_tile_kernel_after_a_fallback(monkeypatch):
-    monkeypatch.setenv("RK_DIST_TILES_AFTER", "1000000")   # (not the switch of a repeatedly joined index: the one after a fallback)
     # default switches: clades of 36 -- only the first three rows of a clade have relatives beyond the near-window kernel's 32
     # columns, so few slice records are wide ones (8 %: the index does not count as one with wide clusters) -- yet those rows
     # fall back.  The first launches run on rk_near_kernel with its exact fallback; once a completed launch has shown the
@@ -486,8 +567,9 @@ def test_index_without_slice_records(monkeypatch):
     assert idx.self_stats[0] == 0
     for metric, D in ((0, 0.05), (1, 0.08)):
         want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=4)
-        assert c.dist_kernel_name(idx, None, 1, metric, 20, D).startswith("rk_tile_kernel<")
+        assert c.dist_kernel_name(idx, None, 1, metric, 20, D).startswith("rk_tile_kernel")
         assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+        assert c.dist_kernel_name(idx, None, 1, metric, 20, D).startswith("rk_tile_kernel<")
     with pytest.raises(Exception, match="no slice records"):
         c.dist_rows(idx, None, 1, 0, 20, 1.5)
     q = c.sketches_from_host(h[: int(off[100])], off[:101])
