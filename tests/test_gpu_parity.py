@@ -486,7 +486,7 @@ def test_tile_records_from_the_build_equal_the_lazily_built_ones(monkeypatch, st
     assert ia.products == 6 and ib.products == 1
     pa, ca = ia.export()
     assert np.array_equal(pa, postings) and np.array_equal(ca, counts)
-    assert np.array_equal(ia.order(), ib.order())
+    assert np.array_equal(ia.order, ib.order)
     for metric, D in ((0, 0.05), (1, 0.05), (0, 0.3), (0, 1.0)):
         want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=8)
         assert a.dist_kernel_name(ia, None, 1, metric, 20, D).startswith("rk_tile_kernel<")
