@@ -277,6 +277,7 @@ void rk_ctx_destroy(rk_ctx *ctx)
         if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+        if (ctx->ev_inv) (void)hipEventDestroy(ctx->ev_inv);
     }
     rk_ctx_trim(ctx);
     // blocks still handed out belong to objects the caller has not freed: they are released with the context

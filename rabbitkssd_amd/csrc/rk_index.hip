@@ -930,15 +930,24 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     const bool two_streams = relabel && !getenv("RK_INDEX_ONE_STREAM");
     if (two_streams) {
         if (!ctx->stream2) {
-            RK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            {   // (its kernels are small and many: at the highest priority they are not queued behind the partition's workgroups)
+                int prio_lo = 0, prio_hi = 0;
+                const bool hi = !getenv("RK_INDEX_STREAM2_PRIO") || atoi(getenv("RK_INDEX_STREAM2_PRIO")) != 0;
+                if (hi && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess && prio_hi != prio_lo)
+                    RK_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_hi));
+                else
+                    RK_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            }
             RK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
             RK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            RK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_inv, hipEventDisableTiming));
         }
         RK_HIP(ctx, hipEventRecord(ctx->ev_fork, st));          // (everything enqueued on ctx->stream so far comes first)
     }
     // The launches of the renumbering are ENQUEUED after the partition's (the fast path calls this once its own first
     // kernels are in the queue): the host needs ~5 us per launch, and with the renumbering's ten launches in front the
     // partition started 70 us late.
+    bool inv_recorded = false;   // ctx->ev_inv was recorded behind the kernel that completes `inv`
     bool renumbering_enqueued = false, want_tab = false;   // want_tab: the fast path is taken (H < 2^30) and wants k_emit_table's table
     auto enqueue_renumbering = [&]() -> int {
       if (renumbering_enqueued) return RK_OK;
@@ -971,6 +980,10 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             hipLaunchKernelGGL(k_cluster_keys32, dim3(nb_n), dim3(kThreads), 0, s2, rl_parent.p, N, id_bits, rl_keys32.p, rl_rank.p);
             hipLaunchKernelGGL(k_rank_keys, dim3((N + kRankQ - 1) / kRankQ, (N + kRankStretch - 1) / kRankStretch), dim3(kRankThreads), 0, s2,
                                rl_keys32.p, N, rl_rank.p);
+            if (forked) {   // (a genome's rank among the keys IS its internal id: all the bucket emission of tile records needs)
+                RK_HIP(ctx, hipEventRecord(ctx->ev_inv, s2));
+                inv_recorded = true;
+            }
             hipLaunchKernelGGL(k_order_from_rank, dim3(nb_n), dim3(kThreads), 0, s2, rl_rank.p, N, s->d_off, idx->d_orig, idx->d_sizes);
             hipLaunchKernelGGL(k_offsets_scan, dim3(1), dim3(1024), 0, s2, idx->d_sizes, N, idx->d_src_off);
             inv = rl_rank.p;   // (a genome's rank among the keys IS its internal id)
@@ -1049,8 +1062,8 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         DevBuf<unsigned long long> keys(ctx), tmp_uhash64(ctx), zeroed(ctx);
         DevBuf<uint2> self_raw(ctx);
         // tile records: unsorted (64 regions), binned by row block, the directory's proto entries
-        DevBuf<uint32_t> rec_key(ctx), bkey(ctx), bins(ctx), tb(ctx);
-        DevBuf<uint2> rec_val(ctx), bval(ctx);
+        DevBuf<uint32_t> bins(ctx), tb(ctx);
+        DevBuf<uint3> rec(ctx), brec(ctx);
         DevBuf<uint4> proto(ctx);
         DevBuf<unsigned long long> level_start(ctx);
         const bool wide = idx->wide;
@@ -1073,10 +1086,8 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             rec_cap = (uint64_t)region_cap * kRecRegions;
             tile_cap = std::min<uint64_t>(rec_cap, (uint64_t)n_blocks * (n_blocks + 1) / 2);
             slot_cap = rec_cap + tile_cap;   // (every tile from an even slot on)
-            RK_HIP(ctx, rec_key.alloc(rec_cap));
-            RK_HIP(ctx, rec_val.alloc(rec_cap));
-            RK_HIP(ctx, bkey.alloc(rec_cap));
-            RK_HIP(ctx, bval.alloc(rec_cap));
+            RK_HIP(ctx, rec.alloc(rec_cap));
+            RK_HIP(ctx, brec.alloc(rec_cap));
             RK_HIP(ctx, tb.alloc(2 * (size_t)n_blocks));
             RK_HIP(ctx, bins.alloc((size_t)n_blocks + 1));   // bin starts (the counts and cursors are in `zeroed`)
             RK_HIP(ctx, proto.alloc(2 * tile_cap));
@@ -1138,7 +1149,10 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         }
         want_tab = !tiles_mode;
         RK_TRY(enqueue_renumbering());   // (behind the partition's launches in the host's queue, beside them on the device)
-        RK_TRY(join());   // the internal order (inv, the offsets in internal order) is needed from here on
+        // the internal order is needed from here on: the translation table alone for tile records (sizes and offsets in internal
+        // order are still on their way on the second stream: joined in front of the row sort), everything for slice records
+        if (tiles_mode && inv_recorded && !joined) RK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_inv, 0));
+        else RK_TRY(join());
         if (!tiles_mode && inv && !rl_tab.p) {   // (second attempt: the renumbering ran for tile records, without the table)
             RK_HIP(ctx, rl_tab.alloc(N));
             hipLaunchKernelGGL(k_emit_table, dim3(blocks_for(N)), dim3(kThreads), 0, st, inv, idx->d_src_off, N, rl_tab.p);
@@ -1161,28 +1175,30 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             ea.tmp_uhash64 = wide ? tmp_uhash64.p : nullptr;
             ea.tmp_upos = tmp_upos.p;
             ea.ucount = ucount.p;
-            ea.rec_key = rec_key.p;
-            ea.rec_val = rec_val.p;
+            ea.rec = rec.p;
             ea.cur = reinterpret_cast<TileCursors *>(zeroed.p + z_tcur);
             ea.region_cap = region_cap;
             ea.tres = tres;
             ea.xcd_map = fa.xcd_map;
+            ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
+            if (ea.debug) {  // developer ablations leave stages out: whatever they do not write must still be harmless downstream
+                RK_HIP(ctx, hipMemsetAsync(ucount.p, 0, (size_t)fa.nb * 4, st));
+                RK_HIP(ctx, hipMemsetAsync(tmp_upos.p, 0, H * 4, st));
+            }
 #define RK_EMIT(TT) do { if (narrow) hipLaunchKernelGGL((k_bucket_emit_tiles<TT, uint32_t>), dim3(fa.nb), dim3(TT), 0, st, ea); \
                          else hipLaunchKernelGGL((k_bucket_emit_tiles<TT, unsigned long long>), dim3(fa.nb), dim3(TT), 0, st, ea); } while (0)
             if (emit_t == 256) RK_EMIT(256);
             else if (emit_t == 1024) RK_EMIT(1024);
             else RK_EMIT(512);
 #undef RK_EMIT
-            ta.rec_key = rec_key.p;
-            ta.rec_val = rec_val.p;
+            ta.rec = rec.p;
             ta.cur = ea.cur;
             ta.region_cap = region_cap;
             ta.n_blocks = n_blocks;
             ta.bin_count = reinterpret_cast<uint32_t *>(zeroed.p + z_bins);
             ta.bin_cursor = ta.bin_count + n_blocks + 1;
             ta.bin_start = bins.p;
-            ta.bkey = bkey.p;
-            ta.bval = bval.p;
+            ta.brec = brec.p;
             ta.blk_min = idx->d_blk_min;
             ta.contrib = t_contrib.p;
             ta.rows = t_rows.p;
@@ -1250,9 +1266,9 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             hipLaunchKernelGGL(k_trec_count, dim3(kRecRegions, kRecParts), dim3(512), hist_lds, st, ta);
             hipLaunchKernelGGL(k_trec_starts, dim3(1), dim3(1024), 0, st, ta);
             hipLaunchKernelGGL(k_trec_scatter, dim3(kRecRegions, kRecParts), dim3(512), hist_lds, st, ta);
-            if (2 * hist_lds > 48 * 1024)
-                RK_HIP(ctx, hipFuncSetAttribute((const void *)k_trec_rowsort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * hist_lds)));
-            hipLaunchKernelGGL(k_trec_rowsort, dim3(n_blocks), dim3(512), 2 * hist_lds, st, ta);
+            RK_TRY(join());   // (the blocks' smallest sketches come from the second stream; by now also the list heads)
+            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_trec_rowsort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowsort_lds(n_blocks)));
+            hipLaunchKernelGGL(k_trec_rowsort, dim3(n_blocks), dim3(512), rowsort_lds(n_blocks), st, ta);
             hipLaunchKernelGGL(k_tdir_scan, dim3(1), dim3(1024), 0, st, ta);
             hipLaunchKernelGGL(k_tdir_place, dim3(n_blocks), dim3(256), 0, st, ta);
         } else {

@@ -25,7 +25,7 @@ struct rk_ctx {
     // a second stream + two events (created on first use): rk_index_build computes the internal genome order there while
     // the partition of the hashes runs on `stream`
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_inv = nullptr;   // ev_inv: the genome translation table of the renumbering is ready (the rest of it -- sizes, offsets -- is not needed by the bucket emission of tile records)
     void *pinned = nullptr;  // page-locked scratch for small read-backs / uploads (grow-only, see rk_pinned_scratch)
     size_t pinned_bytes = 0;
     // caching device allocator: hipMalloc / hipFree cost 50-300 us each (hipFree also synchronises the device) and the

@@ -19,18 +19,8 @@ tiles)
   done ;;
 trace)
   n=${2:-10000}
-  cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r5_trace_$n -o t -- python3 $GRAFT_REPO_ROOT/tools/prof_driver.py index $n 8 > $GRAFT_REPO_ROOT/gpurun_out/r5_trace_$n.log 2>&1
-  cd $GRAFT_REPO_ROOT
-  tail -12 gpurun_out/r5_trace_$n.log
-  f=$(find gpurun_out/r5_trace_$n -name '*kernel_stats.csv' | head -1)
-  [ -n "$f" ] && python3 - "$f" <<'PY'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-for r in rows[:40]:
-    print("%-70s calls %5s  avg %9.1f us  total %9.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e3))
-PY
-  ;;
+  bash tools/kernel_trace.sh r5_trace_$n index $n 8 || exit 1
+  python3 tools/index_timeline.py gpurun_out/r5_trace_$n 4 ;;
 all)
   T=1150 LINES_SHOWN=40 tests "" ;;
 *) echo "usage: $0 tiles|trace|all"; exit 2 ;;

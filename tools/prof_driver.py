@@ -114,6 +114,20 @@ def dist_rq_dev(n_ref=100000, n_query=1000, steps=5, m_ref=76, m_query=45776, bi
                                                                          int(counters[0].item())))
 
 
+def index_only(n_genomes=10000, reps=5):
+    """rk_index_build alone (profiler runs, developer ablations that leave the index unusable)"""
+    ctx = capi.Context(0)
+    names, hashes, off = synth.clade_sketches(n_genomes, 1220, 28)
+    sk = ctx.sketches_from_host(hashes, off)
+    for r in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        idx = ctx.index_build(sk, 28)
+        dt = time.time() - t0
+        print("index build %d: %.3f ms (H=%d U=%d fast=%d products=%d)" % (r, dt * 1e3, idx.total, idx.distinct, idx.built_fast, idx.products))
+        del idx
+
+
 def index(n_genomes=10000, reps=5):
     """rk_index_build wall time, first call (cold pool) and steady state"""
     ctx = capi.Context(0)
@@ -155,4 +169,4 @@ def calib(mbytes=1024, width=16):
 if __name__ == "__main__":
     which = sys.argv[1]
     args = [int(x) for x in sys.argv[2:]]
-    {"sketch": sketch, "dist": dist, "dist_rq": dist_rq, "dist_rq_dev": dist_rq_dev, "index": index, "calib": calib}[which](*args)
+    {"sketch": sketch, "dist": dist, "dist_rq": dist_rq, "dist_rq_dev": dist_rq_dev, "index": index, "index_only": index_only, "calib": calib}[which](*args)
