@@ -76,6 +76,11 @@ def parse_args():
     ap.add_argument("--sketch-genomes", type=int, default=1000, help="BASELINE configs[1]: 1,000 x 5 Mb")
     ap.add_argument("--sketch-length", type=int, default=5_000_000)
     ap.add_argument("--config3-genomes", type=int, default=50000)
+    ap.add_argument("--bare-sketch", action="store_true",
+                    help="also time the reference from a bare .sketch: its own transSketches (src/sketch.cpp:894-1021, ~80 s at 10,000 "
+                         "genomes) + alldist; without it the figure of BASELINE.md (8-vCPU container) stands in, labelled as such")
+    ap.add_argument("--no-scale", action="store_true", help="skip the large-collection leg (scale)")
+    ap.add_argument("--scale-genomes", type=int, default=500000)
     return ap.parse_args()
 
 
@@ -114,6 +119,10 @@ class Env:
             else:
                 dist.init_process_group(args.backend, rank=self.rank, world_size=self.world, timeout=shard.init_timeout())
         self.ctx = capi.Context(self.local_rank)
+        # the device's stream-read rate, measured in this very run, stated next to the nominal 8 TB/s (a 2 GiB buffer:
+        # eight times the 256 MB Infinity Cache, 16 bytes per lane, HIP events around five launches)
+        self.peak_measured = self.ctx.stream_read_gbs(2048, 5) if self.rank == 0 else None
+        self.ctx.trim()
         self.dev = torch.device("cuda", self.local_rank)
         # a stream of our own: torch.cuda.Event measures the stream it is recorded on
         self.stream = torch.cuda.Stream(device=self.dev)
@@ -263,6 +272,30 @@ def canonical_pairs(hits_tensor, n, capi, order=None):
     return np.stack([lo[key], hi[key], h["common"][key].astype(np.int64)])
 
 
+def threshold_legs(env, index, n_pairs, steps=20):
+    """the same resident index under looser thresholds: the tile kernel is output-sensitive -- it only starts the tiles that can
+    hold a reportable pair -- so its pairs/s is an EFFECTIVE rate that falls as -D admits more of the matrix (-D 1.0: alldist's
+    default, every pair that shares a hash)"""
+    from rabbitkssd_amd import capi, shard
+    torch, ctx = env.torch, env.ctx
+    out = {}
+    hits_cap = 1 << 22
+    hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=env.dev)
+    for D in (MAX_DIST, 0.3, 1.0):
+        counters = torch.zeros(counter_slots(steps, 2), dtype=torch.int64, device=env.dev)
+
+        def launch(i, D=D, counters=counters):
+            ctx.dist_rows_dev(index, 1, 0, KMER, D, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i,
+                              stream=env.stream.cuda_stream, row_block=shard.ROW_BLOCK)
+        _, ms, _ = timed_steps(env, launch, steps, 2)
+        ts = index.tile_stats(1, 0, KMER, D)
+        out["D%g" % D] = {"max_dist": D, "kernel": ctx.dist_kernel_name(index, None, 1, 0, KMER, D), "kernel_ms": ms,
+                          "hits": int(counters[2 + steps - 1].item()), "effective_pairs_per_s": n_pairs / (ms * 1e-3),
+                          "tiles_started": ts[1], "tiles_with_records": ts[0],
+                          "cells_formed_share": min(1.0, ts[1] * 1024.0 / n_pairs) if n_pairs else None}
+    return out
+
+
 def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted", build_reps=0, strains=10, tiny=0):
     """alldist over n_genomes synthetic sketches, this rank's block-cyclic row shard; rank 0 returns the report.
     order_mode: the order the collection is listed in ("sorted" as generated, "shuffled", "jitter": synth.genome_order);
@@ -315,12 +348,7 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
                       stream=env.stream.cuda_stream, row_block=shard.ROW_BLOCK)
     env.stream.synchronize()
     t_first = time.perf_counter() - t0
-    # ... and the second: an index that is joined again gets its tile records now (a context that is not single-shot)
-    t0 = time.perf_counter()
-    ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, first.data_ptr(), row_first=rank, row_step=world,
-                      stream=env.stream.cuda_stream, row_block=shard.ROW_BLOCK)
-    env.stream.synchronize()
-    t_second = time.perf_counter() - t0
+    products = index.products   # 1 slice records, 2 tile records, 4 the tile records came with the build (rk_index_products)
     elapsed, kernel_ms, spread = timed_steps(env, launch, steps, warmup)
     # cold steps: other options in between make the library forget what it learned about this (index, options) pair -- here
     # that rk_near_kernel's fallback list is empty --, so every launch of this stretch is a first one (two option sets taking turns)
@@ -373,12 +401,16 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
     # (counts stay in LDS; compact records carry their posting list)
     b_stream = 8.0 * stats[2] / world + 40.0 * my_hits
     tile_records = None
+    tile_stats = None
     if kernel.startswith("rk_tile_kernel"):
         # the tile kernel's stream: its 8-byte tile records (one per posting list and pair of 32-genome blocks) + 40 B per hit
         tile_records = int(index.self_stats[3])
         b_stream = 8.0 * tile_records + 40.0 * my_hits
+        ts = index.tile_stats(1, 0, KMER, MAX_DIST)
+        tile_stats = {"tiles_with_records": ts[0], "tiles_started": ts[1], "tile_records": ts[2],
+                      "cells_formed_share": min(1.0, ts[1] * 1024.0 / n_pairs)}
     return {
-        "tile_records": tile_records,
+        "tile_records": tile_records, "tile_stats": tile_stats, "index_products": products,
         "value": n_pairs * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "genomes": n_genomes, "pairs": n_pairs,
         "hashes": int(H), "postings_streamed_T": int(T), "hits": int(tot_hits), "steps": steps, "warmup": warmup,
         "kernel": kernel, "kernel_ms": kernel_ms, "kernel_ms_min_median_max": spread,
@@ -389,7 +421,7 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
         "e2e_ms": t_bcast * 1e3 + elapsed / steps * 1e3 + gather_ms,
         "slice_records": stats[0], "compact_share": (stats[1] / stats[0]) if stats[0] else None, "records_walked": stats[2],
         "build_plus_dist_ms": t_bd * 1e3 if t_bd else None, "pairs_canonical": pairs, "order": order_mode,
-        "first_call_ms": t_first * 1e3, "second_call_ms": t_second * 1e3, "kernel_ms_cold": kernel_ms_cold,
+        "first_call_ms": t_first * 1e3, "kernel_ms_cold": kernel_ms_cold,
     }
 
 
@@ -534,11 +566,19 @@ def sketch_block(env, n_genomes, length, steps=5, pmc_file=None, cpu=True):
                                    "conflicts) per wave and 1,024 bases, 8 waves per SIMD; the waves are alive 75 % of the kernel's time "
                                    "(uneven pace of the XCDs in the second half of a pass; profiles/r03_pmc_summary.csv, DESIGN.md 4.1)"}}
     pmc = load_pmc(sk_kernel, pmc_file) if pmc_file else None
+    roof = out["roofline"]
+    roof["peak_measured"] = env.peak_measured
+    roof["algorithmic"] = hbm_block(b_alg, kernel_ms * 1e-3, env.peak_measured, "SURVEY 8d: 1.001 B per k-mer window", working_set=b_alg)
     if pmc and pmc.get("hbm_bytes_per_launch"):
-        out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-        out["roofline"]["hbm_frac"] = pmc["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["traffic"] = pmc["hbm_bytes_per_launch"]
+        roof["hbm"] = hbm_block(pmc["hbm_bytes_per_launch"], kernel_ms * 1e-3, env.peak_measured,
+                                "HBM counters (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, profiles/)", working_set=b_alg)
+        roof["hbm_frac"] = roof["hbm"]["frac"]
         if pmc.get("SQ_ACTIVE_INST_VALU"):
-            out["roofline"]["issue_frac"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / ENGINE_CLOCK_HZ / (kernel_ms * 1e-3)
+            roof["issue_frac"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / ENGINE_CLOCK_HZ / (kernel_ms * 1e-3)
+            # what binds the scan kernel is vector issue (+ its LDS probes): `bound` / `frac` say that, the byte model stays beside it
+            roof.update({"bound": "valu_issue", "achieved": roof["issue_frac"] * N_SIMD * ENGINE_CLOCK_HZ, "peak": N_SIMD * ENGINE_CLOCK_HZ,
+                         "unit": "SIMD issue cycles/s", "frac": roof["issue_frac"], "algorithmic_frac": achieved / HBM_PEAK_GBS})
     if cpu and not env.args.no_cpu_baseline:
         out["cpu_baseline"] = sketch_cpu_reference(packed, stride, length, n_genomes) or \
             sketch_cpu_baseline(packed, stride, length, n_genomes, table)
@@ -703,21 +743,58 @@ ENGINE_CLOCK_HZ = 2.4e9   # MI355X peak engine clock (MI355X_MICROARCH.md)
 N_SIMD = 1024             # 256 CUs x 4 SIMDs
 
 
-def apply_pmc(roof, pmc):
-    """fills achieved / frac / traffic (HBM bytes the counters saw) and issue_frac (cycles the SIMDs spent issuing vector
-    instructions: SQ_ACTIVE_INST_VALU x 4 cycles / 1,024 SIMDs, over the kernel's duration) of a roofline block"""
+INFINITY_CACHE_BYTES = 256 << 20   # MI355X_MICROARCH.md: 256 MB memory-side cache in front of HBM
+ISSUE_PEAK = N_SIMD * ENGINE_CLOCK_HZ   # SIMD cycles per second: a SIMD issues one vector instruction per 4 cycles of a wave
+
+
+def hbm_block(bytes_per_launch, secs, peak_measured, source, working_set=None):
+    """the HBM side of a roofline block: GB/s moved against the nominal and the MEASURED peak"""
+    gbs = bytes_per_launch / secs / 1e9
+    blk = {"achieved": gbs, "peak": HBM_PEAK_GBS, "peak_measured": peak_measured, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "frac_of_measured": (gbs / peak_measured) if peak_measured else None, "bytes_per_launch": bytes_per_launch, "from": source}
+    if working_set is not None:
+        blk["working_set_bytes"] = working_set
+        if working_set < INFINITY_CACHE_BYTES:
+            blk["note"] = ("the launch's working set (%.0f MB) is re-read every step and fits the 256 MB Infinity Cache: the counters "
+                           "count fabric requests, not DRAM accesses" % (working_set / 1e6))
+    return blk
+
+
+def apply_pmc(roof, pmc, peak_measured=None, issue_bound=False, working_set=None):
+    """fills traffic (HBM bytes the counters saw), the `hbm` side block and issue_frac (cycles the SIMDs spent issuing vector
+    instructions: SQ_ACTIVE_INST_VALU x 4 cycles / 1,024 SIMDs, over the kernel's duration) of a roofline block.  issue_bound:
+    the kernel is bound by vector issue (tile / near-window / scan kernels): `bound`, `achieved`, `peak`, `frac` then say THAT --
+    busy SIMD cycles per second against 1,024 SIMDs x 2.4 GHz -- and the HBM fraction stays beside it as hbm_frac."""
     if not pmc or not pmc.get("hbm_bytes_per_launch"):
         return
     secs = roof["kernel_ms"] * 1e-3
     roof["traffic"] = pmc["hbm_bytes_per_launch"]
-    roof["achieved"] = pmc["hbm_bytes_per_launch"] / secs / 1e9
-    roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-    roof["achieved_from"] = "HBM counters (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, profiles/)"
+    roof["hbm"] = hbm_block(pmc["hbm_bytes_per_launch"], secs, peak_measured,
+                            "HBM counters (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, profiles/)", working_set)
+    roof["hbm_frac"] = roof["hbm"]["frac"]
     if pmc.get("SQ_ACTIVE_INST_VALU"):
-        roof["issue_frac"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMD / ENGINE_CLOCK_HZ / secs
+        roof["issue_frac"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / ISSUE_PEAK / secs
+    if issue_bound and roof.get("issue_frac"):
+        roof.update({"bound": "valu_issue", "achieved": roof["issue_frac"] * ISSUE_PEAK, "peak": ISSUE_PEAK, "unit": "SIMD issue cycles/s",
+                     "frac": roof["issue_frac"],
+                     "achieved_from": "SQ_ACTIVE_INST_VALU x 4 cycles (profiles/) over the kernel's duration measured in this run"})
+    else:
+        roof.update({"bound": "hbm", "achieved": roof["hbm"]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": roof["hbm"]["frac"],
+                     "achieved_from": roof["hbm"]["from"]})
+    roof["peak_measured"] = peak_measured
 
 
-def alldist_cpu_and_cli(keep, n_pairs):
+def cli_stamps(stderr_text):
+    """the tool's own clock (RK_TIMING=1: `[timing]  12.345 ms  what`) as a table of phase durations"""
+    marks = [(float(m.group(1)), m.group(2).strip()) for m in re.finditer(r"\[timing\]\s+([0-9.]+) ms\s+(.*)", stderr_text)]
+    out, prev = {}, 0.0
+    for t, what in marks:
+        out[what] = t - prev
+        prev = t
+    return out
+
+
+def alldist_cpu_and_cli(keep, n_pairs, bare_sketch=False):
     """the reference's index_tridist on the same sketches on this box's host cores, and -- on the very same files --
     the product's `rabbit_kssd alldist` command line (wall clock incl. process + HIP start-up)"""
     from oracle import oracle as ok
@@ -755,24 +832,42 @@ def alldist_cpu_and_cli(keep, n_pairs):
                        "wall_s": wall, "wall_pairs_per_s": n_pairs / wall, "hits": lines}
         # the product's command line on the same .sketch (the .dict/.index pair exists, so nothing is rewritten)
         if os.path.exists(TOOL):
-            walls = []
-            for _ in range(3):
+            walls, stamps = [], []
+            for _ in range(5):
                 t0 = time.time()
                 p = subprocess.run([TOOL, "alldist", "-i", sk, "-D", str(MAX_DIST), "-o", "gpu.out", "-t", str(min(cores, 16))],
-                                   cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                                   cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, RK_TIMING="1"))
                 walls.append(time.time() - t0)
+                stamps.append(cli_stamps(p.stderr.decode(errors="replace")))
                 if p.returncode != 0:
                     walls = []
                     break
             if walls:
                 lines = sum(1 for _ in open(os.path.join(tmp, "gpu.out"))) - 1
-                med = sorted(walls)[len(walls) // 2]
+                mid = sorted(range(len(walls)), key=lambda i: walls[i])[len(walls) // 2]
+                med = walls[mid]
                 cli = {"cli_wall_ms": med * 1e3, "cli_wall_runs_ms": [w * 1e3 for w in walls], "cli_hits": lines,
+                       "cli_breakdown_ms": stamps[mid],
+                       "cli_breakdown_note": "the tool's own clock (RK_TIMING=1) in the median run, each phase since the one before: "
+                                             "`context ready` is hipInit + context (the .sketch is read meanwhile), `index built` upload + "
+                                             "rk_index_build incl. its code objects, `distances on the host` rk_dist_rows (the tile kernel, "
+                                             "hit download, host-side ordering and libm), `text written` the output file; the wall clock "
+                                             "adds process start and exit",
                        "cli_note": "`rabbit_kssd alldist -i bench.sketch -D %g` end to end (process start, HIP init, read .sketch, "
-                                   "index build, distances, text output), median of 3" % MAX_DIST}
+                                   "index build, distances, text output), median of 5" % MAX_DIST}
                 if res:
                     cli["cli_vs_reference_wall"] = res["wall_s"] / med
                     cli["cli_same_hits_as_reference"] = lines == res["hits"]
+                    # ... and against the reference started from the same bare .sketch: it first writes .dict/.index itself
+                    # (transSketches, src/subCommand.cpp:165-169 -> src/sketch.cpp:894-1021)
+                    t_trans, src = 79.0, "BASELINE.md [probe]: 79 s in the 8-vCPU build container (not timed in this run: --bare-sketch)"
+                    if bare_sketch and os.path.exists(REF_SKETCH):
+                        t0 = time.time()
+                        p = subprocess.run([REF_SKETCH, "resave", sk, os.path.join(tmp, "bare.sketch")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                        if p.returncode == 0:
+                            t_trans, src = time.time() - t0, "timed in this run: the reference's readSketches + saveSketches + transSketches (oracle/_ref/ref_sketch_driver resave)"
+                    cli["cli_vs_reference_wall_bare_sketch"] = {"ratio": (t_trans + res["wall_s"]) / med, "reference_transSketches_s": t_trans,
+                                                                "reference_alldist_wall_s": res["wall_s"], "source": src}
     if res is None:
         # port: the C restatement (same dense index, per-thread counter row, OpenMP dynamic rows)
         t0 = time.time()
@@ -829,14 +924,15 @@ def alldist_variant(env, head, n_genomes, steps, strains, tiny, what):
     strains, a 40-hash sketch among the bacteria.  Kernel time, pairs per second against the headline's, and whether the
     reported pairs and counts are the reference's."""
     k = {}
-    b = alldist_block(env, n_genomes, steps, 3, k, strains=strains, tiny=tiny)
+    b = alldist_block(env, n_genomes, steps, 3, k, strains=strains, tiny=tiny, build_reps=5)
     if env.rank != 0:
         return None
     res = {"workload": what, "genomes": b["genomes"], "pairs": b["pairs"], "hits": b["hits"], "kernel": b["kernel"],
            "kernel_ms": b["kernel_ms"], "kernel_ms_min_median_max": b["kernel_ms_min_median_max"],
            "pairs_per_s": b["pairs"] / (b["kernel_ms"] * 1e-3),
            "pairs_per_s_vs_headline": (b["pairs"] / (b["kernel_ms"] * 1e-3)) / (head["pairs"] / (head["kernel_ms"] * 1e-3)),
-           "index_build_ms": b["index_build_ms"], "first_call_ms": b.get("first_call_ms")}
+           "index_build_ms": b["index_build_ms"], "first_call_ms": b.get("first_call_ms"), "build_plus_dist_ms": b.get("build_plus_dist_ms"),
+           "index_products": b.get("index_products")}
     stats = k["index"].self_stats
     if b["kernel"].startswith("rk_tile_kernel"):
         # the tile kernel's stream: the 8-byte tile records (one per posting list and pair of 32-genome blocks) + 40 B per hit
@@ -849,7 +945,10 @@ def alldist_variant(env, head, n_genomes, steps, strains, tiny, what):
                 "limited_by": "vector issue (bit-sliced adds: ~4 vector instructions per tile record) and the length of a tile's chain of "
                               "records per wave; HBM traffic is a few per cent of the roof by construction (a record stands for up to "
                               "1,024 cell increments)"}
-        apply_pmc(roof, load_pmc(b["kernel"], "pmc_traffic_tile_clade%d.json" % strains) if strains > 10 else None)
+        apply_pmc(roof, load_pmc(b["kernel"], "pmc_traffic_tile_clade%d.json" % strains) if strains > 10 else None, env.peak_measured,
+                  issue_bound=True, working_set=stream)
+        roof["effective"] = True
+        roof["tile_stats"] = b.get("tile_stats")
         res["roofline"] = roof
     if not env.args.no_cpu_baseline and env.world == 1:
         ref = reference_alldist_pairs(k["names"], k["hashes"], k["off"])
@@ -931,16 +1030,18 @@ def multi_gpu_block(block, world):
                     "sketches + rk_index_build on every rank (--replicate blob: rank 0's packed index instead)"}
 
 
-def dist_roofline(block, pmc_file=None):
-    """roofline block of a self-join launch.  `achieved`/`frac`: HBM bytes per second the launch really moved -- from the
-    HBM counters when profiles/ holds them for this very kernel variant, else from the kernel's own stream (8 B per slice
-    record walked + 40 B per hit).  `contract_*`: SURVEY 8d's byte model, which bills count cells that stay in LDS and
-    postings that compact records never stream (it exceeds 1: reported for continuity only)."""
+def dist_roofline(block, pmc_file=None, peak_measured=None):
+    """roofline block of a self-join launch.  What binds these kernels is vector issue, not HBM: with a counter record of this
+    very kernel variant in profiles/ the block says `bound: valu_issue` and `frac` = the share of the launch the SIMDs spent
+    issuing vector instructions; the HBM side (bytes the counters saw per second, against the nominal AND the measured peak)
+    stays beside it as `hbm` / `hbm_frac`.  Without a record: the kernel's own stream against HBM.  `contract_*`: SURVEY 8d's
+    byte model, which bills count cells that are never formed and postings that are never streamed (it exceeds 1: continuity)."""
     secs = block["kernel_ms"] * 1e-3
     stream = block["stream_bytes_per_launch"]
-    roof = {"bound": "hbm", "achieved": stream / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    tile = block["kernel"].startswith("rk_tile_kernel")
+    roof = {"bound": "hbm", "achieved": stream / secs / 1e9, "peak": HBM_PEAK_GBS, "peak_measured": peak_measured, "unit": "GB/s",
             "frac": stream / secs / 1e9 / HBM_PEAK_GBS, "traffic": None,
-            "achieved_from": "the kernel's own stream: 8 B per slice record walked + 40 B per hit written",
+            "achieved_from": "the kernel's own stream: 8 B per %s record + 40 B per hit written (no counter record for this variant)" % ("tile" if tile else "slice"),
             "stream_bytes_per_launch": stream,
             "contract_bytes_per_launch": block["contract_bytes_per_launch"],
             "contract_achieved": block["contract_bytes_per_launch"] / secs / 1e9,
@@ -948,42 +1049,49 @@ def dist_roofline(block, pmc_file=None):
             "issue_frac": None,
             "kernel": block["kernel"], "kernel_ms": block["kernel_ms"],
             "kernel_ms_min_median_max": block["kernel_ms_min_median_max"],
-            "kernel_ms_cold": block["kernel_ms_cold"],
-            "cold_note": "kernel_ms: launches that repeat one (index, options) pair (after the first completed one the empty fallback "
-                         "launch of rk_near_kernel is skipped); kernel_ms_cold: every launch a first one (two option sets taking turns)",
-            "limited_by": "the dependent memory round trips of a unit (row bounds -> slice records -> sizes and ids of the "
-                          "reportable cells) with one short unit per wave, and vector issue; not HBM bandwidth: the kernel's whole "
-                          "stream is the 8-byte slice records (a compact record is its own posting list; the window counts stay in "
-                          "registers), DESIGN.md 4.3; issue_frac = share of the kernel's duration the SIMDs spent issuing vector "
-                          "instructions (SQ_ACTIVE_INST_VALU x 4 / 1,024 SIMDs / 2.4 GHz)"}
-    if block["kernel"].startswith("rk_tile_kernel"):
-        roof["achieved_from"] = "the kernel's own stream: 8 B per tile record + 40 B per hit written"
+            "kernel_ms_cold": block["kernel_ms_cold"]}
+    if tile:
         roof["tile_records"] = block.get("tile_records")
-        roof["cold_note"] = ("an index that is joined again (a context that is not single-shot) runs on the tile kernel from its second "
-                             "unsharded self join on: kernel_ms and kernel_ms_cold are both the tile kernel's (it has no per-launch state); "
-                             "first_call_ms is the first join (rk_near_kernel), build_plus_dist the path of a single join")
-        roof["limited_by"] = ("vector issue (bit-sliced adds: ~4 vector instructions per tile record) and the length of a tile's chain of "
-                              "records per wave; HBM traffic is a few per cent of the roof by construction (a record stands for up to "
-                              "1,024 cell increments), DESIGN.md 4.3c; issue_frac = share of the kernel's duration the SIMDs spent issuing "
-                              "vector instructions (SQ_ACTIVE_INST_VALU x 4 / 1,024 SIMDs / 2.4 GHz)")
+        roof["effective"] = True
+        roof["effective_note"] = ("pairs/s is an EFFECTIVE rate: the kernel starts only the tiles that can hold a reportable pair under "
+                                  "-D (tile_stats: tiles_started of tiles_with_records; cells_formed_share of the pair matrix) and never "
+                                  "streams T postings -- same hits as the reference, which forms every cell (src/dist.cpp:194-255); "
+                                  "threshold_legs shows the rate under -D 0.3 and -D 1.0")
+        roof["tile_stats"] = block.get("tile_stats")
+        roof["cold_note"] = ("the tile records come with rk_index_build (collections of 4,000 genomes and more): the FIRST self join over an "
+                             "index runs on this kernel, which keeps no per-launch state -- kernel_ms, kernel_ms_cold and first_call_ms "
+                             "(a fresh index, host clock around one call) are the same launch")
+        roof["limited_by"] = ("vector issue (bit-sliced adds: ~2.6 vector instructions per tile record) and, at 10,000 genomes, the length "
+                              "of a tile's chain of records per wave (the launch is one round of ~560 workgroups); HBM traffic is a few "
+                              "per cent of the roof by construction (a record stands for up to 1,024 cell increments), DESIGN.md 4.3c")
         if pmc_file:
             pmc_file = {"pmc_traffic.json": "pmc_traffic_tile_clade10.json", "pmc_traffic_50k.json": "pmc_traffic_tile_50k.json"}.get(pmc_file, pmc_file)
+    else:
+        roof["cold_note"] = ("kernel_ms: launches that repeat one (index, options) pair (after the first completed one the empty fallback "
+                             "launch of rk_near_kernel is skipped); kernel_ms_cold: every launch a first one (two option sets taking turns)")
+        roof["limited_by"] = ("the dependent memory round trips of a unit (row bounds -> slice records -> sizes and ids of the "
+                              "reportable cells) with one short unit per wave, and vector issue; not HBM bandwidth, DESIGN.md 4.3")
     if pmc_file:
-        apply_pmc(roof, load_pmc(block["kernel"], pmc_file))
+        apply_pmc(roof, load_pmc(block["kernel"], pmc_file), peak_measured, issue_bound=True, working_set=stream)
     return roof
 
 
-def build_roofline(block):
+def build_roofline(block, peak_measured=None):
     """rk_index_build as its own roofline block: sketches in HBM -> index in HBM.  Algorithmic bytes: the hashes read once
-    (4 B), the postings written (4 B), the distinct hashes + posting offsets (8 B each), one 8-byte slice record per
-    (genome, hash) with later sharers."""
-    b = 8.0 * block["hashes"] + 8.0 * block.get("distinct", 0) + 8.0 * block["slice_records"]
+    (4 B), the postings written (4 B), the distinct hashes + posting offsets (8 B each), and the join structure the build
+    emits: one 8-byte slice record per (genome, hash) with later sharers, or -- from 4,000 genomes on -- 16 bytes per tile
+    record (AoS + the split copy) + 64 bytes of directory per tile."""
+    ts = block.get("tile_stats") or {}
+    join_bytes = 16.0 * ts.get("tile_records", 0) + 64.0 * ts.get("tiles_with_records", 0) if (block.get("index_products", 0) & 4) else 8.0 * block["slice_records"]
+    b = 8.0 * block["hashes"] + 8.0 * block.get("distinct", 0) + join_bytes
     secs = block["index_build_ms"] * 1e-3
-    return {"bound": "hbm", "achieved": b / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / secs / 1e9 / HBM_PEAK_GBS,
-            "traffic": None, "algorithmic_bytes_per_build": b, "build_ms": block["index_build_ms"],
+    return {"bound": "hbm", "achieved": b / secs / 1e9, "peak": HBM_PEAK_GBS, "peak_measured": peak_measured, "unit": "GB/s",
+            "frac": b / secs / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_build": b, "build_ms": block["index_build_ms"],
+            "products": "tile records (rk_index_tiles.inc)" if (block.get("index_products", 0) & 4) else "slice records",
             "path": "bucket sort, second level in LDS (rk_index_fast.inc)" if block["index_built_fast"] else "device-wide radix sort",
-            "limited_by": "a chain of ~20 small kernels (wall time = their sum): the 8,192-way partition's scattered 8-byte "
-                          "stores and the in-LDS sort's vector work dominate (profiles/r03_index_build_kernels.txt)"}
+            "limited_by": "a chain of ~20 dependent kernels none of which is bandwidth-bound: every workgroup of the in-LDS bucket sort is a "
+                          "chain of four memory round trips and eleven barriers (130 us at 10,000 genomes, eight rounds of workgroups per CU), "
+                          "the two-pass partition 120 us, the tile sort 100 us (profiles/r05_index_build_kernels.txt)"}
 
 
 def main():
@@ -1020,6 +1128,9 @@ def main():
                                          "of 100: pairs across lineages share ~28 %% of their hashes and are NOT within -D %g)" % (n_genomes, MAX_DIST)),
             "tiny": alldist_variant(env, head, n_genomes, vs, 10, 1, "the headline collection plus one 40-hash sketch (a plasmid)"),
         }
+    legs = None
+    if world == 1 and not args.no_variants:
+        legs = threshold_legs(env, keep["index"], head["pairs"])
     if world == 1 and not args.no_rehearsal:
         rehearsal = {"10000": shard_rehearsal(env, keep["index"], n_genomes)}
     distinct = int(keep["index"].distinct) if rank == 0 else 0
@@ -1065,6 +1176,9 @@ def main():
     tile = head["kernel"].startswith("rk_tile_kernel")
     out = {
         "metric": "genome-pairs/sec alldist (10k bacteria, L3K10)",
+        "hbm_peak": {"nominal_gbs": HBM_PEAK_GBS, "measured_gbs": env.peak_measured,
+                     "how": "k_calib_read: a streaming read of a 2 GiB buffer (8 x the Infinity Cache), 16 B per lane, HIP events around 5 "
+                            "launches, at the start of this run (SURVEY 8d's measured denominator)"},
         "value": head["value"],
         "unit": "genome-pairs/s",
         "n_gpus": world,
@@ -1087,23 +1201,28 @@ def main():
                    "slice_records": head["slice_records"], "compact_share": head["compact_share"],
                    "records_walked_per_launch": head["records_walked"],
                    "sharding": "query rows in blocks of %d dealt round-robin to %d rank(s); sketches broadcast once (RCCL on GPUs), index built per rank" % (shard.ROW_BLOCK, world),
-                   "first_call_ms": head["first_call_ms"], "second_call_ms": head["second_call_ms"], "tile_records": head.get("tile_records"),
+                   "first_call_ms": head["first_call_ms"], "tile_records": head.get("tile_records"),
+                   "build_plus_dist_ms": head["build_plus_dist_ms"],
+                   "build_plus_dist_pairs_per_s": (n_pairs / (head["build_plus_dist_ms"] * 1e-3)) if head["build_plus_dist_ms"] else None,
+                   "index_build_ms": head["index_build_ms"], "index_products": head.get("index_products"),
+                   "effective": bool(tile), "tile_stats": head.get("tile_stats"), "threshold_legs": legs,
                    "step": ("one rk_dist_rows_dev call over the resident index: rk_tile_kernel counts 32 x 32 tiles of the pair matrix from "
-                            "one 8-byte record per posting list and pair of 32-genome blocks and evaluates their cells.  The library takes "
-                            "this kernel from the second unsharded self join over one index on (second_call_ms: that call builds the tile "
-                            "records); the first join (first_call_ms) and row shards (--gpus N > 1, scaling_rehearsal) run on "
-                            "rk_near_kernel, as does a single-shot context (the command-line tool, build_plus_dist)") if tile else
+                            "one 8-byte record per posting list and pair of 32-genome blocks and evaluates their cells.  The tile records "
+                            "are a product of rk_index_build (collections of 4,000 genomes and more): the FIRST join over an index "
+                            "(first_call_ms, the command-line tool, the reference-side binding, build_plus_dist_ms = build + one join "
+                            "from resident sketches) runs this very kernel; the choice of kernel follows the index's size and shape, "
+                            "never how often it was joined.  `value` is an effective rate (roofline.effective_note)") if tile else
                            ("one rk_dist_rows_dev call: rk_near_kernel counts and evaluates every pair of the launch; its exact "
                             "fallback pass (rows whose far cells could be reportable) is launched until a completed launch with "
                             "the same options has shown that list to be empty -- here after the warm-up -- and skipped from then on "
                             "(RK_DIST_FB_SKIP=0 launches it always: +3 us per step)")},
-        "roofline": dist_roofline(head, "pmc_traffic.json" if world == 1 else None),
+        "roofline": dist_roofline(head, "pmc_traffic.json" if world == 1 else None, env.peak_measured),
         # second headline: what an alldist costs when the index is NOT there yet -- sketches resident in HBM -> hits in HBM
         "build_plus_dist": {
             "ms": head["build_plus_dist_ms"], "pairs_per_s": (n_pairs / (head["build_plus_dist_ms"] * 1e-3)) if head["build_plus_dist_ms"] else None,
             "note": "rk_index_build + rk_dist_rows_dev from device-resident sketches, median of 15, one synchronisation (the "
                     "build's 32-byte read-back); `value` above times the distance kernel alone, as BASELINE configs[2] words it",
-            "index_build": build_roofline(head)},
+            "index_build": build_roofline(head, env.peak_measured)},
         "multi_gpu": multi_gpu_block(head, world),
         "alldist_order": orders or None,
         "alldist_variants": variants,
@@ -1124,10 +1243,12 @@ def main():
             "index_build_ms": config3["index_build_ms"], "index_built_fast": config3["index_built_fast"],
             "build_plus_dist_ms": config3["build_plus_dist_ms"], "compact_share": config3["compact_share"],
             "index_blob_bytes": config3["index_blob_bytes"], "multi_gpu": multi_gpu_block(config3, world),
-            "roofline": dist_roofline(config3, "pmc_traffic_50k.json" if world == 1 else None), "index_build": build_roofline(config3)}
+            "roofline": dist_roofline(config3, "pmc_traffic_50k.json" if world == 1 else None, env.peak_measured),
+            "index_build": build_roofline(config3, env.peak_measured)}
     if rq:
         if world == 1:
-            apply_pmc(rq["roofline"], load_pmc(rq["roofline"]["kernel"], "pmc_traffic_rq.json"))
+            apply_pmc(rq["roofline"], load_pmc(rq["roofline"]["kernel"], "pmc_traffic_rq.json"), env.peak_measured,
+                      working_set=rq["roofline"]["stream_bytes_per_launch"])
             if rq["roofline"]["achieved"] is None:   # no counter record for this variant: the compulsory stream
                 secs = rq["roofline"]["kernel_ms"] * 1e-3
                 rq["roofline"]["achieved"] = rq["roofline"]["stream_bytes_per_launch"] / secs / 1e9
@@ -1148,7 +1269,7 @@ def main():
         if not args.no_sketch_big:
             out["sketch_big"] = sketch_big_block(env)
     if world == 1 and not args.no_cpu_baseline:
-        cb, cli = alldist_cpu_and_cli(keep, n_pairs)
+        cb, cli = alldist_cpu_and_cli(keep, n_pairs, args.bare_sketch)
         out["cpu_baseline"] = cb
         if cb.get("hits") is not None and cb["hits"] != head["hits"]:
             print(json.dumps(out), flush=True)

@@ -279,6 +279,13 @@ typedef struct rk_dist_opts {
                              its member that comes first in that order                                            */
 } rk_dist_opts;
 
+/* The tile kernel is output-sensitive: of the 32 x 32 tiles of the pair matrix that hold a record at all, a launch gives a
+ * workgroup only to those that can hold a reportable pair under `opts` (records per smallest sketch of the tile against the
+ * threshold; the test is exact, the counted tiles are counted exactly).  out[0] = tiles with records, out[1] = tiles a launch
+ * with these options starts (opts == NULL: 0), out[2] = tile records, out[3] = record slots (every tile from an even slot).
+ * All 0 while the index has no tile records.  (The reference forms every cell of every row, src/dist.cpp:194-255.) */
+int rk_index_tile_stats(const rk_index *idx, const rk_dist_opts *opts, uint64_t out[4]);
+
 /* Counts |S_q n S_r| through the inverted index and applies the reference's epilogue.
  * queries == NULL is only valid with triangle=1 (the indexed sketches are the queries).
  * hits_out is library-allocated (rk_free_host), sorted by (row, col).  The jaccard/containment and

@@ -23,7 +23,7 @@ EXPORTS = [
     "rk_sketches_from_host", "rk_sketches_from_host64", "rk_sketches_download64", "rk_sketches_is64", "rk_sketches_from_dev", "rk_sketches_count", "rk_sketches_total", "rk_sketches_windows",
     "rk_sketches_download", "rk_sketches_hashes_dev", "rk_sketches_off_dev", "rk_sketches_free",
     "rk_index_build", "rk_index_import", "rk_index_export", "rk_index_export_lists", "rk_index_import64", "rk_index_export64", "rk_index_total",
-    "rk_index_distinct", "rk_index_genomes", "rk_index_order", "rk_index_hash_bits", "rk_index_built_fast", "rk_index_products", "rk_index_sum_sq", "rk_index_self_stats",
+    "rk_index_distinct", "rk_index_genomes", "rk_index_order", "rk_index_hash_bits", "rk_index_built_fast", "rk_index_products", "rk_index_sum_sq", "rk_index_self_stats", "rk_index_tile_stats",
     "rk_index_free", "rk_index_blob_bytes", "rk_index_pack_dev", "rk_index_unpack_dev", "rk_index_broadcast", "rk_dist_rows", "rk_dist_rows_dev", "rk_topn_rows", "rk_format_hit",
 ]
 
@@ -126,6 +126,15 @@ class Context:
 
     def set_timing(self, on=True):
         lib().rk_ctx_set_timing(self._h, 1 if on else 0)
+
+    def stream_read_gbs(self, mbytes=2048, reps=5):
+        """GB/s of a streaming read over `mbytes` MiB of HBM (k_calib_read, 16 B per lane, HIP events): the measured denominator
+        next to the nominal HBM peak"""
+        L = lib()
+        L.rk_debug_stream_read_gbs.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
+        out = C.c_double()
+        self.check(L.rk_debug_stream_read_gbs(self._h, C.c_uint64(int(mbytes) << 20), int(reps), C.byref(out)))
+        return float(out.value)
 
     def set_single_shot(self, on=True):
         """a process that makes one pass (rk_ctx_set_single_shot): host-side ordering of small hit sets, no switch to the tile kernel"""
@@ -391,6 +400,15 @@ class Index(_Obj):
         kernel -- 0 until a self join has built them)"""
         out = (C.c_uint64 * 4)()
         self.ctx.check(lib().rk_index_self_stats(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
+    def tile_stats(self, triangle=1, metric=0, kmer_size=20, max_dist=0.05):
+        """(tiles with records, tiles a launch with these options starts, tile records, record slots) -- rk_index_tile_stats"""
+        opts = DistOpts(int(triangle), int(metric), int(kmer_size), 0, float(max_dist), 0, 1)
+        out = (C.c_uint64 * 4)()
+        L = lib()
+        L.rk_index_tile_stats.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        self.ctx.check(L.rk_index_tile_stats(self._h, C.byref(opts), out))
         return int(out[0]), int(out[1]), int(out[2]), int(out[3])
 
     @property

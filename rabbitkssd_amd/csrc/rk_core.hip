@@ -152,6 +152,37 @@ extern "C" int rk_debug_calib_read(rk_ctx *ctx, uint64_t bytes, int width)
     return RK_OK;
 }
 
+// the device's streaming-read rate over `bytes` of HBM (bigger than the 256 MB Infinity Cache), HIP events around `reps`
+// launches: the measured denominator SURVEY 8d asks for beside the nominal 8 TB/s (bench.py: roofline.peak_measured)
+extern "C" int rk_debug_stream_read_gbs(rk_ctx *ctx, uint64_t bytes, int reps, double *gbs)
+{
+    if (!ctx || !gbs || reps < 1 || bytes < (1u << 20)) return RK_ERR_ARG;
+    *gbs = 0.0;
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<char> buf(ctx);
+    DevBuf<unsigned long long> sink(ctx);
+    RK_HIP(ctx, buf.alloc(bytes));
+    RK_HIP(ctx, sink.alloc(1));
+    RK_HIP(ctx, hipMemsetAsync(buf.p, 1, bytes, ctx->stream));
+    const unsigned grid = (unsigned)ctx->num_cu * 8;
+    hipEvent_t e0, e1;
+    RK_HIP(ctx, hipEventCreate(&e0));
+    RK_HIP(ctx, hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_calib_read<uint4>, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)buf.p, bytes / 16, sink.p);   // warm-up
+    (void)hipEventRecord(e0, ctx->stream);
+    for (int r = 0; r < reps; r++)
+        hipLaunchKernelGGL(k_calib_read<uint4>, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)buf.p, bytes / 16, sink.p);
+    (void)hipEventRecord(e1, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    RK_HIP(ctx, e);
+    if (ms > 0.f) *gbs = (double)bytes * reps / (ms * 1e-3) / 1e9;
+    return RK_OK;
+}
+
 extern "C" {
 
 const char *rk_version(void) { return "rabbitkssd-amd 0.1.0 (gfx950)"; }

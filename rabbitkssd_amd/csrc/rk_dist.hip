@@ -1406,6 +1406,25 @@ int rk_dist_kernel_name(rk_ctx *ctx, const rk_index *idx, const rk_sketches *que
     return RK_OK;
 }
 
+int rk_index_tile_stats(const rk_index *idx, const rk_dist_opts *opts, uint64_t out[4])
+{
+    if (!idx || !out) return RK_ERR_ARG;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!idx->tiles_ready) return RK_OK;
+    out[0] = idx->n_tiles;
+    out[2] = idx->n_tile_records;
+    out[3] = idx->n_tile_slots;
+    if (opts && opts->kmer_size > 0 && opts->max_dist > 0.0) {
+        const double t = exp(-(double)opts->kmer_size * opts->max_dist);
+        unsigned long long grid = 0;
+        int threads = 256;
+        bool srow = false;
+        tile_launch_shape(idx, opts, ((opts->metric != 0) ? t : t / (2.0 - t)) * (1.0 - 1e-6), &grid, &threads, &srow);
+        out[1] = grid;
+    }
+    return RK_OK;
+}
+
 int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
                      const rk_dist_opts *opts, rk_hit *hits_dev, uint64_t hits_cap,
                      uint64_t *n_hits_dev, void *stream)

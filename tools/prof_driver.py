@@ -114,10 +114,10 @@ def dist_rq_dev(n_ref=100000, n_query=1000, steps=5, m_ref=76, m_query=45776, bi
                                                                          int(counters[0].item())))
 
 
-def index_only(n_genomes=10000, reps=5):
+def index_only(n_genomes=10000, reps=5, clade=10):
     """rk_index_build alone (profiler runs, developer ablations that leave the index unusable)"""
     ctx = capi.Context(0)
-    names, hashes, off = synth.clade_sketches(n_genomes, 1220, 28)
+    names, hashes, off = synth.clade_sketches(n_genomes, 1220, 28, strains_per_clade=clade)
     sk = ctx.sketches_from_host(hashes, off)
     for r in range(reps):
         torch.cuda.synchronize()
