@@ -246,6 +246,24 @@ uint64_t rk_index_sum_sq(const rk_index *idx);
  * the tile kernel (one per posting list and pair of 32-genome blocks it touches; 0 while the index has none: rk_index_products).
  * Computed on first request (one small kernel) and cached; 0s for an imported index. */
 int rk_index_self_stats(const rk_index *idx, uint64_t out[4]);
+/* Multi-GPU, sharded build (round 5).  The all-vs-all join shards twice: the BUILD by hash range (a posting list lives in one
+ * range: its tile records are found without looking at the other ranges), the JOIN by rows (a tile of the pair matrix belongs
+ * to the shard of its row block; blocks of 32 genomes of the internal order dealt round-robin, as rk_dist_opts.row_block = 32
+ * does).  Between the two lies ONE all-to-all of 12-byte tile records -- no index is replicated, nothing is reduced:
+ *   every shard:  rk_index_build_shard(sketches, hash_bits, shard, n_shards)   the lists of hash range `shard` (n_shards a power of
+ *                 two <= 64; every shard holds the same CSR sketches -- one broadcast -- and computes the same internal order)
+ *                 rk_index_shard_records(part, counts[n_shards])    tile records it holds for every destination shard
+ *                 rk_index_shard_pack(part, send_dev, stream)       ... contiguous by destination (12 bytes each)
+ *   (the caller's all-to-all: RCCL / torch.distributed.all_to_all_single, or peer copies)
+ *                 rk_index_join_shard(ctx, part, recv_dev, n, &join)  sorts what arrived by tile: a join-only index over THIS
+ *                 shard's rows; rk_dist_rows(_dev)(join, NULL, opts with row_step = 1) reports the pairs whose row block it
+ *                 owns.  The union over the shards is the whole result (the reference's rows are independent, src/dist.cpp:174).
+ * A collection too big for one pass of the bucket sort (more than ~5 * 10^7 postings) is built the same way on ONE device:
+ * rk_index_build covers the hash space range by range, the postings of a range behind those of the range before. */
+int rk_index_build_shard(rk_ctx *ctx, const rk_sketches *s, int hash_bits, uint32_t shard, uint32_t n_shards, rk_index **out);
+int rk_index_shard_records(const rk_index *part, uint64_t *counts_out);
+int rk_index_shard_pack(const rk_index *part, void *send_dev, void *stream);
+int rk_index_join_shard(rk_ctx *ctx, const rk_index *part, const void *recv_dev, uint64_t n_records, rk_index **out);
 /* Multi-GPU: the whole index as ONE contiguous device blob, so that the owner can hand it
  * to an RCCL broadcast (one collective, no reduction: query rows are independent) and every
  * peer rebuilds an identical rk_index from the received bytes.  pack/unpack only enqueue

@@ -23,7 +23,7 @@ EXPORTS = [
     "rk_sketches_from_host", "rk_sketches_from_host64", "rk_sketches_download64", "rk_sketches_is64", "rk_sketches_from_dev", "rk_sketches_count", "rk_sketches_total", "rk_sketches_windows",
     "rk_sketches_download", "rk_sketches_hashes_dev", "rk_sketches_off_dev", "rk_sketches_free",
     "rk_index_build", "rk_index_import", "rk_index_export", "rk_index_export_lists", "rk_index_import64", "rk_index_export64", "rk_index_total",
-    "rk_index_distinct", "rk_index_genomes", "rk_index_order", "rk_index_hash_bits", "rk_index_built_fast", "rk_index_products", "rk_index_sum_sq", "rk_index_self_stats", "rk_index_tile_stats",
+    "rk_index_distinct", "rk_index_genomes", "rk_index_order", "rk_index_hash_bits", "rk_index_built_fast", "rk_index_products", "rk_index_sum_sq", "rk_index_self_stats", "rk_index_tile_stats", "rk_index_build_shard", "rk_index_shard_records", "rk_index_shard_pack", "rk_index_join_shard",
     "rk_index_free", "rk_index_blob_bytes", "rk_index_pack_dev", "rk_index_unpack_dev", "rk_index_broadcast", "rk_dist_rows", "rk_dist_rows_dev", "rk_topn_rows", "rk_format_hit",
 ]
 
@@ -262,6 +262,22 @@ class Context:
         self.check(lib().rk_index_build(self._h, sketches._h, int(hash_bits_), C.byref(h)))
         return Index(self, h)
 
+    def index_build_shard(self, sketches, hash_bits_, shard, n_shards):
+        """the lists of hash range `shard` of `n_shards` + their tile records grouped by destination shard (rk_index_build_shard)"""
+        h = C.c_void_p()
+        L = lib()
+        L.rk_index_build_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        self.check(L.rk_index_build_shard(self._h, sketches._h, int(hash_bits_), int(shard), int(n_shards), C.byref(h)))
+        return Index(self, h)
+
+    def index_join_shard(self, part, recv_dev_ptr, n_records):
+        """a join-only index over this shard's rows from the tile records that arrived (rk_index_join_shard)"""
+        h = C.c_void_p()
+        L = lib()
+        L.rk_index_join_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        self.check(L.rk_index_join_shard(self._h, part._h, C.c_void_p(recv_dev_ptr), C.c_uint64(n_records), C.byref(h)))
+        return Index(self, h)
+
     def index_import(self, postings, counts, hash_bits_, ref_sizes):
         postings = np.ascontiguousarray(postings, dtype=np.uint32)
         counts = np.ascontiguousarray(counts, dtype=np.uint32)
@@ -401,6 +417,19 @@ class Index(_Obj):
         out = (C.c_uint64 * 4)()
         self.ctx.check(lib().rk_index_self_stats(self._h, out))
         return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
+    def shard_records(self, n_shards):
+        """tile records this shard holds for every destination shard (rk_index_shard_records)"""
+        out = (C.c_uint64 * int(n_shards))()
+        L = lib()
+        L.rk_index_shard_records.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        self.ctx.check(L.rk_index_shard_records(self._h, out))
+        return [int(x) for x in out]
+
+    def shard_pack(self, send_dev_ptr, stream=0):
+        L = lib()
+        L.rk_index_shard_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.ctx.check(L.rk_index_shard_pack(self._h, C.c_void_p(send_dev_ptr), C.c_void_p(stream)))
 
     def tile_stats(self, triangle=1, metric=0, kmer_size=20, max_dist=0.05):
         """(tiles with records, tiles a launch with these options starts, tile records, record slots) -- rk_index_tile_stats"""

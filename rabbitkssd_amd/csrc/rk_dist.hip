@@ -1138,9 +1138,9 @@ __global__ void k_count_flagged(const uint2 *selfrange, uint64_t n_self, unsigne
 int self_uses_tiles(rk_ctx *ctx, const rk_index *cidx, const rk_dist_opts *o, bool dense_mode, hipStream_t stream, bool *use)
 {
     *use = false;
-    if (dense_mode || !cidx->ref_sets || !cidx->d_postings || !cidx->d_upos || !cidx->d_src_off || !cidx->n_ref || o->kmer_size <= 0 || o->row_block < 0 ||
-        !(o->max_dist > 0.0) || cidx->tiles_unusable)
-        return RK_OK;
+    if (dense_mode || !cidx->ref_sets || ((!cidx->d_postings || !cidx->d_upos) && !cidx->tiles_ready) || !cidx->d_src_off || !cidx->n_ref || o->kmer_size <= 0 ||
+        o->row_block < 0 || !(o->max_dist > 0.0) || cidx->tiles_unusable)
+        return RK_OK;   // (a join-only index -- rk_index_join_shard -- has tile records and no postings)
     const bool can_rows = cidx->d_selfrange || (!cidx->slices_refused && cidx->H < (1ULL << 30));   // (slice records exist or can be made: rk_index_ensure_slices)
     if (!ctx->sw_dist_tiles && can_rows) return RK_OK;
     if (ctx->sw_dist_tiles == 1 || !can_rows) { *use = true; return RK_OK; }
@@ -1440,6 +1440,8 @@ int rk_dist_rows_dev(rk_ctx *ctx, const rk_index *idx, const rk_sketches *querie
     }
     if (!opts->triangle || !idx->d_src_off)
         return rk_fail(ctx, RK_ERR_ARG, "queries == NULL needs triangle=1 and an index built by rk_index_build");
+    if (idx->n_shards > 1)
+        return rk_fail(ctx, RK_ERR_ARG, "a shard of a sharded build holds the lists of one hash range: join through rk_index_join_shard");
     return launch_self(ctx, idx, opts, rk_dense_mode(opts), hits_dev, hits_cap, (unsigned long long *)n_hits_dev, (hipStream_t)stream);
 }
 
@@ -1454,6 +1456,8 @@ int rk_dist_rows(rk_ctx *ctx, const rk_index *idx, const rk_sketches *queries,
     if (self && (!opts->triangle || !idx->d_src_off))
         return rk_fail(ctx, RK_ERR_ARG, "queries == NULL needs triangle=1 and an index built by rk_index_build");
     if (self && common_dense) return rk_fail(ctx, RK_ERR_ARG, "common_dense needs explicit query sketches");
+    if (self && idx->n_shards > 1)
+        return rk_fail(ctx, RK_ERR_ARG, "a shard of a sharded build holds the lists of one hash range: join through rk_index_join_shard");
     const uint32_t n_query = self ? idx->n_ref : queries->n;
     if (opts->triangle && n_query != idx->n_ref)
         return rk_fail(ctx, RK_ERR_ARG, "triangle mode needs the indexed sketches as queries (%u vs %u)",

@@ -745,6 +745,7 @@ void rk_index_free(rk_index *idx)
     rk_pool_free(ctx, idx->d_urec);
     rk_pool_free(ctx, idx->d_sizes);
     rk_pool_free(ctx, idx->d_selfrange);
+    rk_pool_free(ctx, idx->d_shard_rec);
     rk_pool_free(ctx, idx->d_self_off);
     rk_pool_free(ctx, idx->d_self_split);
     rk_pool_free(ctx, idx->d_src_off);
@@ -835,7 +836,22 @@ int rk_index_self_stats(const rk_index *cidx, uint64_t out[4])
     return RK_OK;
 }
 
+static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, uint32_t shard_id, uint32_t n_shards, rk_index **out);
+
 int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **out)
+{
+    return index_build_impl(ctx, s, hash_bits, 0, 1, out);
+}
+
+int rk_index_build_shard(rk_ctx *ctx, const rk_sketches *s, int hash_bits, uint32_t shard, uint32_t n_shards, rk_index **out)
+{
+    if (!ctx) return RK_ERR_ARG;
+    if (!n_shards || n_shards > kRecRegions || (n_shards & (n_shards - 1)) || shard >= n_shards)
+        return rk_fail(ctx, RK_ERR_ARG, "rk_index_build_shard: %u shards (a power of two up to %u), shard %u", n_shards, kRecRegions, shard);
+    return index_build_impl(ctx, s, hash_bits, shard, n_shards, out);
+}
+
+static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, uint32_t shard_id, uint32_t n_shards, rk_index **out)
 {
     if (!ctx || !s || !out) return RK_ERR_ARG;
     *out = nullptr;
@@ -890,19 +906,36 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     // ---- which build: the bucket sort (rk_index_fast.inc) when the key fields fit, and then with TILE records as its product
     // (rk_index_tiles.inc) from RK_DIST_TILES_MIN_GENOMES genomes on -- the self join runs on rk_tile_kernel from its first launch --,
     // with slice records (rk_near_kernel, rk_dist_kernel) below
+    // (round 5) The hash space is covered in RANGES (its top bits): one range per shard of a multi-GPU build
+    // (rk_index_build_shard: this call builds the lists of ITS range only), and inside a shard as many passes as it takes to keep
+    // a pass's keys within 2^15 buckets of ~1,536 -- a collection of any size takes the bucket sort, pass after pass on one
+    // stream, the postings of a pass behind those of the pass before.
+    int shard_bits = 0, pass_bits = 0;
+    while ((1u << shard_bits) < n_shards) shard_bits++;
+    const uint64_t H_shard = H / n_shards + (n_shards > 1 ? H / (8ULL * n_shards) + 4096 : 0);   // (estimate: the hashes are spread evenly)
+    while (pass_bits < 8 && (H_shard >> pass_bits) > ((uint64_t)kBucketTarget << kMaxBucketBits)) pass_bits++;
+    if (getenv("RK_INDEX_PASS_BITS")) pass_bits = std::max(0, std::min(7, atoi(getenv("RK_INDEX_PASS_BITS"))));   // (tests: several passes over a small collection)
+    const int range_bits = shard_bits + pass_bits;
+    const uint32_t n_pass = 1u << pass_bits;
+    const int eff_bits = hash_bits - range_bits;   // hash bits inside a range
+    const uint64_t H_pass = range_bits ? (H_shard >> pass_bits) : H;
     int B = 1, gb = 1, rb = 1;
     // (at most kMaxBucketBits: a bigger collection gets fuller buckets, up to the LDS capacity -- beyond it the kernels raise the overflow flag)
-    while (B < hash_bits && B < kMaxBucketBits && ((H + kBucketTarget - 1) / kBucketTarget) > (1ULL << B)) B++;
+    while (B < eff_bits && B < kMaxBucketBits && ((H_pass + kBucketTarget - 1) / kBucketTarget) > (1ULL << B)) B++;
     while ((1ULL << gb) < N) gb++;
     while ((1ULL << rb) < s->max_size) rb++;
-    const int low_bits = hash_bits - B;
+    const int low_bits = eff_bits - B;
     // (64-bit hashes -- use64, e.g. K12 L3: 36 bits -- take the same path as long as the key fields fit: the kernels that read
     // the sketches are templated on the hash type, the bucket sort itself only ever sees the low bits)
-    const bool fast_ok = ctx->sw_index_fast && !no_self && H && H < (1ULL << 30) && s->is_set && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 &&
-                         low_bits + gb + rb <= 63 && gb <= 31 && rb <= 31;
+    const bool fast_common = ctx->sw_index_fast && H && s->is_set && eff_bits >= 1 && B <= kMaxBucketBits && low_bits >= 0 && low_bits <= 31 && gb <= 31 && rb <= 31;
+    const bool slices_ok = fast_common && !range_bits && !no_self && H < (1ULL << 30) && low_bits + gb + rb <= 63;   // (slice records: one pass, offsets below 2^30)
     const uint32_t n_blocks = (N + 31) / 32;
-    bool tiles_mode = fast_ok && N >= 2 && n_blocks <= kTileMaxBlocks &&
-                      (ctx->sw_index_tiles == 1 || (ctx->sw_index_tiles == 2 && N >= (uint32_t)ctx->sw_dist_tiles_min_genomes));
+    const bool tiles_ok = fast_common && N >= 2 && n_blocks <= kTileMaxBlocks && low_bits + gb <= 63 && ctx->sw_index_tiles != 0;
+    bool tiles_mode = tiles_ok && (range_bits || no_self || ctx->sw_index_tiles == 1 || N >= (uint32_t)ctx->sw_dist_tiles_min_genomes);
+    const bool fast_ok = tiles_mode || slices_ok;
+    if (n_shards > 1 && !tiles_mode)
+        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "rk_index_build_shard needs set sketches of 2 .. %u genomes whose key fields fit the bucket sort "
+                                                "(hash bits %d, %u shards)", kTileMaxBlocks * 32, hash_bits, n_shards);
     if (tiles_mode) RK_TRY(pool_array(ctx, &idx->d_blk_min, (size_t)n_blocks));
     const unsigned wave_blocks = (N + 3) / 4;  // 4 waves (genomes) per 256-thread workgroup
 
@@ -1034,16 +1067,19 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
     DevBuf<uint2> t_contrib(ctx);
     DevBuf<uint32_t> t_rows(ctx), t_cols(ctx);
     DevBuf<uint4> t_dir_j(ctx), t_dir_c(ctx);
+    DevBuf<uint3> t_rec(ctx);   // a shard's tile records, grouped by destination shard (they leave for the exchange unsorted)
+    uint32_t t_region_cap = 0;
     for (int attempt = 0; fast_ok && !built && attempt < 2; attempt++) {
         // (second attempt: the tile records of the first did not fit their buffer -- lists scattered over many blocks -- and the
-        // index is built with slice records after all)
-        if (attempt == 1 && (fast_refused || !tr.overflow)) break;
+        // index is built with slice records after all, where those can be had)
+        if (attempt == 1 && (fast_refused || !tr.overflow || !slices_ok)) break;
         if (attempt == 1) {
             tiles_mode = false;
             rk_pool_free(ctx, idx->d_blk_min);
             idx->d_blk_min = nullptr;
         }
         if (!tiles_mode) RK_TRY(alloc_slices());
+        const uint32_t passes = tiles_mode ? n_pass : 1;
         FastArgs fa;
         fa.hashes = idx->wide ? (const void *)s->d_hashes64 : (const void *)s->d_hashes;
         fa.off = s->d_off;
@@ -1058,35 +1094,49 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         fa.xcd_map = getenv("RK_INDEX_XCD") ? atoi(getenv("RK_INDEX_XCD")) : 1;
         fa.nb = 1u << B;
         fa.n_chunks = (uint32_t)((H + kPartChunk - 1) / kPartChunk);
+        fa.range_bits = tiles_mode ? range_bits : 0;
+        fa.range_id = 0;
+        // what a pass may hold: exactly H without ranges; with ranges an estimate + slack (a pass that exceeds it raises the overflow
+        // flag in k_part_starts and the kernels behind it stand still)
+        const uint64_t keys_cap = fa.range_bits ? std::min<uint64_t>(H, H_pass + H_pass / 4 + (1u << 20)) : H;
+        fa.keys_cap = keys_cap;
         DevBuf<uint32_t> chunk_first(ctx), matrix(ctx), total(ctx), bstart(ctx), ucount(ctx), ubase(ctx), tmp_uhash(ctx), tmp_upos(ctx), n_open(ctx), n_cov(ctx);
         DevBuf<unsigned long long> keys(ctx), tmp_uhash64(ctx), zeroed(ctx);
         DevBuf<uint2> self_raw(ctx);
         // tile records: unsorted (64 regions), binned by row block, the directory's proto entries
         DevBuf<uint32_t> bins(ctx), tb(ctx);
-        DevBuf<uint3> rec(ctx), brec(ctx);
+        DevBuf<uint3> brec(ctx);
         DevBuf<uint4> proto(ctx);
         DevBuf<unsigned long long> level_start(ctx);
         const bool wide = idx->wide;
+        const size_t nb1 = (size_t)fa.nb + 1;
         RK_HIP(ctx, chunk_first.alloc((size_t)fa.n_chunks + 1));
         RK_HIP(ctx, matrix.alloc((size_t)fa.n_chunks * fa.nb));
         RK_HIP(ctx, total.alloc(fa.nb));
-        RK_HIP(ctx, bstart.alloc((size_t)fa.nb + 1));
-        RK_HIP(ctx, ucount.alloc(fa.nb));
-        RK_HIP(ctx, ubase.alloc((size_t)fa.nb + 1));
+        RK_HIP(ctx, bstart.alloc(nb1 * passes));   // (per pass: the list heads of a pass are placed while the next one partitions)
+        RK_HIP(ctx, ucount.alloc(nb1 * passes));
+        RK_HIP(ctx, ubase.alloc(nb1 * passes));
         if (wide) RK_HIP(ctx, tmp_uhash64.alloc(H));
         else RK_HIP(ctx, tmp_uhash.alloc(H));
         RK_HIP(ctx, tmp_upos.alloc(H));
-        RK_HIP(ctx, keys.alloc(H));
+        RK_HIP(ctx, keys.alloc(keys_cap));
         uint64_t rec_cap = 0, tile_cap = 0, slot_cap = 0;
         uint32_t region_cap = 0;
+        const bool sort_here = tiles_mode && n_shards == 1;   // (a shard's records leave for the exchange: rk_index_join_shard sorts what arrives)
         if (tiles_mode) {
-            rec_cap = ctx->sw_tile_rec_cap ? ctx->sw_tile_rec_cap : H / 2 + 65536;
+            // related lists write ~0.15-0.3 records per posting; chance collisions of a crowded hash space add H x lambda / 2
+            // (lambda = postings per hash value: 500,000 genomes in 28 bits share every value twice over)
+            const double lambda = hash_bits < 48 ? (double)H / (double)(1ULL << hash_bits) : 0.0;
+            rec_cap = ctx->sw_tile_rec_cap ? ctx->sw_tile_rec_cap : (uint64_t)((double)(H / n_shards) * (0.5 + 0.6 * lambda)) + 65536;
             rec_cap = std::min<uint64_t>(rec_cap, 0x7FFF0000ULL);
             region_cap = (uint32_t)((rec_cap + kRecRegions - 1) / kRecRegions);
             rec_cap = (uint64_t)region_cap * kRecRegions;
+            RK_HIP(ctx, t_rec.alloc(rec_cap));
+            t_region_cap = region_cap;
+        }
+        if (sort_here) {
             tile_cap = std::min<uint64_t>(rec_cap, (uint64_t)n_blocks * (n_blocks + 1) / 2);
             slot_cap = rec_cap + tile_cap;   // (every tile from an even slot on)
-            RK_HIP(ctx, rec.alloc(rec_cap));
             RK_HIP(ctx, brec.alloc(rec_cap));
             RK_HIP(ctx, tb.alloc(2 * (size_t)n_blocks));
             RK_HIP(ctx, bins.alloc((size_t)n_blocks + 1));   // bin starts (the counts and cursors are in `zeroed`)
@@ -1097,25 +1147,25 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             RK_HIP(ctx, t_cols.alloc(slot_cap + 256));
             RK_HIP(ctx, t_dir_j.alloc(2 * tile_cap));
             RK_HIP(ctx, t_dir_c.alloc(2 * tile_cap));
-        } else {
+        }
+        if (!tiles_mode) {
             RK_HIP(ctx, self_raw.alloc(H));
             RK_HIP(ctx, n_open.alloc((size_t)N + 1));
             RK_HIP(ctx, n_cov.alloc((size_t)N + 1));
         }
         // everything the kernels expect zeroed, in one buffer and one fill (each fill is ~5 us on the stream): the result
-        // records, the cursors of the two-pass partition and of the tile sort
+        // records, where the postings of each pass start, the cursors of the two-pass partition (per pass) and of the tile sort
         const bool part2 = (getenv("RK_INDEX_PART2") ? atoi(getenv("RK_INDEX_PART2")) != 0 : true) && B >= 7 && low_bits + gb + fa.rb <= 64 - (int)kFineBits;
         const bool small_wgs = (fa.nb >> kFineBits) <= 128;   // several workgroups per chunk: they share its stretch through counters
-        const size_t z_res = 0, z_tres = z_res + (sizeof(BuildResult) + 7) / 8, z_cursor = z_tres + (sizeof(TileResult) + 7) / 8,
-                     z_taken = z_cursor + (part2 ? (fa.nb + 1) / 2 : 0),
-                     z_tcur = z_taken + (part2 && small_wgs ? ((size_t)fa.n_chunks * (fa.nb >> kFineBits) + 1) / 2 : 0),
-                     z_bins = z_tcur + (tiles_mode ? (sizeof(TileCursors) + 7) / 8 : 0),
-                     z_end = z_bins + (tiles_mode ? (size_t)n_blocks + 1 : 0);   // bin counts (u32[n_blocks + 1]) + bin cursors (u32[n_blocks])
+        const size_t w_cursor = part2 ? (fa.nb + 1) / 2 : 0, w_taken = part2 && small_wgs ? ((size_t)fa.n_chunks * (fa.nb >> kFineBits) + 1) / 2 : 0;
+        const size_t z_res = 0, z_tres = z_res + (sizeof(BuildResult) + 7) / 8, z_pass = z_tres + (sizeof(TileResult) + 7) / 8,
+                     z_cursor = z_pass + passes + 1, z_taken = z_cursor + w_cursor * passes, z_tcur = z_taken + w_taken * passes,
+                     z_bins = z_tcur + (sort_here ? (sizeof(TileCursors) + 7) / 8 : 0),
+                     z_end = z_bins + (sort_here ? (size_t)n_blocks + 1 : 0);   // bin counts (u32[n_blocks + 1]) + bin cursors (u32[n_blocks])
         RK_HIP(ctx, zeroed.alloc(z_end));   // (zeroed by k_chunk_first, the first launch)
         BuildResult *const fres = reinterpret_cast<BuildResult *>(zeroed.p + z_res);
         TileResult *const tres = reinterpret_cast<TileResult *>(zeroed.p + z_tres);
-        uint32_t *const fine_cursor = reinterpret_cast<uint32_t *>(zeroed.p + z_cursor);
-        uint32_t *const seg_taken = reinterpret_cast<uint32_t *>(zeroed.p + z_taken);
+        unsigned long long *const pass_base = zeroed.p + z_pass;   // [passes + 1]: postings before pass p; the last one = all of them
         const size_t part_lds = (size_t)fa.nb * 4 + 2 * kStageGenomes * 8;   // bucket counters + the chunk's genome bounds
         if (part_lds > 48 * 1024) {
             RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_hist<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
@@ -1125,74 +1175,138 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         }
         hipLaunchKernelGGL(k_chunk_first, dim3(blocks_for(std::max<uint64_t>((uint64_t)fa.n_chunks + 1, z_end))), dim3(kThreads), 0, st, s->d_off, N, fa.n_chunks,
                            chunk_first.p, zeroed.p, (uint32_t)z_end);
-        if (wide) hipLaunchKernelGGL(k_part_hist<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, fres);
-        else hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, fres);
-        hipLaunchKernelGGL(k_part_colscan, dim3((fa.nb + 63) / 64), dim3(1024), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
-        hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart.p, fres);
-        // the partition itself: two coalescing passes (rk_index_fast.inc), or one scattering pass
         DevBuf<unsigned long long> mid(ctx);
-        if (part2) {
-            RK_HIP(ctx, mid.alloc(H));
+        if (part2) RK_HIP(ctx, mid.alloc(keys_cap));
+        const int emit_t = getenv("RK_INDEX_EMIT_T") ? atoi(getenv("RK_INDEX_EMIT_T")) : 512;
+        const bool narrow = low_bits + gb <= 32;  // (hash_low, genome) fits 32 bits
+        for (uint32_t pass = 0; pass < passes; pass++) {
+            fa.range_id = (shard_id << pass_bits) | pass;
+            uint32_t *const bstart_p = bstart.p + nb1 * pass, *const ucount_p = ucount.p + nb1 * pass, *const ubase_p = ubase.p + nb1 * pass;
+            uint32_t *const fine_cursor = reinterpret_cast<uint32_t *>(zeroed.p + z_cursor + w_cursor * pass);
+            uint32_t *const seg_taken = reinterpret_cast<uint32_t *>(zeroed.p + z_taken + w_taken * pass);
+            if (wide) hipLaunchKernelGGL(k_part_hist<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, fres);
+            else hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, fres);
+            hipLaunchKernelGGL(k_part_colscan, dim3((fa.nb + 63) / 64), dim3(1024), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
+            hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart_p, fres, pass_base + pass, (unsigned long long)keys_cap);
+            // the partition itself: two coalescing passes (rk_index_fast.inc), or one scattering pass
+            if (part2) {
 #define RK_COARSE(TT, HT, GRID)                                                                                                              \
     do {                                                                                                                                     \
         RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_coarse<TT, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds(TT))); \
-        hipLaunchKernelGGL((k_part_coarse<TT, HT>), dim3(GRID), dim3(TT), part2_lds(TT), st, fa, chunk_first.p, matrix.p, bstart.p, seg_taken, mid.p); \
+        hipLaunchKernelGGL((k_part_coarse<TT, HT>), dim3(GRID), dim3(TT), part2_lds(TT), st, fa, chunk_first.p, matrix.p, bstart_p, seg_taken, mid.p, fres); \
     } while (0)
-            if (small_wgs) { if (wide) RK_COARSE(256, uint64_t, fa.n_chunks * 4); else RK_COARSE(256, uint32_t, fa.n_chunks * 4); }
-            else { if (wide) RK_COARSE(1024, uint64_t, fa.n_chunks); else RK_COARSE(1024, uint32_t, fa.n_chunks); }
+                if (small_wgs) { if (wide) RK_COARSE(256, uint64_t, fa.n_chunks * 4); else RK_COARSE(256, uint32_t, fa.n_chunks * 4); }
+                else { if (wide) RK_COARSE(1024, uint64_t, fa.n_chunks); else RK_COARSE(1024, uint32_t, fa.n_chunks); }
 #undef RK_COARSE
-            hipLaunchKernelGGL(k_part_fine, dim3(fa.nb >> kFineBits, 16), dim3(kPartThreads), 0, st, fa, bstart.p, mid.p, keys.p, fine_cursor);
-        } else if (wide) {
-            hipLaunchKernelGGL(k_part_scatter<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
-        } else {
-            hipLaunchKernelGGL(k_part_scatter<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart.p, keys.p);
-        }
-        want_tab = !tiles_mode;
-        RK_TRY(enqueue_renumbering());   // (behind the partition's launches in the host's queue, beside them on the device)
-        // the internal order is needed from here on: the translation table alone for tile records (sizes and offsets in internal
-        // order are still on their way on the second stream: joined in front of the row sort), everything for slice records
-        if (tiles_mode && inv_recorded && !joined) RK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_inv, 0));
-        else RK_TRY(join());
-        if (!tiles_mode && inv && !rl_tab.p) {   // (second attempt: the renumbering ran for tile records, without the table)
-            RK_HIP(ctx, rl_tab.alloc(N));
-            hipLaunchKernelGGL(k_emit_table, dim3(blocks_for(N)), dim3(kThreads), 0, st, inv, idx->d_src_off, N, rl_tab.p);
-        }
-        const int emit_t = getenv("RK_INDEX_EMIT_T") ? atoi(getenv("RK_INDEX_EMIT_T")) : 512;
-        const bool narrow = low_bits + gb <= 32;  // (hash_low, genome) fits 32 bits
-        TileSortArgs ta;
-        memset(&ta, 0, sizeof ta);
-        if (tiles_mode) {
-            TileEmitArgs ea;
-            ea.keys = keys.p;
-            ea.bstart = bstart.p;
-            ea.inv = inv;
-            ea.low_bits = low_bits;
-            ea.gb = gb;
-            ea.rb = 0;
-            ea.nb = fa.nb;
-            ea.postings = idx->d_postings;
-            ea.tmp_uhash = tmp_uhash.p;
-            ea.tmp_uhash64 = wide ? tmp_uhash64.p : nullptr;
-            ea.tmp_upos = tmp_upos.p;
-            ea.ucount = ucount.p;
-            ea.rec = rec.p;
-            ea.cur = reinterpret_cast<TileCursors *>(zeroed.p + z_tcur);
-            ea.region_cap = region_cap;
-            ea.tres = tres;
-            ea.xcd_map = fa.xcd_map;
-            ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
-            if (ea.debug) {  // developer ablations leave stages out: whatever they do not write must still be harmless downstream
-                RK_HIP(ctx, hipMemsetAsync(ucount.p, 0, (size_t)fa.nb * 4, st));
-                RK_HIP(ctx, hipMemsetAsync(tmp_upos.p, 0, H * 4, st));
+                hipLaunchKernelGGL(k_part_fine, dim3(fa.nb >> kFineBits, 16), dim3(kPartThreads), 0, st, fa, bstart_p, mid.p, keys.p, fine_cursor, fres);
+            } else if (wide) {
+                hipLaunchKernelGGL(k_part_scatter<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart_p, keys.p, fres);
+            } else {
+                hipLaunchKernelGGL(k_part_scatter<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart_p, keys.p, fres);
             }
+            if (pass == 0) {
+                want_tab = !tiles_mode;
+                RK_TRY(enqueue_renumbering());   // (behind the partition's launches in the host's queue, beside them on the device)
+                // the internal order is needed from here on: the translation table alone for tile records (sizes and offsets in internal
+                // order are still on their way on the second stream: joined in front of the row sort), everything for slice records
+                if (tiles_mode && inv_recorded && !joined) RK_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_inv, 0));
+                else RK_TRY(join());
+                if (!tiles_mode && inv && !rl_tab.p) {   // (second attempt: the renumbering ran for tile records, without the table)
+                    RK_HIP(ctx, rl_tab.alloc(N));
+                    hipLaunchKernelGGL(k_emit_table, dim3(blocks_for(N)), dim3(kThreads), 0, st, inv, idx->d_src_off, N, rl_tab.p);
+                }
+            }
+            if (tiles_mode) {
+                TileEmitArgs ea;
+                ea.keys = keys.p;
+                ea.bstart = bstart_p;
+                ea.inv = inv;
+                ea.low_bits = low_bits;
+                ea.gb = gb;
+                ea.rb = 0;
+                ea.nb = fa.nb;
+                ea.postings = idx->d_postings;
+                ea.tmp_uhash = tmp_uhash.p;
+                ea.tmp_uhash64 = wide ? tmp_uhash64.p : nullptr;
+                ea.tmp_upos = tmp_upos.p;
+                ea.ucount = ucount_p;
+                ea.rec = t_rec.p;
+                ea.region_cap = region_cap;
+                ea.pass_base = pass_base + pass;
+                ea.hash_base = fa.range_bits ? ((unsigned long long)fa.range_id << eff_bits) : 0ULL;
+                ea.n_dest = n_shards;
+                ea.stop = fa.range_bits ? fres : nullptr;
+                ea.tres = tres;
+                ea.xcd_map = fa.xcd_map;
+                ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
+                if (ea.debug) {  // developer ablations leave stages out: whatever they do not write must still be harmless downstream
+                    RK_HIP(ctx, hipMemsetAsync(ucount_p, 0, (size_t)fa.nb * 4, st));
+                    RK_HIP(ctx, hipMemsetAsync(tmp_upos.p, 0, H * 4, st));
+                }
 #define RK_EMIT(TT) do { if (narrow) hipLaunchKernelGGL((k_bucket_emit_tiles<TT, uint32_t>), dim3(fa.nb), dim3(TT), 0, st, ea); \
                          else hipLaunchKernelGGL((k_bucket_emit_tiles<TT, unsigned long long>), dim3(fa.nb), dim3(TT), 0, st, ea); } while (0)
-            if (emit_t == 256) RK_EMIT(256);
-            else if (emit_t == 1024) RK_EMIT(1024);
-            else RK_EMIT(512);
+                if (emit_t == 256) RK_EMIT(256);
+                else if (emit_t == 1024) RK_EMIT(1024);
+                else RK_EMIT(512);
 #undef RK_EMIT
-            ta.rec = rec.p;
-            ta.cur = ea.cur;
+            } else {
+                EmitArgs ea;
+                ea.keys = keys.p;
+                ea.bstart = bstart_p;
+                ea.off_new = idx->d_src_off;
+                ea.inv = inv;
+                ea.tab = inv ? rl_tab.p : nullptr;
+                ea.low_bits = low_bits;
+                ea.gb = gb;
+                ea.rb = rb;
+                ea.nb = fa.nb;
+                ea.postings = idx->d_postings;
+                ea.tmp_uhash = tmp_uhash.p;
+                ea.tmp_uhash64 = wide ? tmp_uhash64.p : nullptr;
+                ea.tmp_upos = tmp_upos.p;
+                ea.ucount = ucount_p;
+                ea.self_raw = self_raw.p;
+                ea.res = fres;
+                ea.xcd_map = fa.xcd_map;
+                ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
+                if (ea.debug) {  // developer ablations leave stages out: whatever they do not write must still be harmless downstream
+                    RK_HIP(ctx, hipMemsetAsync(ucount_p, 0, (size_t)fa.nb * 4, st));
+                    RK_HIP(ctx, hipMemsetAsync(self_raw.p, 0, H * sizeof(uint2), st));
+                    RK_HIP(ctx, hipMemsetAsync(tmp_upos.p, 0, H * 4, st));
+                }
+#define RK_EMIT(TT) do { if (narrow) hipLaunchKernelGGL((k_bucket_emit<TT, uint32_t>), dim3(fa.nb), dim3(TT), 0, st, ea); \
+                         else hipLaunchKernelGGL((k_bucket_emit<TT, unsigned long long>), dim3(fa.nb), dim3(TT), 0, st, ea); } while (0)
+                if (emit_t == 256) RK_EMIT(256);
+                else if (emit_t == 1024) RK_EMIT(1024);
+                else RK_EMIT(512);
+#undef RK_EMIT
+            }
+            // the list heads (scan + placement) hang on the emission alone: they go to the second stream (one pass) and run beside
+            // the rows / the tile sort; with several passes they stay in line (the next pass's partition is the bigger job)
+            hipStream_t sh = st;
+            const bool heads_aside = forked && passes == 1;
+            if (heads_aside) {
+                RK_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+                RK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                sh = ctx->stream2;
+            }
+            hipLaunchKernelGGL(k_heads_scan, dim3(1), dim3(1024), 0, sh, ucount_p, fa.nb, ubase_p, fres);
+            if (wide)
+                hipLaunchKernelGGL(k_heads_place<unsigned long long>, dim3(fa.nb), dim3(kThreads), 0, sh, tmp_uhash64.p, tmp_upos.p, bstart_p, ucount_p, ubase_p,
+                                   fa.nb, pass_base + pass, (unsigned long long *)idx->d_uhash64, idx->d_upos);
+            else
+                hipLaunchKernelGGL(k_heads_place<uint32_t>, dim3(fa.nb), dim3(kThreads), 0, sh, tmp_uhash.p, tmp_upos.p, bstart_p, ucount_p, ubase_p, fa.nb,
+                                   pass_base + pass, idx->d_uhash, idx->d_upos);
+            if (heads_aside) {
+                RK_HIP(ctx, hipEventRecord(ctx->ev_join, sh));
+                joined = false;
+            }
+        }
+        TileSortArgs ta;
+        memset(&ta, 0, sizeof ta);
+        if (sort_here) {
+            ta.rec = t_rec.p;
+            ta.cur = reinterpret_cast<TileCursors *>(zeroed.p + z_tcur);
             ta.region_cap = region_cap;
             ta.n_blocks = n_blocks;
             ta.bin_count = reinterpret_cast<uint32_t *>(zeroed.p + z_bins);
@@ -1210,68 +1324,8 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
             ta.dir[0] = t_dir_j.p;
             ta.dir[1] = t_dir_c.p;
             ta.tres = tres;
-        } else {
-            EmitArgs ea;
-            ea.keys = keys.p;
-            ea.bstart = bstart.p;
-            ea.off_new = idx->d_src_off;
-            ea.inv = inv;
-            ea.tab = inv ? rl_tab.p : nullptr;
-            ea.low_bits = low_bits;
-            ea.gb = gb;
-            ea.rb = rb;
-            ea.nb = fa.nb;
-            ea.postings = idx->d_postings;
-            ea.tmp_uhash = tmp_uhash.p;
-            ea.tmp_uhash64 = wide ? tmp_uhash64.p : nullptr;
-            ea.tmp_upos = tmp_upos.p;
-            ea.ucount = ucount.p;
-            ea.self_raw = self_raw.p;
-            ea.res = fres;
-            ea.xcd_map = fa.xcd_map;
-            ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
-            if (ea.debug) {  // developer ablations leave stages out: whatever they do not write must still be harmless downstream
-                RK_HIP(ctx, hipMemsetAsync(ucount.p, 0, (size_t)fa.nb * 4, st));
-                RK_HIP(ctx, hipMemsetAsync(self_raw.p, 0, H * sizeof(uint2), st));
-                RK_HIP(ctx, hipMemsetAsync(tmp_upos.p, 0, H * 4, st));
-            }
-#define RK_EMIT(TT) do { if (narrow) hipLaunchKernelGGL((k_bucket_emit<TT, uint32_t>), dim3(fa.nb), dim3(TT), 0, st, ea); \
-                         else hipLaunchKernelGGL((k_bucket_emit<TT, unsigned long long>), dim3(fa.nb), dim3(TT), 0, st, ea); } while (0)
-            if (emit_t == 256) RK_EMIT(256);
-            else if (emit_t == 1024) RK_EMIT(1024);
-            else RK_EMIT(512);
-#undef RK_EMIT
-        }
-        // the list heads (scan + placement) and the rows / tile records both hang on the emission alone: the heads go to the
-        // second stream, the rest stays here
-        hipStream_t sh = st;
-        if (forked) {
-            RK_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
-            RK_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            sh = ctx->stream2;
-        }
-        hipLaunchKernelGGL(k_heads_scan, dim3(1), dim3(1024), 0, sh, ucount.p, fa.nb, ubase.p, fres);
-        if (wide)
-            hipLaunchKernelGGL(k_heads_place<unsigned long long>, dim3(fa.nb), dim3(kThreads), 0, sh, tmp_uhash64.p, tmp_upos.p, bstart.p, ucount.p, ubase.p,
-                               fa.nb, (uint32_t)H, (unsigned long long *)idx->d_uhash64, idx->d_upos);
-        else
-            hipLaunchKernelGGL(k_heads_place<uint32_t>, dim3(fa.nb), dim3(kThreads), 0, sh, tmp_uhash.p, tmp_upos.p, bstart.p, ucount.p, ubase.p, fa.nb,
-                               (uint32_t)H, idx->d_uhash, idx->d_upos);
-        if (forked) {
-            RK_HIP(ctx, hipEventRecord(ctx->ev_join, sh));
-            joined = false;
-        }
-        if (tiles_mode) {
-            const size_t hist_lds = (size_t)n_blocks * 4;
-            hipLaunchKernelGGL(k_trec_count, dim3(kRecRegions, kRecParts), dim3(512), hist_lds, st, ta);
-            hipLaunchKernelGGL(k_trec_starts, dim3(1), dim3(1024), 0, st, ta);
-            hipLaunchKernelGGL(k_trec_scatter, dim3(kRecRegions, kRecParts), dim3(512), hist_lds, st, ta);
-            RK_TRY(join());   // (the blocks' smallest sketches come from the second stream; by now also the list heads)
-            RK_HIP(ctx, hipFuncSetAttribute((const void *)k_trec_rowsort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowsort_lds(n_blocks)));
-            hipLaunchKernelGGL(k_trec_rowsort, dim3(n_blocks), dim3(512), rowsort_lds(n_blocks), st, ta);
-            hipLaunchKernelGGL(k_tdir_scan, dim3(1), dim3(1024), 0, st, ta);
-            hipLaunchKernelGGL(k_tdir_place, dim3(n_blocks), dim3(256), 0, st, ta);
-        } else {
+            RK_TRY(launch_tile_sort(ctx, ta, st, [&]() { return join(); }));
+        } else if (!tiles_mode) {
             hipLaunchKernelGGL(k_row_counts2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, n_open.p, n_cov.p);
             hipLaunchKernelGGL(k_row_scan, dim3(1), dim3(1024), 0, st, n_open.p, n_cov.p, N, idx->d_self_off, idx->d_self_split, fres);
             hipLaunchKernelGGL(k_row_place2, dim3(wave_blocks), dim3(kThreads), 0, st, idx->d_src_off, N, self_raw.p, idx->d_self_off,
@@ -1279,22 +1333,25 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         }
         RK_HIP(ctx, hipGetLastError());
         RK_TRY(join());
-        {   // the one synchronisation of the build: both result records in one read-back
-            struct { BuildResult r; TileResult t; } both;
-            static_assert(sizeof(BuildResult) % 8 == 0 && sizeof(both) == sizeof(BuildResult) + sizeof(TileResult), "the two records lie back to back");
-            RK_TRY(rk_read_back(ctx, &both, fres, sizeof(both), st));
+        unsigned long long n_postings = 0;
+        {   // the one synchronisation of the build: both result records (and the postings of all passes) in one read-back
+            struct { BuildResult r; TileResult t; unsigned long long pass_base[257]; } both;
+            static_assert(sizeof(BuildResult) % 8 == 0 && offsetof(decltype(both), pass_base) == sizeof(BuildResult) + sizeof(TileResult), "the records lie back to back");
+            RK_TRY(rk_read_back(ctx, &both, fres, sizeof(BuildResult) + sizeof(TileResult) + ((size_t)passes + 1) * 8, st));
             r = both.r;
             tr = both.t;
+            n_postings = both.pass_base[passes];
         }
         if (ctx->sw_dist_debug)
-            fprintf(stderr, "[rk] index build: fast path flags %llu (B %d, low bits %d, genome bits %d, position bits %d)%s\n", r.flags, B, low_bits, gb, rb,
-                    tiles_mode ? (tr.overflow ? ", tile records overflowed" : ", tile records") : "");
+            fprintf(stderr, "[rk] index build: fast path flags %llu (B %d, low bits %d, genome bits %d, position bits %d; shard %u of %u, %u pass(es), %llu postings)%s\n",
+                    r.flags, B, low_bits, gb, rb, shard_id, n_shards, passes, n_postings, tiles_mode ? (tr.overflow ? ", tile records overflowed" : ", tile records") : "");
         if (r.flags == 0 && !(tiles_mode && tr.overflow)) built = true;
-        else if (r.flags) {   // a bucket beyond the LDS sort, or a hash outside the hash space: the general path decides
+        else if (r.flags) {   // a bucket beyond the LDS sort, a pass beyond its key buffer, or a hash outside the hash space: the general path decides
             fast_refused = true;
             r = BuildResult{0, 0, 0, 0, 0};
         }
-        if (built && tiles_mode) {
+        if (built && range_bits) idx->H = n_postings;   // (a shard: the postings of ITS hash range; all passes of one shard: == H)
+        if (built && sort_here) {
             idx->d_tile_contrib = t_contrib.release();
             idx->d_tile_rows = t_rows.release();
             idx->d_tile_cols = t_cols.release();
@@ -1308,11 +1365,22 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
                 for (int k = 0; k < kTileTable; k++) idx->tile_prefix[m][k] = tr.level_count[m][k];
             idx->tiles_ready = true;
             idx->tiles_from_build = true;
+            t_rec.reset();
             if (ctx->sw_dist_debug)
                 fprintf(stderr, "[rk] tiles from the build: %llu tiles, %llu records in %llu slots (capacity %llu), biggest tile %llu\n", tr.n_tiles, tr.n_records,
                         tr.n_slots, (unsigned long long)rec_cap, tr.max_records);
         }
+        if (built && tiles_mode && n_shards > 1) {   // the shard's records wait for the exchange (rk_index_shard_records / _pack)
+            idx->d_shard_rec = t_rec.release();
+            idx->shard_region_cap = t_region_cap;
+            idx->n_shards = n_shards;
+            idx->shard_id = shard_id;
+            for (uint32_t q = 0; q < kRecRegions; q++) idx->shard_rec_count[q] = tr.rec_count[q];
+        }
     }
+    if (!built && n_shards > 1)
+        return rk_fail(ctx, RK_ERR_UNSUPPORTED, "rk_index_build_shard: the bucket sort refused this collection (flags %s: a bucket or a pass beyond its "
+                                                "buffer, a hash outside the hash space, or tile records beyond their capacity)", tr.overflow ? "tile overflow" : "bucket / key overflow");
     if (!built) {   // (no tile records after all)
         t_contrib.reset();
         t_rows.reset();
@@ -1414,6 +1482,159 @@ int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **
         idx->spread_known = 1;
     }
     set_dir_shape(idx);
+    guard.p = nullptr;
+    *out = idx;
+    return RK_OK;
+}
+
+// ---- the exchange of a sharded build -----------------------------------------------------------------------------
+namespace {
+struct PackArgs {
+    unsigned long long dst[kRecRegions];   // where region q's records go in the send buffer
+    unsigned long long cnt[kRecRegions];
+};
+// one workgroup row per region: its valid records to their place in the send buffer (contiguous by destination shard)
+__global__ void k_shard_pack(const uint3 *rec, uint32_t region_cap, PackArgs pa, uint3 *out)
+{
+    const uint32_t q = blockIdx.y;
+    const unsigned long long n = pa.cnt[q];
+    const uint3 *src = rec + (size_t)q * region_cap;
+    uint3 *dst = out + pa.dst[q];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// the received records as kRecRegions equal virtual regions for the tile sort: region q holds records [q * cap, min(n, (q + 1) * cap))
+__global__ void k_virtual_regions(unsigned long long n, uint32_t cap, unsigned long long *rec_count)
+{
+    const uint32_t q = threadIdx.x;
+    if (q >= kRecRegions) return;
+    const unsigned long long lo = (unsigned long long)q * cap;
+    rec_count[q] = n > lo ? min((unsigned long long)cap, n - lo) : 0ULL;
+}
+}  // namespace
+
+int rk_index_shard_records(const rk_index *idx, uint64_t *counts_out)
+{
+    if (!idx || !counts_out) return RK_ERR_ARG;
+    if (!idx->d_shard_rec || !idx->n_shards) return rk_fail(idx->ctx, RK_ERR_ARG, "not a shard of a sharded build (rk_index_build_shard)");
+    const uint32_t sub = kRecRegions / idx->n_shards;
+    for (uint32_t d = 0; d < idx->n_shards; d++) {
+        counts_out[d] = 0;
+        for (uint32_t q = d * sub; q < (d + 1) * sub; q++) counts_out[d] += idx->shard_rec_count[q];
+    }
+    return RK_OK;
+}
+
+int rk_index_shard_pack(const rk_index *idx, void *send_dev, void *stream_v)
+{
+    if (!idx || !send_dev) return RK_ERR_ARG;
+    rk_ctx *ctx = idx->ctx;
+    if (!idx->d_shard_rec || !idx->n_shards) return rk_fail(ctx, RK_ERR_ARG, "not a shard of a sharded build (rk_index_build_shard)");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    PackArgs pa;
+    unsigned long long at = 0;
+    for (uint32_t q = 0; q < kRecRegions; q++) {   // (regions are numbered destination-major)
+        pa.dst[q] = at;
+        pa.cnt[q] = idx->shard_rec_count[q];
+        at += pa.cnt[q];
+    }
+    if (at) hipLaunchKernelGGL(k_shard_pack, dim3(64, kRecRegions), dim3(256), 0, (hipStream_t)stream_v, idx->d_shard_rec, idx->shard_region_cap, pa, (uint3 *)send_dev);
+    RK_HIP(ctx, hipGetLastError());
+    return RK_OK;
+}
+
+int rk_index_join_shard(rk_ctx *ctx, const rk_index *part, const void *recv_dev, uint64_t n_records, rk_index **out)
+{
+    if (!ctx || !part || !out || (!recv_dev && n_records)) return RK_ERR_ARG;
+    *out = nullptr;
+    if (!part->d_src_off || !part->d_sizes || !part->n_ref || part->ctx != ctx)
+        return rk_fail(ctx, RK_ERR_ARG, "rk_index_join_shard needs an index built on this context (rk_index_build_shard) for the genomes' sizes and order");
+    if (n_records >= 0x7FFF0000ULL) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "more than 2^31 tile records for one shard");
+    RK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t N = part->n_ref, n_blocks = (N + 31) / 32;
+    if (n_blocks > kTileMaxBlocks) return rk_fail(ctx, RK_ERR_UNSUPPORTED, "more than %u genomes", kTileMaxBlocks * 32);
+    rk_index *idx = new (std::nothrow) rk_index;
+    if (!idx) return RK_ERR_NOMEM;
+    struct Guard { rk_index *p; ~Guard() { if (p) rk_index_free(p); } } guard{idx};
+    idx->ctx = ctx;
+    idx->n_ref = N;
+    idx->hash_bits = part->hash_bits;
+    idx->wide = part->wide;
+    idx->ref_sets = true;
+    idx->max_src_size = part->max_src_size;
+    idx->max_ref_size = part->max_ref_size;
+    idx->min_ref_size = part->min_ref_size;
+    idx->slices_refused = true;   // (a join-only index: tile records of this shard's rows, no postings)
+    RK_TRY(pool_array(ctx, &idx->d_sizes, (size_t)N + 1));
+    RK_TRY(pool_array(ctx, &idx->d_src_off, (size_t)N + 1));
+    RK_TRY(pool_array(ctx, &idx->d_blk_min, (size_t)n_blocks));
+    RK_HIP(ctx, hipMemcpyAsync(idx->d_sizes, part->d_sizes, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+    RK_HIP(ctx, hipMemcpyAsync(idx->d_src_off, part->d_src_off, ((size_t)N + 1) * 8, hipMemcpyDeviceToDevice, st));
+    if (part->relabeled && part->d_orig) {
+        RK_TRY(pool_array(ctx, &idx->d_orig, (size_t)N + 1));
+        RK_HIP(ctx, hipMemcpyAsync(idx->d_orig, part->d_orig, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+        idx->relabeled = true;
+    }
+    hipLaunchKernelGGL(k_blk_min_sizes, dim3(blocks_for(n_blocks)), dim3(kThreads), 0, st, idx->d_sizes, N, n_blocks, idx->d_blk_min);
+    const uint32_t region_cap = (uint32_t)std::max<uint64_t>(1, (n_records + kRecRegions - 1) / kRecRegions);
+    const uint64_t tile_cap = std::max<uint64_t>(1, std::min<uint64_t>(n_records, (uint64_t)n_blocks * (n_blocks + 1) / 2)), slot_cap = n_records + tile_cap;
+    DevBuf<uint2> t_contrib(ctx);
+    DevBuf<uint32_t> t_rows(ctx), t_cols(ctx), bins(ctx), tb(ctx);
+    DevBuf<uint4> t_dir_j(ctx), t_dir_c(ctx), proto(ctx);
+    DevBuf<uint3> brec(ctx);
+    DevBuf<unsigned long long> level_start(ctx), zeroed(ctx);
+    RK_HIP(ctx, brec.alloc(std::max<uint64_t>(1, n_records)));
+    RK_HIP(ctx, tb.alloc(2 * (size_t)n_blocks));
+    RK_HIP(ctx, bins.alloc((size_t)n_blocks + 1));
+    RK_HIP(ctx, proto.alloc(2 * tile_cap));
+    RK_HIP(ctx, level_start.alloc(2 * (kTileTable + 1)));
+    RK_HIP(ctx, t_contrib.alloc(slot_cap + 256));
+    RK_HIP(ctx, t_rows.alloc(slot_cap + 256));
+    RK_HIP(ctx, t_cols.alloc(slot_cap + 256));
+    RK_HIP(ctx, t_dir_j.alloc(2 * tile_cap));
+    RK_HIP(ctx, t_dir_c.alloc(2 * tile_cap));
+    const size_t z_tres = 0, z_tcur = z_tres + (sizeof(TileResult) + 7) / 8, z_bins = z_tcur + (sizeof(TileCursors) + 7) / 8, z_end = z_bins + (size_t)n_blocks + 1;
+    RK_HIP(ctx, zeroed.alloc(z_end));
+    RK_HIP(ctx, hipMemsetAsync(zeroed.p, 0, z_end * 8, st));
+    TileResult *const tres = reinterpret_cast<TileResult *>(zeroed.p + z_tres);
+    hipLaunchKernelGGL(k_virtual_regions, dim3(1), dim3(64), 0, st, (unsigned long long)n_records, region_cap, &tres->rec_count[0]);
+    TileSortArgs ta;
+    memset(&ta, 0, sizeof ta);
+    ta.rec = (const uint3 *)recv_dev;
+    ta.cur = reinterpret_cast<TileCursors *>(zeroed.p + z_tcur);
+    ta.region_cap = region_cap;
+    ta.n_blocks = n_blocks;
+    ta.bin_count = reinterpret_cast<uint32_t *>(zeroed.p + z_bins);
+    ta.bin_cursor = ta.bin_count + n_blocks + 1;
+    ta.bin_start = bins.p;
+    ta.brec = brec.p;
+    ta.blk_min = idx->d_blk_min;
+    ta.contrib = t_contrib.p;
+    ta.rows = t_rows.p;
+    ta.cols = t_cols.p;
+    ta.tb_base = tb.p;
+    ta.tb_cnt = tb.p + n_blocks;
+    ta.proto = proto.p;
+    ta.level_start = level_start.p;
+    ta.dir[0] = t_dir_j.p;
+    ta.dir[1] = t_dir_c.p;
+    ta.tres = tres;
+    RK_TRY(launch_tile_sort(ctx, ta, st, []() { return RK_OK; }));
+    TileResult tr;
+    RK_TRY(rk_read_back(ctx, &tr, tres, sizeof(tr), st));
+    idx->d_tile_contrib = t_contrib.release();
+    idx->d_tile_rows = t_rows.release();
+    idx->d_tile_cols = t_cols.release();
+    idx->d_tile_dir[0] = t_dir_j.release();
+    idx->d_tile_dir[1] = t_dir_c.release();
+    idx->n_tile_slots = tr.n_slots;
+    idx->n_tiles = tr.n_tiles;
+    idx->n_tile_records = tr.n_records;
+    idx->tile_max_records = tr.max_records;
+    for (int m = 0; m < 2; m++)
+        for (int k = 0; k < kTileTable; k++) idx->tile_prefix[m][k] = tr.level_count[m][k];
+    idx->tiles_ready = true;
+    idx->tiles_from_build = true;
     guard.p = nullptr;
     *out = idx;
     return RK_OK;

@@ -216,6 +216,11 @@ struct rk_index {
     uint64_t n_tiles = 0, n_tile_records = 0;
     bool tiles_ready = false;
     bool tiles_from_build = false;   // the tile records came with rk_index_build (rk_index_tiles.inc), not from the lazy rk_tiles_build
+    // a SHARD of a multi-GPU build (rk_index_build_shard): the lists of one range of the hash space; its tile records, grouped by
+    // the shard that owns their row block, wait here for the exchange (rk_index_shard_records / rk_index_shard_pack)
+    uint3 *d_shard_rec = nullptr;
+    uint32_t shard_region_cap = 0, n_shards = 0, shard_id = 0;
+    unsigned long long shard_rec_count[64] = {};
     bool slices_refused = false;     // built without slice records on purpose (2^31 postings and more, RK_INDEX_NO_SELF): none on first use either
     bool tiles_unusable = false;     // rk_tiles_build found more records than its budget: the self join stays with the row kernels
     int spread_known = 0;            // 1: `spread` below is valid (rk_dist.hip self_uses_tiles)

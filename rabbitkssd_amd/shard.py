@@ -73,3 +73,72 @@ def gather_hits(local_hits, dist, dst=0):
         return None
     merged = np.concatenate([np.frombuffer(p, dtype=local_hits.dtype) for p in parts])
     return merged[np.lexsort((merged["col"], merged["row"]))]
+
+
+# ---- sharded build (round 5): hash ranges build, rows join, ONE all-to-all of 12-byte tile records in between ------------
+REC_BYTES = 12
+
+
+def exchange_records(send, send_counts, dist, device):
+    """all-to-all of tile records: `send` = this rank's records contiguous by destination (uint8 tensor, REC_BYTES each),
+    send_counts[d] = records for rank d.  Returns (recv uint8 tensor on `device`, records received).  RCCL: one
+    all_to_all_single on device memory; gloo (CPU rehearsal): the same collective on host copies, or -- where the backend has no
+    all-to-all -- one broadcast per source rank."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    counts = torch.tensor(send_counts, dtype=torch.int64)
+    table = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
+    if dist.get_backend() == "nccl":
+        table = [t.to(device) for t in table]
+        dist.all_gather(table, counts.to(device))
+        table = [t.cpu() for t in table]
+    else:
+        dist.all_gather(table, counts)
+    recv_counts = [int(table[r][rank]) for r in range(world)]
+    n_recv = sum(recv_counts)
+    in_split = [int(c) * REC_BYTES for c in send_counts]
+    out_split = [c * REC_BYTES for c in recv_counts]
+    if dist.get_backend() == "nccl":
+        recv = torch.empty(max(1, n_recv * REC_BYTES), dtype=torch.uint8, device=device)
+        dist.all_to_all_single(recv[: n_recv * REC_BYTES], send[: sum(in_split)], out_split, in_split)
+        return recv, n_recv
+    host = send[: sum(in_split)].cpu()
+    recv = torch.empty(n_recv * REC_BYTES, dtype=torch.uint8)
+    try:
+        dist.all_to_all_single(recv, host, out_split, in_split)
+    except Exception:  # noqa: BLE001 -- a backend without all-to-all: every rank's buffer travels whole, each takes its slice
+        at = 0
+        for r in range(world):
+            n_r = int(table[r].sum()) * REC_BYTES
+            buf = host if r == rank else torch.empty(n_r, dtype=torch.uint8)
+            dist.broadcast(buf, r)
+            lo = int(table[r][:rank].sum()) * REC_BYTES
+            recv[at:at + out_split[r]] = buf[lo:lo + out_split[r]]
+            at += out_split[r]
+    out = torch.empty(max(1, n_recv * REC_BYTES), dtype=torch.uint8, device=device)
+    out[: n_recv * REC_BYTES] = recv.to(device)
+    return out, n_recv
+
+
+def sharded_join_index(ctx, sketches, hash_bits, dist, device, stream=0):
+    """this rank's join-only index of a sharded all-vs-all: build the lists of its hash range, exchange the tile records, sort what
+    arrives (rk_index_build_shard -> rk_index_shard_records / _pack -> all-to-all -> rk_index_join_shard).  Returns
+    (join index, part index, seconds spent [build, exchange, join build], records sent, records received)."""
+    import time
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t0 = time.perf_counter()
+    part = ctx.index_build_shard(sketches, hash_bits, rank, world)
+    counts = part.shard_records(world)
+    send = torch.empty(max(1, sum(counts) * REC_BYTES), dtype=torch.uint8, device=device)
+    part.shard_pack(send.data_ptr(), stream)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    recv, n_recv = exchange_records(send, counts, dist, device)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    t2 = time.perf_counter()
+    join = ctx.index_join_shard(part, recv.data_ptr(), n_recv)
+    t3 = time.perf_counter()
+    return join, part, (t1 - t0, t2 - t1, t3 - t2), sum(counts), n_recv

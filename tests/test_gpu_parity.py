@@ -498,6 +498,79 @@ def test_tile_records_from_the_build_equal_the_lazily_built_ones(monkeypatch, st
     b.close()
 
 
+@pytest.mark.parametrize("strains,n,m,W", [(10, 3000, 300, 2), (10, 3000, 300, 8), (100, 2600, 200, 4), (36, 1296, 500, 8)])
+def test_sharded_build_and_join_equal_the_whole(monkeypatch, strains, n, m, W):
+    # (round 5) the all-vs-all sharded twice: every shard builds the posting lists of ONE range of the hash space
+    # (rk_index_build_shard) and groups their tile records by the shard that owns the row block; the records are exchanged (here:
+    # by slicing the send buffers of one process); every shard sorts what arrived (rk_index_join_shard) and joins ITS rows.
+    # The shards' postings, in range order, are the whole .dict; the union of their hits is the oracle's result; a hit belongs to
+    # the shard of its row block.
+    import torch
+    names, h, off = synth.clade_sketches(n, m, 26, strains_per_clade=strains, seed=700 + strains)
+    order = synth.genome_order(len(names), "shuffled", seed=W)
+    names, h, off = synth.permute_genomes(names, h, off, order)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    c = capi.Context(0)
+    sk = c.sketches_from_host(h, off)
+    parts = [c.index_build_shard(sk, 26, r, W) for r in range(W)]
+    assert sum(p.total for p in parts) == len(h)
+    assert np.array_equal(np.concatenate([p.export(want_counts=False)[0][: p.total] for p in parts]), postings)
+    for p in parts[1:]:
+        assert np.array_equal(p.order, parts[0].order)          # every shard computes the same internal genome order
+    with pytest.raises(Exception, match="rk_index_join_shard"):
+        c.dist_rows(parts[0], None, 1, 0, 20, 0.05)
+    sent = [p.shard_records(W) for p in parts]
+    bufs = []
+    for p, cnt in zip(parts, sent):
+        b = torch.empty(max(1, sum(cnt) * 12), dtype=torch.uint8, device="cuda")
+        p.shard_pack(b.data_ptr())
+        bufs.append(b)
+    torch.cuda.synchronize()
+    joins = []
+    for d in range(W):
+        chunks = [bufs[r][12 * sum(sent[r][:d]): 12 * sum(sent[r][:d + 1])] for r in range(W)]
+        recv = torch.cat(chunks) if sum(len(x) for x in chunks) else torch.empty(1, dtype=torch.uint8, device="cuda")
+        joins.append((c.index_join_shard(parts[d], recv.data_ptr(), sum(sent[r][d] for r in range(W))), recv))
+    whole = c.index_build(sk, 26)
+    assert sum(j.self_stats[3] for j, _ in joins) == (whole.self_stats[3] if whole.products & 2 else sum(sum(x) for x in sent))
+    for metric, D in ((0, 0.05), (1, 0.05), (0, 0.3), (0, 1.0)):
+        want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=8)
+        got = []
+        for d, (j, _) in enumerate(joins):
+            hits, _ = c.dist_rows(j, None, 1, metric, 20, D)
+            assert np.all(parts[0].shard_of(hits, W, 32) == d)
+            got.append(hits)
+        merged = np.concatenate(got)
+        assert_hits_equal(merged[np.lexsort((merged["col"], merged["row"]))], want)
+    del joins, parts, whole
+    c.close()
+
+
+@pytest.mark.parametrize("pass_bits", ["1", "3"])
+def test_index_build_in_several_passes_over_the_hash_space(monkeypatch, pass_bits):
+    # a collection with more postings than 2^15 buckets hold is built range by range of the hash space, the postings of a pass
+    # behind those of the pass before (RK_INDEX_PASS_BITS forces it on a small one): same .dict / .index, same hits
+    names, h, off = synth.clade_sketches(3000, 300, 26, seed=41, tiny=2)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    monkeypatch.setenv("RK_INDEX_PASS_BITS", pass_bits)
+    monkeypatch.setenv("RK_INDEX_TILES", "1")
+    c = capi.Context(0)
+    idx = c.index_build(c.sketches_from_host(h, off), 26)
+    assert idx.products == 6 and idx.built_fast and idx.total == len(h)
+    p2, c2 = idx.export()
+    assert np.array_equal(p2, postings) and np.array_equal(c2, counts)
+    for metric, D in ((0, 0.05), (1, 0.1), (0, 1.0)):
+        want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=4)
+        assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+    q = c.sketches_from_host(h[: int(off[64])], off[:65])   # explicit queries read the same postings
+    want, _ = ok.index_dist32(counts, 26, postings, sizes, h[: int(off[64])], off[:65], 0, 0, 20, 0.1, threads=4)
+    assert_hits_equal(c.dist_rows(idx, q, 0, 0, 20, 0.1)[0], want)
+    del idx, q
+    c.close()
+
+
 def test_tile_records_that_do_not_fit_fall_back_to_slice_records(monkeypatch):
     # the build's unsorted tile records have a fixed capacity (H / 2 + 64 K); a collection whose lists scatter over many blocks
     # overflows it: the index is then built with slice records after all (RK_TILE_REC_CAP forces it), same results; and the

@@ -158,3 +158,83 @@ def test_two_contexts_in_one_process_index_broadcast(tmp_path):
     want, _ = ok.index_dist32(counts, BITS, postings, np.diff(off).astype(np.uint32), h[int(off[250]):], q_off, 0, 1, 20, 0.3)
     assert len(want) > 250 and got["row"].tolist() == want["row"].tolist() and got["col"].tolist() == want["col"].tolist()
     assert np.array_equal(got["common"], want["common"])
+
+
+# --------------------------------------------------------------------------- sharded build: the exchange of tile records
+def _worker_exchange(rank, port, outdir):
+    """CPU tier: the all-to-all of 12-byte records between two gloo ranks (rank r sends 100 (d + 1) + 7 r records to rank d,
+    each stamped with its source, destination and number)"""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        counts = [100 * (d + 1) + 7 * rank for d in range(WORLD)]
+        recs = np.zeros((sum(counts), 3), dtype=np.uint32)
+        at = 0
+        for d, c in enumerate(counts):
+            recs[at:at + c, 0], recs[at:at + c, 1], recs[at:at + c, 2] = rank, d, np.arange(c)
+            at += c
+        send = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy())
+        recv, n = shard.exchange_records(send, counts, dist, torch.device("cpu"))
+        got = recv.numpy()[: n * shard.REC_BYTES].view(np.uint32).reshape(-1, 3)
+        want_n = sum(100 * (rank + 1) + 7 * r for r in range(WORLD))
+        assert n == want_n and np.all(got[:, 1] == rank)
+        at = 0
+        for r in range(WORLD):   # contiguous by source rank, in the order they were packed
+            c = 100 * (rank + 1) + 7 * r
+            assert np.all(got[at:at + c, 0] == r) and np.array_equal(got[at:at + c, 2], np.arange(c))
+            at += c
+        open(os.path.join(outdir, "ok%d" % rank), "w").write("%d" % n)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_record_exchange_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_exchange, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    assert int(open(tmp_path / "ok0").read()) == 207 and int(open(tmp_path / "ok1").read()) == 407
+
+
+def _worker_sharded_gpu(rank, port, outdir):
+    """two ranks share cuda:0: every rank holds the sketches, builds the posting lists of ITS half of the hash space, the tile
+    records travel in one all-to-all (through the host under gloo), every rank sorts what arrived and joins ITS rows; the union
+    of the hits is the oracle's unsharded result -- no index is replicated"""
+    import torch
+    import torch.distributed as dist
+    from rabbitkssd_amd import capi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        torch.cuda.set_device(0)
+        ctx = capi.Context(0)
+        names, h, off = synth.clade_sketches(1500, 120, BITS, strains_per_clade=40, seed=53)
+        sk = ctx.sketches_from_host(h, off)
+        join, part, secs, n_sent, n_recv = shard.sharded_join_index(ctx, sk, BITS, dist, torch.device("cuda", 0))
+        assert join.products == 6 and n_sent > 0 and n_recv > 0
+        mine, _ = ctx.dist_rows(join, None, 1, 0, 20, 0.1)
+        assert np.all(part.shard_of(mine, WORLD, shard.ROW_BLOCK) == rank)
+        merged = shard.gather_hits(mine, dist, 0)
+        if rank == 0:
+            postings, counts = ok.index_build32(h, off, BITS)
+            want, _ = ok.index_dist32(counts, BITS, postings, np.diff(off).astype(np.uint32), h, off, 1, 0, 20, 0.1)
+            assert len(want) > 1000 and len(merged) == len(want)
+            for f in ("row", "col", "common", "size0", "size1"):
+                assert np.array_equal(merged[f], want[f]), f
+            assert np.array_equal(merged["dist"], want["dist"])
+            open(os.path.join(outdir, "ok"), "w").write("%d" % len(merged))
+        del join, part
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_build_and_join_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_sharded_gpu, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    assert int(open(tmp_path / "ok").read()) > 1000
