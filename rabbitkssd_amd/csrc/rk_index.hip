@@ -913,7 +913,8 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
     int shard_bits = 0, pass_bits = 0;
     while ((1u << shard_bits) < n_shards) shard_bits++;
     const uint64_t H_shard = H / n_shards + (n_shards > 1 ? H / (8ULL * n_shards) + 4096 : 0);   // (estimate: the hashes are spread evenly)
-    while (pass_bits < 8 && (H_shard >> pass_bits) > ((uint64_t)kBucketTarget << kMaxBucketBits)) pass_bits++;
+    // (a pass may fill its 2^15 buckets to ~2,600 keys on average: the LDS sort holds 4,096, and every extra pass reads all hashes again)
+    while (pass_bits < 8 && (H_shard >> pass_bits) > (2600ULL << kMaxBucketBits)) pass_bits++;
     if (getenv("RK_INDEX_PASS_BITS")) pass_bits = std::max(0, std::min(7, atoi(getenv("RK_INDEX_PASS_BITS"))));   // (tests: several passes over a small collection)
     const int range_bits = shard_bits + pass_bits;
     const uint32_t n_pass = 1u << pass_bits;
@@ -1069,11 +1070,21 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
     DevBuf<uint4> t_dir_j(ctx), t_dir_c(ctx);
     DevBuf<uint3> t_rec(ctx);   // a shard's tile records, grouped by destination shard (they leave for the exchange unsorted)
     uint32_t t_region_cap = 0;
-    for (int attempt = 0; fast_ok && !built && attempt < 2; attempt++) {
-        // (second attempt: the tile records of the first did not fit their buffer -- lists scattered over many blocks -- and the
-        // index is built with slice records after all, where those can be had)
-        if (attempt == 1 && (fast_refused || !tr.overflow || !slices_ok)) break;
+    uint64_t rec_cap_retry = 0;   // tile records the first attempt asked for, had they fit
+    for (int attempt = 0; fast_ok && !built && attempt < 3; attempt++) {
+        // (the tile records of an attempt did not fit their buffer -- wide species, lists scattered over many blocks --: the
+        // attempt has counted what it needs, and the next one gets exactly that, within a budget of 6 records per posting; beyond
+        // it the index is built with slice records after all, where those can be had)
+        if (attempt >= 1 && (fast_refused || !tr.overflow)) break;
         if (attempt == 1) {
+            unsigned long long worst = 0;
+            for (uint32_t q = 0; q < kRecRegions; q++) worst = std::max<unsigned long long>(worst, tr.rec_count[q]);
+            rec_cap_retry = (worst + worst / 16 + 1024) * kRecRegions;
+            if (rec_cap_retry > 6 * (H / n_shards) + (1u << 22) || ctx->sw_tile_rec_cap) rec_cap_retry = 0;   // (RK_TILE_REC_CAP: a test forces the fallback)
+        }
+        if (attempt == 2 || (attempt == 1 && !rec_cap_retry)) {
+            if (!slices_ok) break;
+            if (!tiles_mode) break;
             tiles_mode = false;
             rk_pool_free(ctx, idx->d_blk_min);
             idx->d_blk_min = nullptr;
@@ -1104,7 +1115,7 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         DevBuf<unsigned long long> keys(ctx), tmp_uhash64(ctx), zeroed(ctx);
         DevBuf<uint2> self_raw(ctx);
         // tile records: unsorted (64 regions), binned by row block, the directory's proto entries
-        DevBuf<uint32_t> bins(ctx), tb(ctx);
+        DevBuf<uint32_t> bins(ctx), tb(ctx), big_list(ctx);
         DevBuf<uint3> brec(ctx);
         DevBuf<uint4> proto(ctx);
         DevBuf<unsigned long long> level_start(ctx);
@@ -1127,7 +1138,7 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
             // related lists write ~0.15-0.3 records per posting; chance collisions of a crowded hash space add H x lambda / 2
             // (lambda = postings per hash value: 500,000 genomes in 28 bits share every value twice over)
             const double lambda = hash_bits < 48 ? (double)H / (double)(1ULL << hash_bits) : 0.0;
-            rec_cap = ctx->sw_tile_rec_cap ? ctx->sw_tile_rec_cap : (uint64_t)((double)(H / n_shards) * (0.5 + 0.6 * lambda)) + 65536;
+            rec_cap = ctx->sw_tile_rec_cap ? ctx->sw_tile_rec_cap : rec_cap_retry ? rec_cap_retry : (uint64_t)((double)(H / n_shards) * (0.5 + 0.6 * lambda)) + 65536;
             rec_cap = std::min<uint64_t>(rec_cap, 0x7FFF0000ULL);
             region_cap = (uint32_t)((rec_cap + kRecRegions - 1) / kRecRegions);
             rec_cap = (uint64_t)region_cap * kRecRegions;
@@ -1159,7 +1170,7 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         const bool small_wgs = (fa.nb >> kFineBits) <= 128;   // several workgroups per chunk: they share its stretch through counters
         const size_t w_cursor = part2 ? (fa.nb + 1) / 2 : 0, w_taken = part2 && small_wgs ? ((size_t)fa.n_chunks * (fa.nb >> kFineBits) + 1) / 2 : 0;
         const size_t z_res = 0, z_tres = z_res + (sizeof(BuildResult) + 7) / 8, z_pass = z_tres + (sizeof(TileResult) + 7) / 8,
-                     z_cursor = z_pass + passes + 1, z_taken = z_cursor + w_cursor * passes, z_tcur = z_taken + w_taken * passes,
+                     z_big = z_pass + passes + 1, z_cursor = z_big + (passes + 1) / 2, z_taken = z_cursor + w_cursor * passes, z_tcur = z_taken + w_taken * passes,
                      z_bins = z_tcur + (sort_here ? (sizeof(TileCursors) + 7) / 8 : 0),
                      z_end = z_bins + (sort_here ? (size_t)n_blocks + 1 : 0);   // bin counts (u32[n_blocks + 1]) + bin cursors (u32[n_blocks])
         RK_HIP(ctx, zeroed.alloc(z_end));   // (zeroed by k_chunk_first, the first launch)
@@ -1179,6 +1190,11 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         if (part2) RK_HIP(ctx, mid.alloc(keys_cap));
         const int emit_t = getenv("RK_INDEX_EMIT_T") ? atoi(getenv("RK_INDEX_EMIT_T")) : 512;
         const bool narrow = low_bits + gb <= 32;  // (hash_low, genome) fits 32 bits
+        // buckets beyond the LDS sort (a hash shared by thousands of genomes) go to k_bucket_heavy: tile records, 32-bit sort keys
+        const bool big_ok = tiles_mode && narrow && !getenv("RK_INDEX_NO_HEAVY");
+        if (big_ok) RK_HIP(ctx, big_list.alloc((size_t)fa.nb * passes));
+        const size_t heavy_lds = (((size_t)n_blocks * 4 + (size_t)n_blocks * 2) + 15) & ~(size_t)15;
+        if (big_ok) RK_HIP(ctx, hipFuncSetAttribute((const void *)k_bucket_heavy<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heavy_lds));
         for (uint32_t pass = 0; pass < passes; pass++) {
             fa.range_id = (shard_id << pass_bits) | pass;
             uint32_t *const bstart_p = bstart.p + nb1 * pass, *const ucount_p = ucount.p + nb1 * pass, *const ubase_p = ubase.p + nb1 * pass;
@@ -1187,7 +1203,9 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
             if (wide) hipLaunchKernelGGL(k_part_hist<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, fres);
             else hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, fres);
             hipLaunchKernelGGL(k_part_colscan, dim3((fa.nb + 63) / 64), dim3(1024), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
-            hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart_p, fres, pass_base + pass, (unsigned long long)keys_cap);
+            uint32_t *const n_big_p = reinterpret_cast<uint32_t *>(zeroed.p + z_big) + pass;
+            hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart_p, fres, pass_base + pass, (unsigned long long)keys_cap,
+                               big_ok ? big_list.p + (size_t)fa.nb * pass : nullptr, n_big_p);
             // the partition itself: two coalescing passes (rk_index_fast.inc), or one scattering pass
             if (part2) {
 #define RK_COARSE(TT, HT, GRID)                                                                                                              \
@@ -1236,6 +1254,8 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
                 ea.hash_base = fa.range_bits ? ((unsigned long long)fa.range_id << eff_bits) : 0ULL;
                 ea.n_dest = n_shards;
                 ea.stop = fa.range_bits ? fres : nullptr;
+                ea.big_ok = big_ok ? 1 : 0;
+                ea.stop_rw = fres;
                 ea.tres = tres;
                 ea.xcd_map = fa.xcd_map;
                 ea.debug = getenv("RK_INDEX_DEBUG") ? atoi(getenv("RK_INDEX_DEBUG")) : 0;
@@ -1249,6 +1269,14 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
                 else if (emit_t == 1024) RK_EMIT(1024);
                 else RK_EMIT(512);
 #undef RK_EMIT
+                if (big_ok) {
+                    HeavyArgs ha;
+                    ha.e = ea;
+                    ha.big_list = big_list.p + (size_t)fa.nb * pass;
+                    ha.n_big = n_big_p;
+                    ha.n_blocks = n_blocks;
+                    hipLaunchKernelGGL(k_bucket_heavy<1024>, dim3((unsigned)std::max(1, ctx->num_cu)), dim3(1024), heavy_lds, st, ha);
+                }
             } else {
                 EmitArgs ea;
                 ea.keys = keys.p;

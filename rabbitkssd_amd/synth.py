@@ -160,3 +160,79 @@ def write_sketch_file(path, half_k, half_subk, drlevel, names, hashes, off):
         for g in range(n):
             f.write(enc[g])
             f.write(raw[4 * int(off[g]):4 * int(off[g + 1])].tobytes())
+
+
+# ---- large collections, generated on the device (round 5: the scale leg of bench.py) ----------------------------------
+def _mix64(torch, x):
+    """splitmix64 finaliser on int64 tensors (a counter-based generator: value = f(stream, id, position), nothing is stored)"""
+    x = (x ^ (x >> 30)) * -4658895280553007687   # 0xBF58476D1CE4E5B9
+    x = (x ^ ((x >> 27) & 0x1FFFFFFFFF)) * -7723592293110705685   # 0x94D049BB133111EB
+    return x ^ ((x >> 31) & 0x1FFFFFFFF)
+
+
+def scale_species_plan(n_genomes, seed=20261005, max_species=10000, zipf_a=2.0, min_size=200, max_size=3000):
+    """species of a large collection: sizes Zipf-distributed (1 .. max_species strains), every species with its own sketch
+    size, log-uniform in [min_size, max_size] (a sketch size follows the genome length: strains of a species agree).
+    Returns (species id of every genome int64[N], sketch size of every species int64[S])."""
+    rng = np.random.default_rng(seed)
+    sizes = []
+    left = n_genomes
+    while left > 0:
+        s = int(min(max_species, rng.zipf(zipf_a), left))
+        sizes.append(s)
+        left -= s
+    sizes = np.array(sizes, dtype=np.int64)
+    m = np.exp(rng.uniform(np.log(min_size), np.log(max_size), size=len(sizes))).astype(np.int64)
+    return np.repeat(np.arange(len(sizes), dtype=np.int64), sizes), m
+
+
+def scale_collection_torch(n_genomes, hash_bits=28, kmer_size=20, seed=20261005, device="cuda", max_species=10000, chunk_elems=1 << 26):
+    """A collection of `n_genomes` sketches generated ON THE DEVICE (torch): species by scale_species_plan; inside a species the
+    tree of strain_rates (lineages of 100 strains 0.026 from the ancestor, sub-lineages of 10 strains 0.006 from their lineage,
+    strain c 0.001 c from its sub-lineage); a hash of the level above survives with probability (1 - rate)^k, else it is replaced
+    by a fresh uniform value -- every value a function of (level, id, position) through a counter-based generator.  Per genome
+    the hashes are sorted and distinct.  Returns (hashes int32 tensor viewed as u32, off int64 tensor[N + 1], species int64[N])."""
+    import torch
+    species_np, m_np = scale_species_plan(n_genomes, seed, max_species)
+    species = torch.from_numpy(species_np).to(device)
+    m = torch.from_numpy(m_np).to(device)
+    first = torch.zeros(len(m_np), dtype=torch.int64, device=device)   # first genome of every species
+    first[1:] = torch.cumsum(torch.bincount(species, minlength=len(m_np)), 0)[:-1]
+    size = m[species]
+    rank = torch.arange(n_genomes, device=device) - first[species]      # strain number inside its species
+    space_mask = (1 << hash_bits) - 1
+    p_lin, p_sub = (1.0 - 0.026) ** kmer_size, (1.0 - 0.006) ** kmer_size
+
+    def rnd(stream, ident, pos):
+        return _mix64(torch, _mix64(torch, ident * 1000003 + stream * 7919 + seed) ^ (pos * -7046029254386353131))
+
+    def keep(r, p):   # p: float or tensor
+        return ((r >> 11) & 0xFFFFFF).to(torch.float32) < (p * 16777216.0)
+
+    out_h, sizes = [], torch.zeros(n_genomes, dtype=torch.int64, device=device)
+    start = 0
+    csum = torch.cumsum(size, 0)
+    while start < n_genomes:   # chunks of whole genomes
+        base = int(csum[start - 1].item()) if start else 0
+        stop = int(torch.searchsorted(csum, torch.tensor(base + chunk_elems, device=device)).item())
+        stop = max(start + 1, min(n_genomes, stop))
+        g = torch.repeat_interleave(torch.arange(start, stop, device=device), size[start:stop])
+        pos = torch.arange(len(g), device=device) - torch.repeat_interleave(csum[start:stop] - size[start:stop] - base, size[start:stop])
+        sp, rk = species[g], rank[g]
+        lin, sub = sp * 1024 + rk // 100, sp * 16384 + rk // 10
+        v = rnd(1, sp, pos)                                             # the species' ancestor
+        v = torch.where(keep(rnd(2, lin, pos), p_lin), v, rnd(3, lin, pos))
+        v = torch.where(keep(rnd(4, sub, pos), p_sub), v, rnd(5, sub, pos))
+        p_str = torch.pow(1.0 - 0.001 * (rk % 10).to(torch.float32), kmer_size)
+        v = torch.where(keep(rnd(6, g, pos), p_str), v, rnd(7, g, pos))
+        key = (g << hash_bits) | (v & space_mask)
+        key = torch.unique(key)                                         # sorted by (genome, hash), repeats dropped
+        gg = key >> hash_bits
+        sizes[start:stop] = torch.bincount(gg - start, minlength=stop - start)
+        out_h.append((key & space_mask).to(torch.int32))
+        del g, pos, sp, rk, lin, sub, v, key, gg
+        start = stop
+    hashes = torch.cat(out_h)
+    off = torch.zeros(n_genomes + 1, dtype=torch.int64, device=device)
+    off[1:] = torch.cumsum(sizes, 0)
+    return hashes, off, species

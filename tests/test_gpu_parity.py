@@ -571,6 +571,41 @@ def test_index_build_in_several_passes_over_the_hash_space(monkeypatch, pass_bit
     c.close()
 
 
+@pytest.mark.parametrize("bits,n,m,strains", [(26, 6000, 150, 3000), (20, 5000, 250, 2500), (24, 4500, 400, 1500)])
+def test_buckets_beyond_the_lds_sort(monkeypatch, bits, n, m, strains):
+    # a hash shared by thousands of genomes (a species of 1,500 - 3,000 strains) is a posting list that overflows a bucket of the
+    # in-LDS sort on its own: k_bucket_heavy builds such buckets slab by slab, single heavy lists through a bitmap over the genomes
+    # (26 / 24 bits: the sub-buckets are split by their remaining hash bits first; 20 bits: a sub-bucket IS one hash value).
+    # Until round 5 one such bucket sent the whole build to the device-wide sort (RK_INDEX_NO_HEAVY=1 still does).
+    names, h, off = synth.clade_sketches(n, m, bits, strains_per_clade=strains, seed=900 + strains)
+    postings, counts = ok.index_build32(h, off, bits)
+    sizes = np.diff(off).astype(np.uint32)
+    assert counts.max() > 1000
+    monkeypatch.setenv("RK_INDEX_TILES", "1")
+    c = capi.Context(0)
+    monkeypatch.setenv("RK_INDEX_NO_HEAVY", "1")
+    g = capi.Context(0)
+    sk = c.sketches_from_host(h, off)
+    idx = c.index_build(sk, bits)
+    old = g.index_build(g.sketches_from_host(h, off), bits)
+    assert idx.built_fast and idx.products == 6 and not old.built_fast
+    p2, c2 = idx.export()
+    assert np.array_equal(p2, postings) and np.array_equal(c2, counts)
+    assert np.array_equal(idx.order, old.order)
+    for metric, D in ((0, 0.05), (1, 0.02), (0, 1.0)):
+        want, _ = ok.index_dist32(counts, bits, postings, sizes, h, off, 1, metric, 20, D, threads=8)
+        assert len(want) > 10000
+        assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+    assert_hits_equal(g.dist_rows(old, None, 1, 0, 20, 0.05)[0], ok.index_dist32(counts, bits, postings, sizes, h, off, 1, 0, 20, 0.05, threads=8)[0])
+    # the same buckets in a sharded build
+    parts = [c.index_build_shard(sk, bits, r, 4) for r in range(4)]
+    assert np.array_equal(np.concatenate([p.export(want_counts=False)[0][: p.total] for p in parts]), postings)
+    assert sum(sum(p.shard_records(4)) for p in parts) == idx.self_stats[3]
+    del idx, old, parts
+    c.close()
+    g.close()
+
+
 def test_tile_records_that_do_not_fit_fall_back_to_slice_records(monkeypatch):
     # the build's unsorted tile records have a fixed capacity (H / 2 + 64 K); a collection whose lists scatter over many blocks
     # overflows it: the index is then built with slice records after all (RK_TILE_REC_CAP forces it), same results; and the

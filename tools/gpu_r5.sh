@@ -10,7 +10,7 @@ mkdir -p gpurun_out
 tests() { timeout -k 10 ${T:-900} python3 -m pytest tests -m gpu -x -q -k "$1" > gpurun_out/r5_tests.log 2>&1; rc=$?; tail -${LINES_SHOWN:-25} gpurun_out/r5_tests.log; [ $rc -eq 0 ] || exit 1; }
 case "$1" in
 tiles)
-  tests "tile or kernel_follows or index_without or near_window or shard"
+  tests "tile or kernel_follows or index_without or near_window or shard or passes or beyond"
   for n in 10000 50000; do
     RK_DIST_DEBUG=1 timeout -k 10 300 python3 tools/prof_driver.py index $n 6 > gpurun_out/r5_index_$n.log 2>&1 || { tail -30 gpurun_out/r5_index_$n.log; exit 1; }
     grep -v amdgpu.ids gpurun_out/r5_index_$n.log | tail -14
