@@ -461,6 +461,151 @@ def shard_rehearsal(env, index, n_genomes, steps=30):
     return out
 
 
+XGMI_LINK_GBS = 153.0   # MI355X_MICROARCH.md: seven point-to-point links per GPU, ~153 GB/s each
+
+
+def scale_block(env, n_genomes):
+    """A collection where eight GPUs and HBM matter (one rank; round 5): `n_genomes` sketches generated on the device -- species
+    sizes Zipf-distributed up to 10,000 strains, sketch sizes log-uniform in 200..3,000 (synth.scale_collection_torch) --, -D 0.05.
+    One GPU: index build (the bucket sort in several passes over the hash space, species-wide lists through k_bucket_heavy),
+    one self join, bytes resident.  Then the SHARDED run played on this one GPU for 2 / 4 / 8 shards: every shard builds the lists
+    of its hash range, the tile records change hands (here: slices of the send buffers), every shard sorts what arrived and joins
+    its rows.  Checked: the shards' hits add up to the single GPU's (count and a checksum over row, column and count), and the
+    hits of sampled genomes equal a brute-force Jaccard over their species on the host."""
+    from rabbitkssd_amd import capi, shard, synth
+    torch, ctx = env.torch, env.ctx
+    t0 = time.perf_counter()
+    h, off, species = synth.scale_collection_torch(n_genomes, HASH_BITS, KMER, device=env.dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    H = int(h.numel())
+    sk = ctx.sketches_from_dev(h.data_ptr(), off.data_ptr(), n_genomes)
+    ts = []
+    index = None
+    for _ in range(2):
+        del index
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        index = ctx.index_build(sk, HASH_BITS)
+        ts.append(time.perf_counter() - t0)
+    build_ms = ts[-1] * 1e3
+    pool = ctx.pool_stats()
+    hits_cap = 1 << 25
+    hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=env.dev)
+    steps = 5
+    counters = torch.zeros(counter_slots(steps, 1), dtype=torch.int64, device=env.dev)
+
+    def launch(i):
+        ctx.dist_rows_dev(index, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i, stream=env.stream.cuda_stream)
+    _, join_ms, _ = timed_steps(env, launch, steps, 1)
+    n_hits = int(counters[steps].item())
+    if n_hits > hits_cap:
+        sys.exit("bench.py: scale leg: %d hits do not fit the buffer" % n_hits)
+
+    def digest(buf, n):   # order-independent checksum of (row, col, common) on the device
+        rec = buf[: n * capi.HIT_DTYPE.itemsize].view(torch.int32).view(-1, capi.HIT_DTYPE.itemsize // 4)
+        r, c, m = rec[:, 0].to(torch.int64), rec[:, 1].to(torch.int64), rec[:, 2].to(torch.int64)
+        return int(((r * 1000003 + c) * 31 + m).sum().item() & ((1 << 62) - 1)), rec
+
+    want_digest, rec = digest(hits, n_hits)
+    # ---- sampled genomes against a brute-force join over their species (host)
+    sp_sizes = torch.bincount(species)
+    order = torch.argsort(sp_sizes, descending=True)
+    picks = [int(order[0]), int(order[len(order) // 200]), int(order[len(order) // 20]), int(order[len(order) // 3])]
+    off_h = off.cpu().numpy()
+    sampled, sample_ok = 0, True
+    t_min = np.exp(-KMER * MAX_DIST)
+    for sp in picks:
+        members = torch.nonzero(species == sp).flatten().cpu().numpy()
+        lo, hi = int(members[0]), int(members[-1]) + 1           # a species is a contiguous range of genomes
+        sh = h[int(off_h[lo]):int(off_h[hi])].cpu().numpy().view(np.uint32)
+        gid = np.repeat(np.arange(lo, hi), np.diff(off_h[lo:hi + 1]).astype(np.int64))
+        sizes = np.diff(off_h[lo:hi + 1]).astype(np.int64)
+        for g in members[:: max(1, len(members) // 3)][:3]:
+            a = sh[int(off_h[g] - off_h[lo]):int(off_h[g + 1] - off_h[lo])]
+            common = np.bincount(gid[np.isin(sh, a)] - lo, minlength=hi - lo)
+            j = common / np.maximum(1, sizes[g - lo] + sizes - common)
+            with np.errstate(divide="ignore"):
+                d = np.where(j >= 1.0, 0.0, np.where(j <= 0.0, 1.0, -np.log(2.0 * j / (1.0 + j)) / KMER))
+            mates = set((np.nonzero((d < MAX_DIST) & (np.arange(lo, hi) != g))[0] + lo).tolist())
+            sel = rec[(rec[:, 0] == int(g)) | (rec[:, 1] == int(g))]
+            got = set((sel[:, 0] + sel[:, 1] - int(g)).cpu().numpy().tolist())
+            cm = {int(x[0] + x[1] - int(g)): int(x[2]) for x in sel.cpu().numpy()}
+            sample_ok = sample_ok and got == mates and all(cm[x] == int(common[x - lo]) for x in mates)
+            sampled += 1
+    del rec
+    ts1 = index.tile_stats(1, 0, KMER, MAX_DIST)
+    single = {"index_build_ms": build_ms, "index_products": index.products, "index_built_fast": bool(index.built_fast), "join_ms": join_ms,
+              "hits": n_hits, "kernel": ctx.dist_kernel_name(index, None, 1, 0, KMER, MAX_DIST), "e2e_ms": build_ms + join_ms,
+              "pool_bytes": int(pool[0]), "tile_records": ts1[2], "tiles_with_records": ts1[0], "tiles_started": ts1[1],
+              "pairs_per_s": n_genomes * (n_genomes - 1) / 2 / (join_ms * 1e-3),
+              "hbm": hbm_block(8.0 * ts1[2] * (ts1[1] / max(1, ts1[0])) + 40.0 * n_hits, join_ms * 1e-3, env.peak_measured,
+                               "the join's stream by construction: 8 B per record of the started tiles (estimated from their share of the tiles) + 40 B per hit")}
+    del index
+    # ---- the sharded run, played shard by shard on this GPU
+    rehearsal = {}
+    for S in (2, 4, 8):
+        sends, counts, t_build, part0 = [], [], [], None
+        for r in range(S):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            part = ctx.index_build_shard(sk, HASH_BITS, r, S)
+            cnt = part.shard_records(S)
+            buf = torch.empty(max(1, sum(cnt) * shard.REC_BYTES), dtype=torch.uint8, device=env.dev)
+            part.shard_pack(buf.data_ptr(), env.stream.cuda_stream)
+            env.stream.synchronize()
+            t_build.append(time.perf_counter() - t0)
+            sends.append(buf)
+            counts.append(cnt)
+            if part0 is None:
+                part0 = part
+            else:
+                del part
+        t_join, t_step, got_hits, got_digest, sent_bytes = [], [], 0, 0, []
+        for d in range(S):
+            chunks = [sends[r][shard.REC_BYTES * sum(counts[r][:d]): shard.REC_BYTES * sum(counts[r][:d + 1])] for r in range(S)]
+            recv = torch.cat(chunks)
+            n_recv = sum(counts[r][d] for r in range(S))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            join = ctx.index_join_shard(part0, recv.data_ptr(), n_recv)
+            t_join.append(time.perf_counter() - t0)
+            cnts = torch.zeros(counter_slots(steps, 1), dtype=torch.int64, device=env.dev)
+
+            def launch_d(i, join=join, cnts=cnts):
+                ctx.dist_rows_dev(join, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, cnts.data_ptr() + 8 * i, stream=env.stream.cuda_stream)
+            _, ms, _ = timed_steps(env, launch_d, steps, 1)
+            t_step.append(ms)
+            nh = int(cnts[steps].item())
+            got_hits += nh
+            got_digest = (got_digest + digest(hits, nh)[0]) & ((1 << 62) - 1)
+            sent_bytes.append(shard.REC_BYTES * sum(counts[d][x] for x in range(S) if x != d))
+            del join, recv
+        # the exchange on real links: every rank sends (S - 1) / S of its records, one peer per link (up to seven)
+        t_xchg = max(sent_bytes) / (XGMI_LINK_GBS * 1e9 * min(S - 1, 7)) * 1e3
+        e2e = max(t_build) * 1e3 + t_xchg + max(a * 1e3 + b for a, b in zip(t_join, t_step))
+        rehearsal[str(S)] = {"shard_build_ms": [t * 1e3 for t in t_build], "join_build_ms": [t * 1e3 for t in t_join], "step_ms": t_step,
+                             "records_sent_bytes_per_rank": sent_bytes, "exchange_ms_estimated": t_xchg,
+                             "e2e_ms_predicted": e2e, "e2e_speedup_vs_one_gpu": single["e2e_ms"] / e2e,
+                             "e2e_efficiency_predicted": single["e2e_ms"] / e2e / S,
+                             "step_efficiency_predicted": join_ms / (S * max(t_step)),
+                             "same_hits_as_one_gpu": bool(got_hits == n_hits and got_digest == want_digest)}
+        if not rehearsal[str(S)]["same_hits_as_one_gpu"]:
+            sys.exit("bench.py: scale leg: %d shards report %d hits, one GPU %d" % (S, got_hits, n_hits))
+        del sends, part0
+    del sk
+    ctx.trim()
+    return {"workload": "alldist over %d sketches generated on the device: species sizes Zipf(2.0) up to 10,000 strains, sketch sizes log-uniform "
+                        "200..3,000 (one per species), species trees as in the 10,000-genome variants, 28-bit hashes, -D %g" % (n_genomes, MAX_DIST),
+            "genomes": n_genomes, "hashes": H, "species": int(len(sp_sizes)), "largest_species": int(sp_sizes.max()), "generate_s": t_gen,
+            "one_gpu": single, "sharded_rehearsal": rehearsal,
+            "sampled_genomes_vs_brute_force": {"genomes": sampled, "same_pairs_and_counts": bool(sample_ok)},
+            "note": "sharded_rehearsal: ONE GPU plays every shard in turn (build of its hash range incl. the records' packing, join build from "
+                    "the records it would receive, its rows' join); e2e_ms_predicted = slowest shard build + the all-to-all of 12-byte tile "
+                    "records on %d GB/s links (estimated: no second device here) + slowest (join build + step); the broadcast of the sketches "
+                    "that precedes it is in multi_gpu.replicate_ms of an N > 1 run" % int(XGMI_LINK_GBS)}
+
+
 def dist_rq_block(env, n_ref=100000, n_query=1000, steps=20, warmup=3, keep=None):
     """BASELINE configs[4] shape on one node: references 100,000 x 76 hashes, queries 1,000 x 45,776 hashes, 24-bit
     hashes (K10 S7 L4), -D 0.05.  Queries shard contiguously over the ranks; the index is broadcast once."""
@@ -487,6 +632,22 @@ def dist_rq_block(env, n_ref=100000, n_query=1000, steps=20, warmup=3, keep=None
 
     elapsed, kernel_ms, spread = timed_steps(env, launch, steps, warmup)
     tot_hits = env.sum_over_ranks(int(counters[warmup + steps - 1].item()))
+    # one GPU plays every contiguous query shard of a 2-, 4-, 8-GPU run in turn (src/dist.cpp:560: the rows -- queries -- are independent)
+    rq_rehearsal = None
+    if world == 1 and not env.args.no_rehearsal:
+        rq_rehearsal = {}
+        for S in (2, 4, 8):
+            per = []
+            blk = (n_query + S - 1) // S
+            for r in range(S):
+                c2 = torch.zeros(counter_slots(8, 1), dtype=torch.int64, device=env.dev)
+
+                def launch_s(i, r=r, S=S, blk=blk, c2=c2):
+                    ctx.dist_rows_dev(index, 0, 0, kmer, MAX_DIST, hits.data_ptr(), hits_cap, c2.data_ptr() + 8 * i, row_first=r, row_step=S,
+                                      row_block=blk, stream=env.stream.cuda_stream, queries=qs)
+                _, ms, _ = timed_steps(env, launch_s, 8, 1)
+                per.append(ms)
+            rq_rehearsal[str(S)] = {"shard_ms": per, "slowest_ms": max(per), "predicted_efficiency": kernel_ms / (S * max(per))}
     if rank != 0:
         return None
     if keep is not None:
@@ -505,7 +666,7 @@ def dist_rq_block(env, n_ref=100000, n_query=1000, steps=20, warmup=3, keep=None
                     "-D %g; one fused kernel per rank, queries in %d contiguous block(s)" % (n_ref, n_query, MAX_DIST, world),
         "value": n_pairs * steps / elapsed, "unit": "genome-pairs/s", "ms_per_step": elapsed / steps * 1e3,
         "pairs": n_pairs, "query_hashes": int(len(qh)), "postings_streamed_T": T_all, "hits": int(tot_hits),
-        "steps": steps, "warmup": warmup, "replicate_ms": t_bcast * 1e3,
+        "steps": steps, "warmup": warmup, "replicate_ms": t_bcast * 1e3, "scaling_rehearsal": rq_rehearsal,
         "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                      "contract_achieved": achieved, "contract_frac": achieved / HBM_PEAK_GBS,
                      "kernel": ctx.dist_kernel_name(index, qs, 0, 0, kmer, MAX_DIST), "kernel_ms": kernel_ms,
@@ -1261,6 +1422,8 @@ def main():
         out["dist_rq"] = rq
     if world == 1 and not args.no_variants:
         out["use64"] = use64_block(env)
+    if world == 1 and not args.no_scale:
+        out["scale"] = scale_block(env, args.scale_genomes)
     if world == 1 and not args.no_sketch:
         out["sketch"] = sketch_block(env, args.sketch_genomes, args.sketch_length,
                                      pmc_file="pmc_traffic_sketch%d.json" % args.sketch_genomes)

@@ -253,6 +253,7 @@ int rk_ctx_create(int device, rk_ctx **out)
     ctx->sw_index_relabel = getenv("RK_INDEX_RELABEL") ? atoi(getenv("RK_INDEX_RELABEL")) != 0 : 1;
     ctx->sw_index_no_self = getenv("RK_INDEX_NO_SELF") ? atoi(getenv("RK_INDEX_NO_SELF")) != 0 : 0;
     if (getenv("RK_INDEX_TILES")) ctx->sw_index_tiles = atoi(getenv("RK_INDEX_TILES"));
+    if (getenv("RK_INDEX_NO_HEAVY")) ctx->sw_index_heavy = atoi(getenv("RK_INDEX_NO_HEAVY")) == 0;
     if (getenv("RK_TILE_REC_CAP")) ctx->sw_tile_rec_cap = strtoull(getenv("RK_TILE_REC_CAP"), nullptr, 10);
     *out = ctx;
     return RK_OK;

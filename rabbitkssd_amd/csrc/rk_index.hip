@@ -1191,9 +1191,9 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         const int emit_t = getenv("RK_INDEX_EMIT_T") ? atoi(getenv("RK_INDEX_EMIT_T")) : 512;
         const bool narrow = low_bits + gb <= 32;  // (hash_low, genome) fits 32 bits
         // buckets beyond the LDS sort (a hash shared by thousands of genomes) go to k_bucket_heavy: tile records, 32-bit sort keys
-        const bool big_ok = tiles_mode && narrow && !getenv("RK_INDEX_NO_HEAVY");
+        const bool big_ok = tiles_mode && narrow && ctx->sw_index_heavy;
         if (big_ok) RK_HIP(ctx, big_list.alloc((size_t)fa.nb * passes));
-        const size_t heavy_lds = (((size_t)n_blocks * 4 + (size_t)n_blocks * 2) + 15) & ~(size_t)15;
+        const size_t heavy_lds = heavy_lds_bytes(n_blocks);
         if (big_ok) RK_HIP(ctx, hipFuncSetAttribute((const void *)k_bucket_heavy<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heavy_lds));
         for (uint32_t pass = 0; pass < passes; pass++) {
             fa.range_id = (shard_id << pass_bits) | pass;
@@ -1255,6 +1255,8 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
                 ea.n_dest = n_shards;
                 ea.stop = fa.range_bits ? fres : nullptr;
                 ea.big_ok = big_ok ? 1 : 0;
+                ea.big_list = big_ok ? big_list.p + (size_t)fa.nb * pass : nullptr;
+                ea.n_big = n_big_p;
                 ea.stop_rw = fres;
                 ea.tres = tres;
                 ea.xcd_map = fa.xcd_map;

@@ -67,6 +67,7 @@ struct rk_ctx {
     int sw_index_fast = 1;     // RK_INDEX_FAST=0: always the general (device-wide radix sort) build
     int sw_index_relabel = 1;  // RK_INDEX_RELABEL=0: keep the caller's genome order inside the index
     int sw_index_no_self = 0;  // RK_INDEX_NO_SELF=1: build every index without slice records (as one of 2^31 postings and more is)
+    int sw_index_heavy = 1;    // RK_INDEX_NO_HEAVY=1: a bucket beyond the LDS sort refuses the bucket-sort build (as until round 5) instead of going to k_bucket_heavy
     int sw_index_tiles = 2;    // RK_INDEX_TILES: 0 the fast build always emits slice records, 1 tile records whenever it can, 2 from RK_DIST_TILES_MIN_GENOMES genomes on
     unsigned long long sw_tile_rec_cap = 0;   // RK_TILE_REC_CAP: capacity of the build's unsorted tile records (default H / 2 + 64 K; tests force the overflow)
 };
