@@ -466,3 +466,42 @@ def test_one_gigabase_genome_k10s7l4(ctx, tmp_path):
         assert b"big file:" in p.stderr                               # the streamed path ran
         _, names, h, off = ok.read_sketches32(str(tmp_path / (name + ".sketch")))
         assert np.array_equal(h[int(off[1]):int(off[2])].astype(np.uint64), want), name
+
+
+def test_threshold_within_one_ulp_device_log_vs_host_libm(ctx):
+    """The reference keeps a pair when mashD < maxDist (src/dist.cpp:232), mashD from glibc's log.  rk_dist_rows recomputes every
+    reported distance with the host libm and decides there: bit for bit the reference, also for a threshold ON a pair's distance.
+    rk_dist_rows_dev keeps the device's own log (north_star: 1e-12): a pair whose distance lies within an ulp or two of -D may
+    land on either side there -- this test pins how far: thresholds four ulps away from any pair's distance agree with the host,
+    and the device's distance itself is within 2 ulps of the host's."""
+    import math
+    rng = np.random.default_rng(12)
+    m = 400
+    base = np.sort(rng.choice(1 << 26, size=m, replace=False)).astype(np.uint32)
+    parts = [base]
+    for c in (397, 380, 351, 300, 260, 201):           # genomes sharing c of base's m hashes
+        own = rng.choice(1 << 26, size=m - c, replace=False).astype(np.uint32)
+        parts.append(np.unique(np.concatenate([base[:c], own])))
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    h = np.concatenate(parts)
+    idx = ctx.index_build(ctx.sketches_from_host(h, off), 26)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    allp, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 0, 20, 0.9999)
+    dists = sorted(set(float(x) for x in allp["dist"] if 0.0 < x < 0.5))
+    assert len(dists) >= 6
+    ulp_off = 0
+    for d0 in dists[:6]:
+        ulp = math.ulp(d0)
+        for k, D in ((-4, d0 - 4 * ulp), (-1, math.nextafter(d0, 0.0)), (0, d0), (1, math.nextafter(d0, 1.0)), (4, d0 + 4 * ulp)):
+            want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 0, 20, D)
+            check_hits(ctx.dist_rows(idx, None, 1, 0, 20, D)[0], want)          # the synchronous API: the reference's decision, always
+            dev = dev_hits(ctx, idx, 1, 0, 20, D)
+            if abs(k) >= 4:
+                assert len(dev) == len(want) and np.array_equal(dev["row"], want["row"]) and np.array_equal(dev["col"], want["col"]), (d0, k)
+            else:
+                ulp_off += int(len(dev) != len(want))                            # (allowed: the device's log is its own)
+        dev = dev_hits(ctx, idx, 1, 0, 20, 0.9999)
+        mine = dev[np.isclose(dev["dist"], d0, rtol=0, atol=8 * ulp)]
+        assert len(mine) >= 1 and np.all(np.abs(mine["dist"] - d0) <= 2 * ulp)
+    print("thresholds within one ulp of a pair's distance where the device-resident API decided differently from the host: %d of 18" % ulp_off)
