@@ -838,9 +838,21 @@ int rk_index_self_stats(const rk_index *cidx, uint64_t out[4])
 
 static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, uint32_t shard_id, uint32_t n_shards, rk_index **out);
 
+// (a failing build may leave kernels in flight on both of the context's streams that still write into temporaries its DevBufs
+// have just returned to the pool: nothing may be handed out again before they are done)
+static int settle_streams(rk_ctx *ctx, int rc)
+{
+    if (rc && ctx) {
+        if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        (void)hipGetLastError();
+    }
+    return rc;
+}
+
 int rk_index_build(rk_ctx *ctx, const rk_sketches *s, int hash_bits, rk_index **out)
 {
-    return index_build_impl(ctx, s, hash_bits, 0, 1, out);
+    return settle_streams(ctx, index_build_impl(ctx, s, hash_bits, 0, 1, out));
 }
 
 int rk_index_build_shard(rk_ctx *ctx, const rk_sketches *s, int hash_bits, uint32_t shard, uint32_t n_shards, rk_index **out)
@@ -848,7 +860,7 @@ int rk_index_build_shard(rk_ctx *ctx, const rk_sketches *s, int hash_bits, uint3
     if (!ctx) return RK_ERR_ARG;
     if (!n_shards || n_shards > kRecRegions || (n_shards & (n_shards - 1)) || shard >= n_shards)
         return rk_fail(ctx, RK_ERR_ARG, "rk_index_build_shard: %u shards (a power of two up to %u), shard %u", n_shards, kRecRegions, shard);
-    return index_build_impl(ctx, s, hash_bits, shard, n_shards, out);
+    return settle_streams(ctx, index_build_impl(ctx, s, hash_bits, shard, n_shards, out));
 }
 
 static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, uint32_t shard_id, uint32_t n_shards, rk_index **out)

@@ -215,7 +215,17 @@ int tile_scan_u64(rk_ctx *ctx, unsigned long long *v, uint64_t n, unsigned long 
 
 }  // namespace
 
+static int tiles_build_body(rk_ctx *ctx, rk_index *idx, hipStream_t st);
 int rk_tiles_build(rk_ctx *ctx, rk_index *idx, hipStream_t st)
+{
+    const int rc = tiles_build_body(ctx, idx, st);
+    if (rc) {   // (kernels of a failing build may still write into temporaries that went back to the pool)
+        (void)hipStreamSynchronize(st);
+        (void)hipGetLastError();
+    }
+    return rc;
+}
+static int tiles_build_body(rk_ctx *ctx, rk_index *idx, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(idx->lazy_mu);
     if (idx->tiles_ready || idx->tiles_unusable) return RK_OK;

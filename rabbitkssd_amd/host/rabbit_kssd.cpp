@@ -316,7 +316,20 @@ static bool sketch_big_sequential(Gpu &gpu, const rk_filter *flt, const string &
                 if (b[ls] == '@') {
                     const void *e1 = memchr(b + ls, '\n', n - ls);
                     const void *e2 = e1 ? memchr((const uint8_t *)e1 + 1, '\n', n - ((const uint8_t *)e1 + 1 - b)) : nullptr;
-                    if (e2 && (size_t)((const uint8_t *)e2 + 1 - b) < n && ((const uint8_t *)e2)[1] == '+') return ls;
+                    if (e2 && (size_t)((const uint8_t *)e2 + 1 - b) < n && ((const uint8_t *)e2)[1] == '+') {
+                        // ... and, so that a quality line that starts with '@' inside a MULTI-line record (two lines further on: another
+                        // quality line starting with '+': both are valid Phred characters) is not taken for a record start: the
+                        // candidate's sequence line and its quality line have the same length (a four-line record; a multi-line file
+                        // offers no such candidate and takes the whole-file path)
+                        const uint8_t *p3 = (const uint8_t *)e2 + 1;
+                        const void *e3 = memchr(p3, '\n', n - (size_t)(p3 - b));
+                        const uint8_t *p4 = e3 ? (const uint8_t *)e3 + 1 : nullptr;
+                        const void *e4 = p4 ? memchr(p4, '\n', n - (size_t)(p4 - b)) : nullptr;
+                        if (e4) {
+                            auto len = [](const uint8_t *a, const void *e) { size_t l = (size_t)((const uint8_t *)e - a); return l && a[l - 1] == '\r' ? l - 1 : l; };
+                            if (len((const uint8_t *)e1 + 1, e2) == len(p4, e4)) return ls;
+                        }
+                    }
                 }
                 if (ls == 0) break;
                 pos = ls;   // (the newline before this line start is at ls - 1)

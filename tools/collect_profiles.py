@@ -142,8 +142,8 @@ def main(tag, traffic_only=False):
     t_q = traffic(groups["rq"], "rk_distq_kernel", "pmc_traffic_rq.json", "dist 100,000 refs x 1,000 queries (tools/prof_driver.py dist_rq_dev), MI355X", 0,
                   coalesced_bytes=4 * 45776 * 1000)   # the query hashes, read once, 4 B per lane
     traffic(groups["dist_50k"], "rk_near_kernel", "pmc_traffic_50k.json", "alldist 50,000 sketches (tools/prof_driver.py dist 50000 3), MI355X", 8)
-    traffic(groups["tile_clade10"], "rk_tile_kernel", "pmc_traffic_tile_clade10.json", "alldist 10,000 sketches, clades of 10, a resident index from its second join on (tools/prof_driver.py dist 10000 4), MI355X", 8)
-    traffic(groups["tile_50k"], "rk_tile_kernel", "pmc_traffic_tile_50k.json", "alldist 50,000 sketches, a resident index from its second join on (tools/prof_driver.py dist 50000 3), MI355X", 8)
+    traffic(groups["tile_clade10"], "rk_tile_kernel", "pmc_traffic_tile_clade10.json", "alldist 10,000 sketches, clades of 10, tile records from the index build: every join (tools/prof_driver.py dist 10000 4), MI355X", 8)
+    traffic(groups["tile_50k"], "rk_tile_kernel", "pmc_traffic_tile_50k.json", "alldist 50,000 sketches, tile records from the index build: every join (tools/prof_driver.py dist 50000 3), MI355X", 8)
     traffic(groups["tile_clade100"], "rk_tile_kernel", "pmc_traffic_tile_clade100.json", "alldist 10,000 sketches in species of 100 (tools/prof_driver.py dist 10000 4 1 0 0 100), MI355X", 8)
     traffic(groups["tile_clade1000"], "rk_tile_kernel", "pmc_traffic_tile_clade1000.json", "alldist 10,000 sketches in species of 1,000 (tools/prof_driver.py dist 10000 4 1 0 0 1000), MI355X", 8)
     traffic(groups["sketch_1000"], "rk_scan2_kernel", "pmc_traffic_sketch1000.json", "sketch 1,000 x 5 Mb (tools/prof_driver.py sketch 1000 5000000 2), MI355X", 16)
