@@ -934,7 +934,8 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
     const uint64_t H_pass = range_bits ? (H_shard >> pass_bits) : H;
     int B = 1, gb = 1, rb = 1;
     // (at most kMaxBucketBits: a bigger collection gets fuller buckets, up to the LDS capacity -- beyond it the kernels raise the overflow flag)
-    while (B < eff_bits && B < kMaxBucketBits && ((H_pass + kBucketTarget - 1) / kBucketTarget) > (1ULL << B)) B++;
+    const uint64_t bucket_target = getenv("RK_INDEX_BUCKET_TARGET") ? std::max(64, atoi(getenv("RK_INDEX_BUCKET_TARGET"))) : kBucketTarget;
+    while (B < eff_bits && B < kMaxBucketBits && ((H_pass + bucket_target - 1) / bucket_target) > (1ULL << B)) B++;
     while ((1ULL << gb) < N) gb++;
     while ((1ULL << rb) < s->max_size) rb++;
     const int low_bits = eff_bits - B;
