@@ -264,6 +264,11 @@ int rk_index_build_shard(rk_ctx *ctx, const rk_sketches *s, int hash_bits, uint3
 int rk_index_shard_records(const rk_index *part, uint64_t *counts_out);
 int rk_index_shard_pack(const rk_index *part, void *send_dev, void *stream);
 int rk_index_join_shard(rk_ctx *ctx, const rk_index *part, const void *recv_dev, uint64_t n_records, rk_index **out);
+/* One process, one context per GPU (`rabbit_kssd alldist --gpus N`): the exchange without a communicator -- GPU d pulls chunk d
+ * of every shard's packed records over its own links (hipMemcpyPeerAsync, bounded wait).  parts[r] = shard r of n, each on its own
+ * context; recv_dev[d] (free with rk_dev_free) and n_recv[d] are what rk_index_join_shard takes on GPU d.
+ * Called from one host thread; the shard builds before it and the joins behind it may run one thread per GPU. */
+int rk_index_shard_exchange(rk_index *const *parts, uint32_t n, void **recv_dev, uint64_t *n_recv);
 /* Multi-GPU: the whole index as ONE contiguous device blob, so that the owner can hand it
  * to an RCCL broadcast (one collective, no reduction: query rows are independent) and every
  * peer rebuilds an identical rk_index from the received bytes.  pack/unpack only enqueue

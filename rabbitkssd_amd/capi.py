@@ -23,7 +23,7 @@ EXPORTS = [
     "rk_sketches_from_host", "rk_sketches_from_host64", "rk_sketches_download64", "rk_sketches_is64", "rk_sketches_from_dev", "rk_sketches_count", "rk_sketches_total", "rk_sketches_windows",
     "rk_sketches_download", "rk_sketches_hashes_dev", "rk_sketches_off_dev", "rk_sketches_free",
     "rk_index_build", "rk_index_import", "rk_index_export", "rk_index_export_lists", "rk_index_import64", "rk_index_export64", "rk_index_total",
-    "rk_index_distinct", "rk_index_genomes", "rk_index_order", "rk_index_hash_bits", "rk_index_built_fast", "rk_index_products", "rk_index_sum_sq", "rk_index_self_stats", "rk_index_tile_stats", "rk_index_build_shard", "rk_index_shard_records", "rk_index_shard_pack", "rk_index_join_shard",
+    "rk_index_distinct", "rk_index_genomes", "rk_index_order", "rk_index_hash_bits", "rk_index_built_fast", "rk_index_products", "rk_index_sum_sq", "rk_index_self_stats", "rk_index_tile_stats", "rk_index_build_shard", "rk_index_shard_records", "rk_index_shard_pack", "rk_index_join_shard", "rk_index_shard_exchange",
     "rk_index_free", "rk_index_blob_bytes", "rk_index_pack_dev", "rk_index_unpack_dev", "rk_index_broadcast", "rk_dist_rows", "rk_dist_rows_dev", "rk_topn_rows", "rk_format_hit",
 ]
 

@@ -1585,6 +1585,98 @@ int rk_index_shard_pack(const rk_index *idx, void *send_dev, void *stream_v)
     return RK_OK;
 }
 
+// One process, one context per GPU (what `rabbit_kssd alldist --gpus N` does): the all-to-all of the shards' tile records by
+// direct copies -- GPU d pulls chunk d of every shard's packed records over its own links (hipMemcpyPeerAsync; on one device a
+// plain copy), no communicator.  recv_dev[d] (library-owned: rk_dev_free on parts[d]'s context) holds what shard d joins.
+int rk_index_shard_exchange(rk_index *const *parts, uint32_t n, void **recv_dev, uint64_t *n_recv)
+{
+    if (!parts || !n || !recv_dev || !n_recv || n > kRecRegions) return RK_ERR_ARG;
+    for (uint32_t r = 0; r < n; r++) {
+        recv_dev[r] = nullptr;
+        n_recv[r] = 0;
+        if (!parts[r] || !parts[r]->d_shard_rec || parts[r]->n_shards != n || parts[r]->shard_id != r)
+            return rk_fail(parts[0] ? parts[0]->ctx : nullptr, RK_ERR_ARG, "rk_index_shard_exchange: parts[r] must be shard r of %u (rk_index_build_shard)", n);
+    }
+    std::vector<std::vector<uint64_t>> cnt(n, std::vector<uint64_t>(n, 0));
+    std::vector<uint3 *> send(n, nullptr);
+    auto cleanup = [&](bool also_recv) {
+        for (uint32_t r = 0; r < n; r++) {
+            rk_ctx *c = parts[r]->ctx;
+            if (hipSetDevice(c->device) == hipSuccess) (void)hipStreamSynchronize(c->stream);
+            if (send[r]) rk_pool_free(c, send[r]);
+            if (also_recv && recv_dev[r]) { (void)hipFree(recv_dev[r]); recv_dev[r] = nullptr; }   // (plain hipMalloc: the caller frees with rk_dev_free)
+        }
+        (void)hipGetLastError();
+    };
+    for (uint32_t r = 0; r < n; r++) {   // every shard packs its records, contiguous by destination
+        rk_ctx *c = parts[r]->ctx;
+        int rc = rk_index_shard_records(parts[r], cnt[r].data());
+        if (rc) { cleanup(true); return rc; }
+        uint64_t tot = 0;
+        for (uint32_t d = 0; d < n; d++) tot += cnt[r][d];
+        if (hipSetDevice(c->device) != hipSuccess) { cleanup(true); return rk_fail(c, RK_ERR_HIP, "cannot select device %d", c->device); }
+        send[r] = static_cast<uint3 *>(rk_pool_alloc(c, std::max<uint64_t>(1, tot) * sizeof(uint3)));
+        if (!send[r]) { cleanup(true); return rk_fail(c, RK_ERR_NOMEM, "cannot allocate the send buffer of %llu tile records", (unsigned long long)tot); }
+        rc = rk_index_shard_pack(parts[r], send[r], c->stream);
+        if (rc) { cleanup(true); return rc; }
+    }
+    for (uint32_t r = 0; r < n; r++) {
+        rk_ctx *c = parts[r]->ctx;
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { cleanup(true); return rk_fail(c, RK_ERR_HIP, "packing the tile records of shard %u failed", r); }
+    }
+    for (uint32_t d = 0; d < n; d++) {   // every destination pulls its chunks
+        rk_ctx *c = parts[d]->ctx;
+        uint64_t tot = 0;
+        for (uint32_t r = 0; r < n; r++) tot += cnt[r][d];
+        n_recv[d] = tot;
+        if (hipSetDevice(c->device) != hipSuccess) { cleanup(true); return rk_fail(c, RK_ERR_HIP, "cannot select device %d", c->device); }
+        if (hipMalloc(&recv_dev[d], std::max<uint64_t>(1, tot) * sizeof(uint3)) != hipSuccess) {
+            recv_dev[d] = nullptr;
+            (void)hipGetLastError();
+            cleanup(true);
+            return rk_fail(c, RK_ERR_NOMEM, "cannot allocate the receive buffer of %llu tile records", (unsigned long long)tot);
+        }
+        uint64_t at = 0;
+        for (uint32_t r = 0; r < n; r++) {
+            const uint64_t c_rd = cnt[r][d];
+            if (!c_rd) continue;
+            uint64_t from = 0;
+            for (uint32_t q = 0; q < d; q++) from += cnt[r][q];
+            rk_ctx *sc = parts[r]->ctx;
+            uint3 *dst = static_cast<uint3 *>(recv_dev[d]) + at;
+            hipError_t e;
+            if (sc->device == c->device) e = hipMemcpyAsync(dst, send[r] + from, c_rd * sizeof(uint3), hipMemcpyDeviceToDevice, c->stream);
+            else {
+                int can = 0;
+                (void)hipDeviceCanAccessPeer(&can, c->device, sc->device);
+                if (can && hipDeviceEnablePeerAccess(sc->device, 0) != hipSuccess) (void)hipGetLastError();   // (already enabled)
+                e = hipMemcpyPeerAsync(dst, c->device, send[r] + from, sc->device, c_rd * sizeof(uint3), c->stream);
+            }
+            if (e != hipSuccess) { cleanup(true); return rk_fail(c, RK_ERR_HIP, "copy of tile records from device %d to device %d failed: %s", sc->device, c->device, hipGetErrorString(e)); }
+            at += c_rd;
+        }
+    }
+    for (uint32_t d = 0; d < n; d++) {   // bounded wait: a peer copy that never completes must end in an error, not in a hang
+        rk_ctx *c = parts[d]->ctx;
+        hipError_t qe = hipSetDevice(c->device);
+        const auto t_start = std::chrono::steady_clock::now();
+        while (qe == hipSuccess) {
+            qe = hipStreamQuery(c->stream);
+            if (qe != hipErrorNotReady) break;
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(120)) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            qe = hipSuccess;
+        }
+        (void)hipGetLastError();
+        if (qe != hipSuccess) {
+            // (a copy that is stuck: its buffers are leaked rather than waited for)
+            return rk_fail(c, RK_ERR_HIP, "the exchange of tile records did not complete on device %d: %s", c->device, hipGetErrorString(qe));
+        }
+    }
+    for (uint32_t r = 0; r < n; r++) { rk_pool_free(parts[r]->ctx, send[r]); send[r] = nullptr; }
+    return RK_OK;
+}
+
 int rk_index_join_shard(rk_ctx *ctx, const rk_index *part, const void *recv_dev, uint64_t n_records, rk_index **out)
 {
     if (!ctx || !part || !out || (!recv_dev && n_records)) return RK_ERR_ARG;

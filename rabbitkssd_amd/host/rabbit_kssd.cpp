@@ -1230,7 +1230,51 @@ static int cmd_alldist(const Args &a)
     const bool missing = !exist_file(sketch_path + ".index") || !exist_file(sketch_path + ".dict");
     const size_t G = set.size();
     vector<rk_index *> idx(G, nullptr);
-    build_everywhere(set, s, sketch_path, missing, idx);
+    // Several GPUs (round 5): the all-vs-all shards twice -- every GPU builds the posting lists of ITS range of the hash space, the
+    // tile records change hands once (GPU d pulls what belongs to its rows over its own links), every GPU sorts what arrived and
+    // joins its rows.  No index is replicated.  Taken for a power-of-two number of GPUs when the .dict / .index pair exists (writing
+    // them needs the whole index on one GPU) and the collection takes the bucket sort with tile records (set sketches, 2 and more
+    // genomes); anything else -- and RK_MULTI_REPLICATE=1 -- builds the whole index on every GPU as before.
+    // (a dense report -- -D above 1.0: every pair -- needs counter rows over slice records, which a join-only index has not)
+    bool sharded = G > 1 && (G & (G - 1)) == 0 && !missing && !(1.0 < max_dist) && !(getenv("RK_MULTI_REPLICATE") && atoi(getenv("RK_MULTI_REPLICATE")));
+    if (sharded) {
+        const int bits = 4 * (s.info.half_k - s.info.drlevel);
+        vector<rk_index *> part(G, nullptr);
+        vector<int> rcs(G, 0);
+        auto build_part = [&](size_t g) {
+            rk_sketches *sk = upload(set[g], s);
+            rcs[g] = rk_index_build_shard(set[g].ctx, sk, bits, (uint32_t)g, (uint32_t)G, &part[g]);
+            rk_sketches_free(sk);
+        };
+        {
+            vector<std::thread> pool;
+            for (size_t g = 1; g < G; g++) pool.emplace_back(build_part, g);
+            build_part(0);
+            for (auto &th : pool) th.join();
+        }
+        bool ok = true;
+        for (size_t g = 0; g < G; g++) ok = ok && rcs[g] == 0;
+        vector<void *> recv(G, nullptr);
+        vector<uint64_t> n_recv(G, 0);
+        if (ok) ok = rk_index_shard_exchange(part.data(), (uint32_t)G, recv.data(), n_recv.data()) == 0;
+        if (ok) stamp("shards built, tile records exchanged");
+        if (ok) {
+            auto join_part = [&](size_t g) { rcs[g] = rk_index_join_shard(set[g].ctx, part[g], recv[g], n_recv[g], &idx[g]); };
+            vector<std::thread> pool;
+            for (size_t g = 1; g < G; g++) pool.emplace_back(join_part, g);
+            join_part(0);
+            for (auto &th : pool) th.join();
+            for (size_t g = 0; g < G; g++) ok = ok && rcs[g] == 0;
+        }
+        for (size_t g = 0; g < G; g++) {
+            rk_dev_free(recv[g]);
+            rk_index_free(part[g]);
+            if (!ok && idx[g]) { rk_index_free(idx[g]); idx[g] = nullptr; }
+        }
+        if (!ok && getenv("RK_TIMING")) fprintf(stderr, "[timing] sharded build refused (%s): the whole index on every GPU\n", rk_last_error(set[0].ctx));
+        sharded = ok;
+    }
+    if (!sharded) build_everywhere(set, s, sketch_path, missing, idx);
     stamp("index built");
     // (the reference's phase line, src/dist.cpp:132-135: there the phase loads .dict/.index, here it builds the index on the device)
     cerr << "===================time of read index and offset sketch file is: " << get_sec() - t0 << endl;
@@ -1244,7 +1288,7 @@ static int cmd_alldist(const Args &a)
         o.metric = metric;
         o.kmer_size = 2 * s.info.half_k;
         o.max_dist = max_dist;
-        if (G > 1) {
+        if (G > 1 && !sharded) {   // (a join-only index of the sharded flow holds this GPU's rows and nothing else)
             o.row_first = (uint32_t)g;
             o.row_step = (uint32_t)G;
             o.row_block = kRowBlock;

@@ -561,6 +561,16 @@ def test_cli_multi_gpu_row_shards_reproduce_the_reference_text(tmp_path):
                 lines = (tmp_path / "o.txt").read_text().split("\n")[:-1]
                 assert lines[1:] == want, (case["file"], gpus)     # queries in order, -N heap order per query
     os.environ.pop("RK_MULTI_BROADCAST", None)
+    # (round 5) with two GPUs and the .dict / .index pair in place a sparse alldist takes the SHARDED flow -- every GPU builds the
+    # lists of its hash range, the tile records change hands, every GPU joins its rows --, RK_MULTI_REPLICATE=1 the old one: same text
+    case = [c for c in man["cases"] if c["cmd"] == "alldist" and c["max_dist"] < 1.0 and c["metric"] == 0][0]
+    want = open(os.path.join(d, case["file"])).read().split("\n")[:-1]
+    for repl in ("0", "1"):
+        p = subprocess.run([TOOL, "alldist", "-i", "ref.sketch", "-D", str(case["max_dist"]), "-o", "s.txt", "--gpus", "2", "--same-device", "-t", "4"],
+                           cwd=tmp_path, env=dict(os.environ, RK_TIMING="1", RK_MULTI_REPLICATE=repl), capture_output=True)
+        assert p.returncode == 0, p.stderr.decode()
+        assert (b"tile records exchanged" in p.stderr) == (repl == "0") and b"refused" not in p.stderr
+        assert sorted((tmp_path / "s.txt").read_text().split("\n")[1:-1]) == want
     # the same through the sub-file layout (src/dist.cpp:311-335)
     case = [c for c in man["cases"] if c["cmd"] == "alldist" and c["max_dist"] == 1.5 and c["metric"] == 0][0]
     want = open(os.path.join(d, case["file"])).read().split("\n")[:-1]
