@@ -173,7 +173,9 @@ int rk_pack_genomes(const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
  * ascending.  A sketch that repeats a hash keeps its repeats (they count, src/dist.cpp:199-202). */
 int rk_sketches_from_host(rk_ctx *ctx, const uint32_t *hashes, const uint64_t *off,
                           uint32_t n_genomes, rk_sketches **out);
-/* same from device-resident arrays (copied device-to-device into a library-owned object) */
+/* same from device-resident arrays (copied device-to-device into a library-owned object).  The copies run on the
+ * context's own stream: the arrays must be COMPLETE when the call is made (synchronise the stream that produced them
+ * first).  RK_ERR_ARG when off_dev is not a CSR offset table (off[0] = 0, non-decreasing). */
 int rk_sketches_from_dev(rk_ctx *ctx, const uint32_t *hashes_dev, const uint64_t *off_dev,
                          uint32_t n_genomes, rk_sketches **out);
 /* 64-bit hash layout (use64: half_k - drlevel > 8, src/sketch.cpp:336): the sketch kernel produces it

@@ -371,7 +371,9 @@ __global__ void k_minhash_insert(const K *hashes, const uint64_t *off, uint32_t 
             if (cur == kEmptySlot) return;
         }
         if ((uint32_t)(cur >> 32) == h) {
-            atomicMin(&table[slot], mine);
+            // (the slot only ever decreases: a genome that finds a smaller one there has nothing to add -- in a species of 10,000
+            // strains all but the first few arrivals at a hash; their atomics queued on ONE address, 0.9 ms at 500,000 genomes)
+            if (cur > mine) atomicMin(&table[slot], mine);
             return;
         }
         slot = (slot + 1) & mask;
@@ -1009,7 +1011,10 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         int id_bits = 1;
         while ((1ULL << id_bits) < N) id_bits++;
         uint32_t slots = 1024;
-        while (slots < 4ull * N * kMinK && slots < (1u << 30)) slots <<= 1;
+        // (at most half full, usually far less -- relatives share their smallest hashes.  Twice this size was 268 MB at 500,000 genomes:
+        // beyond the last-level cache, every probe a DRAM row of its own, and the kernels streaming beside it slowed to a third)
+        const unsigned long long want_slots = (getenv("RK_INDEX_TABLE_X") ? strtoull(getenv("RK_INDEX_TABLE_X"), nullptr, 10) : 2ULL) * N * kMinK;
+        while (slots < want_slots && slots < (1u << 30)) slots <<= 1;
         RK_HIP(ctx, rl_table.alloc(slots));
         RK_HIP(ctx, rl_parent.alloc(N));
         RK_HIP(ctx, hipMemsetAsync(rl_table.p, 0xFF, (size_t)slots * 8, s2));
@@ -1124,6 +1129,8 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         // flag in k_part_starts and the kernels behind it stand still)
         const uint64_t keys_cap = fa.range_bits ? std::min<uint64_t>(H, H_pass + H_pass / 4 + (1u << 20)) : H;
         fa.keys_cap = keys_cap;
+        fa.filtered = nullptr;
+        fa.n_filtered = nullptr;
         DevBuf<uint32_t> chunk_first(ctx), matrix(ctx), total(ctx), bstart(ctx), ucount(ctx), ubase(ctx), tmp_uhash(ctx), tmp_upos(ctx), n_open(ctx), n_cov(ctx);
         DevBuf<unsigned long long> keys(ctx), tmp_uhash64(ctx), zeroed(ctx);
         DevBuf<uint2> self_raw(ctx);
@@ -1134,8 +1141,13 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         DevBuf<unsigned long long> level_start(ctx);
         const bool wide = idx->wide;
         const size_t nb1 = (size_t)fa.nb + 1;
+        // the two-pass partition needs six spare key bits and >= 128 buckets
+        const bool part2 = (getenv("RK_INDEX_PART2") ? atoi(getenv("RK_INDEX_PART2")) != 0 : true) && B >= 7 && low_bits + gb + fa.rb <= 64 - (int)kFineBits;
+        // a range pass partitions what k_range_filter kept of the hashes (RK_INDEX_FILTER=0: every kernel of the pass walks them all)
+        const bool use_filter = fa.range_bits && part2 && eff_bits + gb <= 64 && (getenv("RK_INDEX_FILTER") ? atoi(getenv("RK_INDEX_FILTER")) != 0 : true);
+        const uint32_t part_chunks = use_filter ? (uint32_t)((keys_cap + kPartChunk - 1) / kPartChunk) : fa.n_chunks;   // rows of the count matrix
         RK_HIP(ctx, chunk_first.alloc((size_t)fa.n_chunks + 1));
-        RK_HIP(ctx, matrix.alloc((size_t)fa.n_chunks * fa.nb));
+        RK_HIP(ctx, matrix.alloc((size_t)part_chunks * fa.nb));
         RK_HIP(ctx, total.alloc(fa.nb));
         RK_HIP(ctx, bstart.alloc(nb1 * passes));   // (per pass: the list heads of a pass are placed while the next one partitions)
         RK_HIP(ctx, ucount.alloc(nb1 * passes));
@@ -1162,7 +1174,7 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
             tile_cap = std::min<uint64_t>(rec_cap, (uint64_t)n_blocks * (n_blocks + 1) / 2);
             slot_cap = rec_cap + tile_cap;   // (every tile from an even slot on)
             RK_HIP(ctx, brec.alloc(rec_cap));
-            RK_HIP(ctx, tb.alloc(2 * (size_t)n_blocks));
+            RK_HIP(ctx, tb.alloc(3 * (size_t)n_blocks));
             RK_HIP(ctx, bins.alloc((size_t)n_blocks + 1));   // bin starts (the counts and cursors are in `zeroed`)
             RK_HIP(ctx, proto.alloc(2 * tile_cap));
             RK_HIP(ctx, level_start.alloc(2 * (kTileTable + 1)));
@@ -1179,11 +1191,10 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         }
         // everything the kernels expect zeroed, in one buffer and one fill (each fill is ~5 us on the stream): the result
         // records, where the postings of each pass start, the cursors of the two-pass partition (per pass) and of the tile sort
-        const bool part2 = (getenv("RK_INDEX_PART2") ? atoi(getenv("RK_INDEX_PART2")) != 0 : true) && B >= 7 && low_bits + gb + fa.rb <= 64 - (int)kFineBits;
         const bool small_wgs = (fa.nb >> kFineBits) <= 128;   // several workgroups per chunk: they share its stretch through counters
         const size_t w_cursor = part2 ? (fa.nb + 1) / 2 : 0, w_taken = part2 && small_wgs ? ((size_t)fa.n_chunks * (fa.nb >> kFineBits) + 1) / 2 : 0;
         const size_t z_res = 0, z_tres = z_res + (sizeof(BuildResult) + 7) / 8, z_pass = z_tres + (sizeof(TileResult) + 7) / 8,
-                     z_big = z_pass + passes + 1, z_cursor = z_big + (passes + 1) / 2, z_taken = z_cursor + w_cursor * passes, z_tcur = z_taken + w_taken * passes,
+                     z_big = z_pass + passes + 1, z_filt = z_big + (passes + 1) / 2, z_hq = z_filt + passes, z_cursor = z_hq + (passes + 1) / 2, z_taken = z_cursor + w_cursor * passes, z_tcur = z_taken + w_taken * passes,
                      z_bins = z_tcur + (sort_here ? (sizeof(TileCursors) + 7) / 8 : 0),
                      z_end = z_bins + (sort_here ? (size_t)n_blocks + 1 : 0);   // bin counts (u32[n_blocks + 1]) + bin cursors (u32[n_blocks])
         RK_HIP(ctx, zeroed.alloc(z_end));   // (zeroed by k_chunk_first, the first launch)
@@ -1213,9 +1224,21 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
             uint32_t *const bstart_p = bstart.p + nb1 * pass, *const ucount_p = ucount.p + nb1 * pass, *const ubase_p = ubase.p + nb1 * pass;
             uint32_t *const fine_cursor = reinterpret_cast<uint32_t *>(zeroed.p + z_cursor + w_cursor * pass);
             uint32_t *const seg_taken = reinterpret_cast<uint32_t *>(zeroed.p + z_taken + w_taken * pass);
-            if (wide) hipLaunchKernelGGL(k_part_hist<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, fres);
-            else hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, fres);
-            hipLaunchKernelGGL(k_part_colscan, dim3((fa.nb + 63) / 64), dim3(1024), 0, st, matrix.p, fa.n_chunks, fa.nb, total.p);
+            FastArgs pa = fa;   // what the partition kernels of this pass see
+            if (use_filter) {
+                unsigned long long *const n_filt = zeroed.p + z_filt + pass;
+                // (the filtered elements lie in `keys`: the coarse pass reads them and writes `mid`, the fine pass writes `keys` again)
+                if (wide) hipLaunchKernelGGL(k_range_filter<uint64_t>, dim3(fa.n_chunks * kFilterSplit), dim3(kFilterThreads), 0, st, fa, chunk_first.p, keys.p, n_filt, fres);
+                else hipLaunchKernelGGL(k_range_filter<uint32_t>, dim3(fa.n_chunks * kFilterSplit), dim3(kFilterThreads), 0, st, fa, chunk_first.p, keys.p, n_filt, fres);
+                pa.filtered = keys.p;
+                pa.n_filtered = n_filt;
+                pa.hash_bits = eff_bits;
+                pa.range_bits = 0;
+                pa.range_id = 0;
+            }
+            if (wide) hipLaunchKernelGGL(k_part_hist<uint64_t>, dim3(part_chunks), dim3(kPartThreads), part_lds, st, pa, chunk_first.p, matrix.p, fres);
+            else hipLaunchKernelGGL(k_part_hist<uint32_t>, dim3(part_chunks), dim3(kPartThreads), part_lds, st, pa, chunk_first.p, matrix.p, fres);
+            hipLaunchKernelGGL(k_part_colscan, dim3((fa.nb + 63) / 64), dim3(1024), 0, st, matrix.p, part_chunks, fa.nb, total.p);
             uint32_t *const n_big_p = reinterpret_cast<uint32_t *>(zeroed.p + z_big) + pass;
             hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, st, total.p, fa.nb, bstart_p, fres, pass_base + pass, (unsigned long long)keys_cap,
                                big_ok ? big_list.p + (size_t)fa.nb * pass : nullptr, n_big_p);
@@ -1224,12 +1247,12 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
 #define RK_COARSE(TT, HT, GRID)                                                                                                              \
     do {                                                                                                                                     \
         RK_HIP(ctx, hipFuncSetAttribute((const void *)k_part_coarse<TT, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds(TT))); \
-        hipLaunchKernelGGL((k_part_coarse<TT, HT>), dim3(GRID), dim3(TT), part2_lds(TT), st, fa, chunk_first.p, matrix.p, bstart_p, seg_taken, mid.p, fres); \
+        hipLaunchKernelGGL((k_part_coarse<TT, HT>), dim3(GRID), dim3(TT), part2_lds(TT), st, pa, chunk_first.p, matrix.p, bstart_p, seg_taken, mid.p, fres); \
     } while (0)
-                if (small_wgs) { if (wide) RK_COARSE(256, uint64_t, fa.n_chunks * 4); else RK_COARSE(256, uint32_t, fa.n_chunks * 4); }
-                else { if (wide) RK_COARSE(1024, uint64_t, fa.n_chunks); else RK_COARSE(1024, uint32_t, fa.n_chunks); }
+                if (small_wgs) { if (wide) RK_COARSE(256, uint64_t, part_chunks * 4); else RK_COARSE(256, uint32_t, part_chunks * 4); }
+                else { if (wide) RK_COARSE(1024, uint64_t, part_chunks); else RK_COARSE(1024, uint32_t, part_chunks); }
 #undef RK_COARSE
-                hipLaunchKernelGGL(k_part_fine, dim3(fa.nb >> kFineBits, 16), dim3(kPartThreads), 0, st, fa, bstart_p, mid.p, keys.p, fine_cursor, fres);
+                hipLaunchKernelGGL(k_part_fine, dim3(fa.nb >> kFineBits, 16), dim3(kPartThreads), 0, st, pa, bstart_p, mid.p, keys.p, fine_cursor, fres);
             } else if (wide) {
                 hipLaunchKernelGGL(k_part_scatter<uint64_t>, dim3(fa.n_chunks), dim3(kPartThreads), part_lds, st, fa, chunk_first.p, matrix.p, bstart_p, keys.p, fres);
             } else {
@@ -1289,6 +1312,7 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
                     ha.e = ea;
                     ha.big_list = big_list.p + (size_t)fa.nb * pass;
                     ha.n_big = n_big_p;
+                    ha.next = reinterpret_cast<uint32_t *>(zeroed.p + z_hq) + pass;
                     ha.n_blocks = n_blocks;
                     hipLaunchKernelGGL(k_bucket_heavy<1024>, dim3((unsigned)std::max(1, ctx->num_cu)), dim3(1024), heavy_lds, st, ha);
                 }
@@ -1362,6 +1386,7 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
             ta.cols = t_cols.p;
             ta.tb_base = tb.p;
             ta.tb_cnt = tb.p + n_blocks;
+            ta.order = tb.p + 2 * (size_t)n_blocks;
             ta.proto = proto.p;
             ta.level_start = level_start.p;
             ta.dir[0] = t_dir_j.p;
@@ -1384,6 +1409,22 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
             r = both.r;
             tr = both.t;
             n_postings = both.pass_base[passes];
+        }
+        if (ctx->sw_dist_debug && big_ok) {   // (developer output: what k_bucket_heavy had to take)
+            std::vector<uint32_t> nbig(passes), bs((size_t)nb1 * passes);
+            RK_TRY(rk_read_back(ctx, nbig.data(), zeroed.p + z_big, (size_t)passes * 4, st));
+            RK_TRY(rk_read_back(ctx, bs.data(), bstart.p, bs.size() * 4, st));
+            for (uint32_t pass = 0; pass < passes; pass++) {
+                std::vector<uint32_t> bl(nbig[pass]);
+                if (nbig[pass]) RK_TRY(rk_read_back(ctx, bl.data(), big_list.p + (size_t)fa.nb * pass, bl.size() * 4, st));
+                unsigned long long keys_in = 0, biggest = 0;
+                for (uint32_t b : bl) {
+                    const unsigned long long n = bs[nb1 * pass + b + 1] - bs[nb1 * pass + b];
+                    keys_in += n;
+                    biggest = std::max(biggest, n);
+                }
+                fprintf(stderr, "[rk] index build pass %u: %u of %u buckets for k_bucket_heavy, %llu keys, biggest %llu\n", pass, nbig[pass], fa.nb, keys_in, biggest);
+            }
         }
         if (ctx->sw_dist_debug)
             fprintf(stderr, "[rk] index build: fast path flags %llu (B %d, low bits %d, genome bits %d, position bits %d; shard %u of %u, %u pass(es), %llu postings)%s\n",
@@ -1719,7 +1760,7 @@ int rk_index_join_shard(rk_ctx *ctx, const rk_index *part, const void *recv_dev,
     DevBuf<uint3> brec(ctx);
     DevBuf<unsigned long long> level_start(ctx), zeroed(ctx);
     RK_HIP(ctx, brec.alloc(std::max<uint64_t>(1, n_records)));
-    RK_HIP(ctx, tb.alloc(2 * (size_t)n_blocks));
+    RK_HIP(ctx, tb.alloc(3 * (size_t)n_blocks));
     RK_HIP(ctx, bins.alloc((size_t)n_blocks + 1));
     RK_HIP(ctx, proto.alloc(2 * tile_cap));
     RK_HIP(ctx, level_start.alloc(2 * (kTileTable + 1)));
@@ -1749,6 +1790,7 @@ int rk_index_join_shard(rk_ctx *ctx, const rk_index *part, const void *recv_dev,
     ta.cols = t_cols.p;
     ta.tb_base = tb.p;
     ta.tb_cnt = tb.p + n_blocks;
+    ta.order = tb.p + 2 * (size_t)n_blocks;
     ta.proto = proto.p;
     ta.level_start = level_start.p;
     ta.dir[0] = t_dir_j.p;
@@ -1757,6 +1799,20 @@ int rk_index_join_shard(rk_ctx *ctx, const rk_index *part, const void *recv_dev,
     RK_TRY(launch_tile_sort(ctx, ta, st, []() { return RK_OK; }));
     TileResult tr;
     RK_TRY(rk_read_back(ctx, &tr, tres, sizeof(tr), st));
+    if (ctx->sw_dist_debug) {   // (developer output: how the records spread over the row blocks)
+        std::vector<uint32_t> bc(n_blocks);
+        RK_TRY(rk_read_back(ctx, bc.data(), ta.bin_count, (size_t)n_blocks * 4, st));
+        std::sort(bc.begin(), bc.end(), std::greater<uint32_t>());
+        unsigned long long top = 0, all = 0;
+        uint32_t non_empty = 0;
+        for (uint32_t i = 0; i < n_blocks; i++) {
+            all += bc[i];
+            if (i < 64) top += bc[i];
+            non_empty += bc[i] != 0;
+        }
+        fprintf(stderr, "[rk] join shard: %llu records in %u of %u row blocks; fullest %u, 64th %u, the 64 fullest hold %llu\n", all, non_empty, n_blocks, bc[0],
+                bc[std::min<uint32_t>(63, n_blocks - 1)], top);
+    }
     idx->d_tile_contrib = t_contrib.release();
     idx->d_tile_rows = t_rows.release();
     idx->d_tile_cols = t_cols.release();

@@ -820,6 +820,12 @@ int rk_sketches_from_dev(rk_ctx *ctx, const uint32_t *hashes_dev, const uint64_t
     s->h_off.resize((size_t)n + 1);
     RK_HIP(ctx, hipMemcpyAsync(s->h_off.data(), off_dev, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     RK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (the offsets steer every kernel that walks the sketches: a table that is not a CSR table -- e.g. one whose producer on
+    // another stream had not finished when this call was made -- is refused here, not met as a memory fault later)
+    if (s->h_off[0] != 0) return rk_fail(ctx, RK_ERR_ARG, "rk_sketches_from_dev: off[0] must be 0");
+    for (uint32_t g = 0; g < n; g++)
+        if (s->h_off[g + 1] < s->h_off[g])
+            return rk_fail(ctx, RK_ERR_ARG, "rk_sketches_from_dev: offsets must be non-decreasing (genome %u; were the arrays complete when the call was made?)", g);
     s->total = s->h_off[n];
     if (!hashes_dev && s->total) return rk_fail(ctx, RK_ERR_ARG, "hashes_dev is NULL");
     RK_TRY(pool_array(ctx, &s->d_hashes, s->total + 1));

@@ -878,6 +878,21 @@ def test_edge_cases_empty_inputs(ctx):
     assert dense.tolist() == [[0, 3, 0]] and len(hits) == 1 and hits[0]["common"] == 3
 
 
+def test_device_sketches_with_a_broken_offset_table_are_refused(ctx):
+    """rk_sketches_from_dev: offsets that are no CSR table (what a caller gets who hands over arrays another stream is still
+    writing) are an argument error -- the kernels never walk them"""
+    h = torch.arange(64, dtype=torch.int32, device="cuda")
+    for bad in ([0, 40, 20, 64], [8, 16, 32, 64]):
+        off = torch.tensor(bad, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        with pytest.raises(capi.RkError):
+            ctx.sketches_from_dev(h.data_ptr(), off.data_ptr(), 3)
+    off = torch.tensor([0, 20, 40, 64], dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    sk = ctx.sketches_from_dev(h.data_ptr(), off.data_ptr(), 3)
+    assert sk.count == 3 and sk.total == 64
+
+
 # ------------------------------------------------------------------ sketching
 def sketch_case(ctx, k, s, l, genomes):
     """genomes: list of (seq uint8, rec_off) -> GPU CSR vs oracle sets"""
