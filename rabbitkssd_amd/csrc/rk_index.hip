@@ -352,17 +352,15 @@ template <class K> __device__ inline uint32_t fold_hash(K h)
     else return (uint32_t)h;
 }
 
-// table slot = (hash << 32 | smallest genome that lists the hash among its kMinK smallest); open addressing
-template <class K>
-__global__ void k_minhash_insert(const K *hashes, const uint64_t *off, uint32_t n_genomes, unsigned long long *table, uint32_t mask)
+// table slot = (hash << 32 | smallest genome that lists the hash among its kMinK smallest); open addressing.
+// (round 5) A workgroup holds 64 neighbouring genomes -- relatives, in a collection listed species by species -- and first settles
+// "the smallest genome per hash" among ITS 1,024 elements in an LDS table; only the winners go to the device-wide table.  Its loads
+// and atomics are device-scope round trips (~30 us per million, and whatever streams beside them waits: 0.55 ms at 500,000 genomes,
+// paid by every shard of a sharded build); among relatives an LDS table leaves a sixteenth of them.
+constexpr uint32_t kInsertThreads = 1024, kInsertLocal = 2048;
+__device__ inline void minhash_insert_global(unsigned long long *table, uint32_t mask, unsigned long long mine)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t g = (uint32_t)(t / kMinK), i = (uint32_t)(t % kMinK);
-    if (g >= n_genomes) return;
-    const uint64_t e = off[g] + i;
-    if (e >= off[g + 1]) return;
-    const uint32_t h = fold_hash(hashes[e]);
-    const unsigned long long mine = ((unsigned long long)h << 32) | g;
+    const uint32_t h = (uint32_t)(mine >> 32);
     uint32_t slot = mix32(h) & mask;
     for (uint32_t probe = 0; probe <= mask; probe++) {
         unsigned long long cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -371,12 +369,45 @@ __global__ void k_minhash_insert(const K *hashes, const uint64_t *off, uint32_t 
             if (cur == kEmptySlot) return;
         }
         if ((uint32_t)(cur >> 32) == h) {
-            // (the slot only ever decreases: a genome that finds a smaller one there has nothing to add -- in a species of 10,000
-            // strains all but the first few arrivals at a hash; their atomics queued on ONE address, 0.9 ms at 500,000 genomes)
+            // (the slot only ever decreases: a genome that finds a smaller one there has nothing to add)
             if (cur > mine) atomicMin(&table[slot], mine);
             return;
         }
         slot = (slot + 1) & mask;
+    }
+}
+template <class K>
+__global__ __launch_bounds__(kInsertThreads) void k_minhash_insert(const K *hashes, const uint64_t *off, uint32_t n_genomes, unsigned long long *table, uint32_t mask)
+{
+    __shared__ unsigned long long loc[kInsertLocal];   // (at most half full: 1,024 elements)
+    for (uint32_t s = threadIdx.x; s < kInsertLocal; s += kInsertThreads) loc[s] = kEmptySlot;
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * kInsertThreads + threadIdx.x;
+    const uint32_t g = (uint32_t)(t / kMinK), i = (uint32_t)(t % kMinK);
+    if (g < n_genomes) {
+        const uint64_t e = off[g] + i;
+        if (e < off[g + 1]) {
+            const uint32_t h = fold_hash(hashes[e]);
+            const unsigned long long mine = ((unsigned long long)h << 32) | g;
+            uint32_t slot = (mix32(h) >> 11) & (kInsertLocal - 1);   // (other bits than the device-wide table's)
+            for (uint32_t probe = 0; probe < kInsertLocal; probe++) {
+                unsigned long long cur = loc[slot];
+                if (cur == kEmptySlot) {
+                    cur = atomicCAS(&loc[slot], kEmptySlot, mine);
+                    if (cur == kEmptySlot) break;
+                }
+                if ((uint32_t)(cur >> 32) == h) {
+                    if (cur > mine) atomicMin(&loc[slot], mine);
+                    break;
+                }
+                slot = (slot + 1) & (kInsertLocal - 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < kInsertLocal; s += kInsertThreads) {
+        const unsigned long long v = loc[s];
+        if (v != kEmptySlot) minhash_insert_global(table, mask, v);
     }
 }
 
@@ -1018,12 +1049,12 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         RK_HIP(ctx, rl_table.alloc(slots));
         RK_HIP(ctx, rl_parent.alloc(N));
         RK_HIP(ctx, hipMemsetAsync(rl_table.p, 0xFF, (size_t)slots * 8, s2));
-        const unsigned nb_k = blocks_for((uint64_t)N * kMinK), nb_n = blocks_for(N);
+        const unsigned nb_ins = (unsigned)(((uint64_t)N * kMinK + kInsertThreads - 1) / kInsertThreads), nb_n = blocks_for(N);
         if (idx->wide) {
-            hipLaunchKernelGGL(k_minhash_insert<uint64_t>, dim3(nb_k), dim3(kThreads), 0, s2, s->d_hashes64, s->d_off, N, rl_table.p, slots - 1);
+            hipLaunchKernelGGL(k_minhash_insert<uint64_t>, dim3(nb_ins), dim3(kInsertThreads), 0, s2, s->d_hashes64, s->d_off, N, rl_table.p, slots - 1);
             hipLaunchKernelGGL(k_minhash_vote<uint64_t>, dim3(nb_n), dim3(kThreads), 0, s2, s->d_hashes64, s->d_off, N, rl_table.p, slots - 1, rl_parent.p);
         } else {
-            hipLaunchKernelGGL(k_minhash_insert<uint32_t>, dim3(nb_k), dim3(kThreads), 0, s2, s->d_hashes, s->d_off, N, rl_table.p, slots - 1);
+            hipLaunchKernelGGL(k_minhash_insert<uint32_t>, dim3(nb_ins), dim3(kInsertThreads), 0, s2, s->d_hashes, s->d_off, N, rl_table.p, slots - 1);
             hipLaunchKernelGGL(k_minhash_vote<uint32_t>, dim3(nb_n), dim3(kThreads), 0, s2, s->d_hashes, s->d_off, N, rl_table.p, slots - 1, rl_parent.p);
         }
         if (N <= kRankMaxN) {
@@ -1230,6 +1261,8 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
                 // (the filtered elements lie in `keys`: the coarse pass reads them and writes `mid`, the fine pass writes `keys` again)
                 if (wide) hipLaunchKernelGGL(k_range_filter<uint64_t>, dim3(fa.n_chunks * kFilterSplit), dim3(kFilterThreads), 0, st, fa, chunk_first.p, keys.p, n_filt, fres);
                 else hipLaunchKernelGGL(k_range_filter<uint32_t>, dim3(fa.n_chunks * kFilterSplit), dim3(kFilterThreads), 0, st, fa, chunk_first.p, keys.p, n_filt, fres);
+                // (tried: starting the renumbering BEHIND the filter -- then k_part_hist takes 0.84 ms instead of 0.16 beside
+                // k_minhash_insert: whatever runs beside that kernel pays its 0.55 ms)
                 pa.filtered = keys.p;
                 pa.n_filtered = n_filt;
                 pa.hash_bits = eff_bits;
