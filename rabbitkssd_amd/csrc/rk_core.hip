@@ -24,11 +24,69 @@ static size_t pool_round(size_t bytes)
     return (bytes + ((1u << 21) - 1)) & ~(size_t)((1u << 21) - 1);
 }
 
+// (ctx->mu held) a block back into the cache, or to the driver when the cache is full
+static void pool_put_locked(rk_ctx *ctx, void *p)
+{
+    auto it = ctx->live.find(p);
+    if (it == ctx->live.end()) {  // not from this pool
+        (void)hipFree(p);
+        return;
+    }
+    if (ctx->cached_bytes + it->second > ctx->cache_limit) {  // the cache is full: back to the driver
+        ctx->pool_bytes -= it->second;
+        ctx->live.erase(it);
+        ctx->driver_frees++;
+        (void)hipFree(p);
+        return;
+    }
+    ctx->cached_bytes += it->second;
+    ctx->free_blocks.emplace(it->second, p);
+}
+
+// (ctx->mu held) deferred blocks whose event has passed return to the cache; wait: all of them (the stream is synchronised first)
+static void pool_collect_locked(rk_ctx *ctx, bool wait)
+{
+    size_t kept = 0;
+    for (auto &d : ctx->deferred) {
+        const hipError_t e = wait ? hipEventSynchronize(d.second) : hipEventQuery(d.second);
+        if (e == hipSuccess || (wait && e != hipErrorNotReady)) {
+            pool_put_locked(ctx, d.first);
+            ctx->spare_events.push_back(d.second);
+        } else {
+            (void)hipGetLastError();   // (hipErrorNotReady is not an error here)
+            ctx->deferred[kept++] = d;
+        }
+    }
+    ctx->deferred.resize(kept);
+}
+
+void rk_pool_free_after(rk_ctx *ctx, void *p, hipStream_t st)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipEvent_t ev = nullptr;
+    if (!ctx->spare_events.empty()) {
+        ev = ctx->spare_events.back();
+        ctx->spare_events.pop_back();
+    } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+        ev = nullptr;
+    }
+    if (!ev || hipEventRecord(ev, st) != hipSuccess) {   // no event to be had: wait for the stream instead
+        (void)hipGetLastError();
+        if (ev) ctx->spare_events.push_back(ev);
+        (void)hipStreamSynchronize(st);
+        pool_put_locked(ctx, p);
+        return;
+    }
+    ctx->deferred.emplace_back(p, ev);
+}
+
 void *rk_pool_alloc(rk_ctx *ctx, size_t bytes)
 {
     const size_t want = pool_round(bytes ? bytes : 1);
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!ctx->deferred.empty()) pool_collect_locked(ctx, false);
         auto it = ctx->free_blocks.lower_bound(want);
         // best fit, but never hand a block far bigger than the request (it would be missing when its own size is asked for)
         if (it != ctx->free_blocks.end() && (it->first <= 2 * want || it->first <= (1u << 16))) {
@@ -58,20 +116,7 @@ void rk_pool_free(rk_ctx *ctx, void *p)
 {
     if (!p) return;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    auto it = ctx->live.find(p);
-    if (it == ctx->live.end()) {  // not from this pool
-        (void)hipFree(p);
-        return;
-    }
-    if (ctx->cached_bytes + it->second > ctx->cache_limit) {  // the cache is full: back to the driver
-        ctx->pool_bytes -= it->second;
-        ctx->live.erase(it);
-        ctx->driver_frees++;
-        (void)hipFree(p);
-        return;
-    }
-    ctx->cached_bytes += it->second;
-    ctx->free_blocks.emplace(it->second, p);
+    pool_put_locked(ctx, p);
 }
 
 void *rk_pinned_scratch(rk_ctx *ctx, size_t bytes)
@@ -289,6 +334,7 @@ void rk_ctx_trim(rk_ctx *ctx)
     if (!ctx) return;
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
+    if (!ctx->deferred.empty()) pool_collect_locked(ctx, true);
     for (auto &b : ctx->free_blocks) {
         ctx->live.erase(b.second);
         ctx->pool_bytes -= b.first;
@@ -312,6 +358,7 @@ void rk_ctx_destroy(rk_ctx *ctx)
         if (ctx->ev_inv) (void)hipEventDestroy(ctx->ev_inv);
     }
     rk_ctx_trim(ctx);
+    for (hipEvent_t e : ctx->spare_events) (void)hipEventDestroy(e);
     // blocks still handed out belong to objects the caller has not freed: they are released with the context
     for (auto &b : ctx->live) (void)hipFree(b.first);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -37,6 +37,10 @@ struct rk_ctx {
     size_t pool_bytes = 0;           // everything obtained from the driver
     size_t cached_bytes = 0;         // of which idle in free_blocks
     uint64_t driver_allocs = 0, driver_frees = 0;  // hipMalloc / hipFree calls made by the pool
+    // blocks whose last user is still running on some stream (rk_pool_free_after: the scratch of a rocprim call): they return to
+    // free_blocks once their event has passed -- looked at whenever the pool is asked for memory
+    std::vector<std::pair<void *, hipEvent_t>> deferred;
+    std::vector<hipEvent_t> spare_events;
     size_t cache_limit = 0;          // idle bytes above this go straight back to the driver (RK_POOL_LIMIT_MB, default 32 GiB)
     std::map<std::tuple<const void *, int, size_t>, int> occupancy;  // hipOccupancy... costs 10-70 us per query
     // optional HIP-event timing of the dominant kernel of a pass (rk_ctx_set_timing): [0] sketch kernel
@@ -76,6 +80,10 @@ constexpr size_t kPinnedBytes = 1 << 16;
 int rk_fail(rk_ctx *ctx, int code, const char *fmt, ...);
 void *rk_pool_alloc(rk_ctx *ctx, size_t bytes);  // nullptr when the device is out of memory
 void rk_pool_free(rk_ctx *ctx, void *p);
+// the block goes back to the pool once everything enqueued on `st` so far has run (an event): for temporaries of work that is still
+// in flight when the host function returns -- the pool itself is not stream-aware, and another host thread of the same context may
+// ask for memory in the meantime
+void rk_pool_free_after(rk_ctx *ctx, void *p, hipStream_t st);
 // device -> host copy of a few bytes through the pinned scratch (a pageable hipMemcpy costs 20-30 us more);
 // synchronises `stream`
 int rk_read_back(rk_ctx *ctx, void *dst, const void *src_dev, size_t bytes, hipStream_t stream);

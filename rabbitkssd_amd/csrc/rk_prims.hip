@@ -18,7 +18,7 @@
     } while (0)
 
 // two-phase rocprim call: size query, temporary from the context's pool, the call itself (enqueued on `st`; the temporary
-// goes back to the pool when the wrapper returns: callers synchronise `st` before they reuse pool memory on another stream)
+// goes back to the pool behind an event on `st`: rk_pool_free_after)
 #define RK_TWO_PHASE(EXPR)                                      \
     do {                                                        \
         size_t tb = 0;                                          \
@@ -28,6 +28,7 @@
         if (tmp.alloc(tb) != hipSuccess) return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %zu bytes of sort/scan scratch", tb); \
         tmp_p = tmp.p;                                          \
         RK_PRIM(EXPR);                                          \
+        rk_pool_free_after(ctx, tmp.release(), st);             \
     } while (0)
 
 int rk_prim_sort_keys_u64(rk_ctx *ctx, const unsigned long long *in, unsigned long long *out, uint64_t n, unsigned begin_bit, unsigned end_bit,
@@ -41,6 +42,7 @@ int rk_prim_sort_keys_u64(rk_ctx *ctx, const unsigned long long *in, unsigned lo
     if (tmp.alloc(tb) != hipSuccess) return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %zu bytes of sort scratch", tb);
     RK_PRIM(rocprim::radix_sort_keys(tmp.p, tb, in, out, (size_t)n, begin_bit, end_bit, st));
     if (tmp_keep) *tmp_keep = tmp.release();   // (the caller frees it once `st` is done: a stream other than the context's)
+    else rk_pool_free_after(ctx, tmp.release(), st);
     return RK_OK;
 }
 

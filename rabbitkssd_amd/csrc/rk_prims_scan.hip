@@ -19,7 +19,7 @@
     } while (0)
 
 // two-phase rocprim call: size query, temporary from the context's pool, the call itself (enqueued on `st`; the temporary
-// goes back to the pool when the wrapper returns: callers synchronise `st` before they reuse pool memory on another stream)
+// goes back to the pool behind an event on `st`: rk_pool_free_after)
 #define RK_TWO_PHASE(EXPR)                                      \
     do {                                                        \
         size_t tb = 0;                                          \
@@ -29,6 +29,7 @@
         if (tmp.alloc(tb) != hipSuccess) return rk_fail(ctx, RK_ERR_NOMEM, "cannot allocate %zu bytes of sort/scan scratch", tb); \
         tmp_p = tmp.p;                                          \
         RK_PRIM(EXPR);                                          \
+        rk_pool_free_after(ctx, tmp.release(), st);             \
     } while (0)
 
 int rk_prim_inclusive_scan_u32(rk_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t st)

@@ -158,6 +158,58 @@ def test_gpu_wide_index_fast_build_equals_general_build(monkeypatch):
     slow.close()
 
 
+@pytest.mark.gpu
+def test_gpu_wide_index_in_passes_and_in_shards(monkeypatch):
+    """36-bit hashes through the range passes of the bucket sort (k_range_filter<u64>: its hashes are read twice, not kept in
+    registers; 64-bit sort keys in the bucket emission) and through the sharded build + join: the same postings, distinct hashes
+    and hits as the oracle"""
+    import torch
+    names, h, off = synth.clade_sketches(3000, 300, 36, kmer_size=24, seed=15, wide=True)
+    order = synth.genome_order(len(names), "shuffled", seed=4)
+    names, h, off = synth.permute_genomes(names, h, off, order)
+    uhash, ucount, postings = ok.index_build64(h, off)
+    sizes = np.diff(off).astype(np.uint32)
+    want, _ = ok.index_dist64(uhash, ucount, postings, sizes, h, off, 1, 0, 24, 0.05)
+    assert len(want) > 3000
+    monkeypatch.setenv("RK_INDEX_PASS_BITS", "2")
+    c = capi.Context(0)
+    monkeypatch.delenv("RK_INDEX_PASS_BITS")
+    sk = c.sketches_from_host64(h, off)
+    idx = c.index_build(sk, 36)
+    assert idx.built_fast and idx.products == 6
+    p2, h2, c2 = idx.export64()
+    assert np.array_equal(p2, postings) and np.array_equal(h2, uhash) and np.array_equal(c2, ucount)
+
+    def same(mine):
+        assert len(mine) == len(want) and np.array_equal(mine["row"], want["row"]) and np.array_equal(mine["col"], want["col"])
+        assert np.array_equal(mine["common"], want["common"]) and np.array_equal(mine["dist"], want["dist"])
+    same(c.dist_rows(idx, None, 1, 0, 24, 0.05)[0])
+    del idx
+    c.close()
+    c = capi.Context(0)
+    sk = c.sketches_from_host64(h, off)
+    W = 4
+    parts = [c.index_build_shard(sk, 36, r, W) for r in range(W)]
+    assert sum(p.total for p in parts) == len(h)
+    sent = [p.shard_records(W) for p in parts]
+    bufs = []
+    for p, cnt in zip(parts, sent):
+        b = torch.empty(max(1, sum(cnt) * 12), dtype=torch.uint8, device="cuda")
+        p.shard_pack(b.data_ptr())
+        bufs.append(b)
+    torch.cuda.synchronize()
+    got = []
+    for d in range(W):
+        recv = torch.cat([bufs[r][12 * sum(sent[r][:d]): 12 * sum(sent[r][:d + 1])] for r in range(W)] + [torch.empty(1, dtype=torch.uint8, device="cuda")])
+        j = c.index_join_shard(parts[d], recv.data_ptr(), sum(sent[r][d] for r in range(W)))
+        got.append(c.dist_rows(j, None, 1, 0, 24, 0.05)[0])
+        del j
+    merged = np.concatenate(got)
+    same(merged[np.lexsort((merged["col"], merged["row"]))])
+    del parts
+    c.close()
+
+
 # ------------------------------------------------------------------ host tool on the 64-bit layout
 def _tool(args, cwd=None, check=True):
     import subprocess
