@@ -171,11 +171,11 @@ def test_gpu_wide_index_in_passes_and_in_shards(monkeypatch):
     sizes = np.diff(off).astype(np.uint32)
     want, _ = ok.index_dist64(uhash, ucount, postings, sizes, h, off, 1, 0, 24, 0.05)
     assert len(want) > 3000
-    monkeypatch.setenv("RK_INDEX_PASS_BITS", "2")
+    monkeypatch.setenv("RK_INDEX_PASS_BITS", "2")   # (read by the build itself)
     c = capi.Context(0)
-    monkeypatch.delenv("RK_INDEX_PASS_BITS")
     sk = c.sketches_from_host64(h, off)
     idx = c.index_build(sk, 36)
+    monkeypatch.delenv("RK_INDEX_PASS_BITS")
     assert idx.built_fast and idx.products == 6
     p2, h2, c2 = idx.export64()
     assert np.array_equal(p2, postings) and np.array_equal(h2, uhash) and np.array_equal(c2, ucount)
