@@ -1120,6 +1120,7 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
     DevBuf<uint3> t_rec(ctx);   // a shard's tile records, grouped by destination shard (they leave for the exchange unsorted)
     uint32_t t_region_cap = 0;
     uint64_t rec_cap_retry = 0;   // tile records the first attempt asked for, had they fit
+    uint64_t keys_cap_retry = 0;  // keys of the fullest range pass, had they fit (the ranges of a real hash space are not equally full)
     for (int attempt = 0; fast_ok && !built && attempt < 3; attempt++) {
         // (the tile records of an attempt did not fit their buffer -- wide species, lists scattered over many blocks --: the
         // attempt has counted what it needs, and the next one gets exactly that, within a budget of 6 records per posting; beyond
@@ -1158,7 +1159,9 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         fa.range_id = 0;
         // what a pass may hold: exactly H without ranges; with ranges an estimate + slack (a pass that exceeds it raises the overflow
         // flag in k_part_starts and the kernels behind it stand still)
-        const uint64_t keys_cap = fa.range_bits ? std::min<uint64_t>(H, H_pass + H_pass / 4 + (1u << 20)) : H;
+        // (RK_INDEX_KEYS_CAP_PCT: tests make the estimate too small)
+        const uint64_t keys_pct = getenv("RK_INDEX_KEYS_CAP_PCT") ? std::max(1, atoi(getenv("RK_INDEX_KEYS_CAP_PCT"))) : 125;
+        const uint64_t keys_cap = fa.range_bits ? std::min<uint64_t>(H, keys_cap_retry ? keys_cap_retry : H_pass * keys_pct / 100 + (keys_pct >= 100 ? (1u << 20) : 0)) : H;
         fa.keys_cap = keys_cap;
         fa.filtered = nullptr;
         fa.n_filtered = nullptr;
@@ -1462,6 +1465,19 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
         if (ctx->sw_dist_debug)
             fprintf(stderr, "[rk] index build: fast path flags %llu (B %d, low bits %d, genome bits %d, position bits %d; shard %u of %u, %u pass(es), %llu postings)%s\n",
                     r.flags, B, low_bits, gb, rb, shard_id, n_shards, passes, n_postings, tiles_mode ? (tr.overflow ? ", tile records overflowed" : ", tile records") : "");
+        if ((r.flags & kFastOverflow) && use_filter && !keys_cap_retry) {
+            // a range holds more keys than estimated: every pass's filter has counted what it needs -- once more with exactly that
+            std::vector<unsigned long long> asked(passes);
+            RK_TRY(rk_read_back(ctx, asked.data(), zeroed.p + z_filt, (size_t)passes * 8, st));
+            const unsigned long long need = *std::max_element(asked.begin(), asked.end());
+            if (need > keys_cap && need <= H) {
+                keys_cap_retry = need + need / 64 + 65536;
+                if (ctx->sw_dist_debug) fprintf(stderr, "[rk] index build: a range pass holds %llu keys (buffers for %llu): again\n", need, (unsigned long long)keys_cap);
+                memset(&tr, 0, sizeof tr);
+                attempt--;
+                continue;
+            }
+        }
         if (r.flags == 0 && !(tiles_mode && tr.overflow)) built = true;
         else if (r.flags) {   // a bucket beyond the LDS sort, a pass beyond its key buffer, or a hash outside the hash space: the general path decides
             fast_refused = true;

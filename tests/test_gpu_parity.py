@@ -571,6 +571,31 @@ def test_index_build_in_several_passes_over_the_hash_space(monkeypatch, pass_bit
     c.close()
 
 
+def test_a_range_with_more_keys_than_estimated_is_built_again(monkeypatch):
+    # the ranges of a real hash space are not equally full (the hashes are pieces of k-mers: base composition shows in their top
+    # bits); a range pass -- of a one-GPU build or a shard -- whose keys exceed the estimated buffers has counted what it needs and
+    # is repeated with that, instead of refusing the collection (a shard) or taking the device-wide sort (one GPU)
+    names, h, off = synth.clade_sketches(3000, 400, 26, strains_per_clade=36, seed=77)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, 0, 20, 0.05, threads=4)
+    monkeypatch.setenv("RK_INDEX_KEYS_CAP_PCT", "60")   # (buffers for 60 % of a range's expected keys)
+    monkeypatch.setenv("RK_INDEX_PASS_BITS", "2")
+    c = capi.Context(0)
+    sk = c.sketches_from_host(h, off)
+    idx = c.index_build(sk, 26)
+    assert idx.built_fast and idx.products == 6 and idx.total == len(h)
+    p2, c2 = idx.export()
+    assert np.array_equal(p2, postings) and np.array_equal(c2, counts)
+    assert_hits_equal(c.dist_rows(idx, None, 1, 0, 20, 0.05)[0], want)
+    monkeypatch.delenv("RK_INDEX_PASS_BITS")
+    parts = [c.index_build_shard(sk, 26, r, 4) for r in range(4)]
+    assert sum(p.total for p in parts) == len(h)
+    assert np.array_equal(np.concatenate([p.export(want_counts=False)[0][: p.total] for p in parts]), postings)
+    del idx, parts
+    c.close()
+
+
 @pytest.mark.parametrize("bits,n,m,strains", [(26, 6000, 150, 3000), (20, 5000, 250, 2500), (24, 4500, 400, 1500)])
 def test_buckets_beyond_the_lds_sort(monkeypatch, bits, n, m, strains):
     # a hash shared by thousands of genomes (a species of 1,500 - 3,000 strains) is a posting list that overflows a bucket of the
