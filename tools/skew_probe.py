@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer probe: rk_index_build over a collection whose hashes crowd the low end of the hash space (h -> 2^bits (h / 2^bits)^p:
 the fullest buckets of the bucket sort hold several times the mean) -- real sketches are pieces of k-mers, not uniform values.
-    python3 tools/skew_probe.py [n_genomes] [power x 10]"""
+    python3 tools/skew_probe.py [n_genomes] [power x 10; 0 / 1: quarters of the hash space filled 7 : 5 : 3 : 1, on one / two levels]"""
 import os
 import sys
 import time
@@ -17,7 +17,18 @@ def main(n=10000, p10=15):
     bits = 28
     names, h, off = synth.clade_sketches(n, 1220, bits)
     p = p10 / 10.0
-    hs = np.minimum((1 << bits) - 1, np.floor((h.astype(np.float64) / (1 << bits)) ** p * (1 << bits))).astype(np.uint32)
+    x = h.astype(np.float64) / (1 << bits)
+    if p10 in (0, 1):   # the canonical k-mer's leading base: quarters of the hash space filled 7 : 5 : 3 : 1 (0), and once more inside every quarter (1)
+        cum = np.array([0.0, 7.0, 12.0, 15.0, 16.0]) / 16.0
+
+        def quarters(u):   # u in [0, 1) uniform -> position in [0, 1) with the quarters filled 7 : 5 : 3 : 1
+            q = np.minimum(3, np.searchsorted(cum, u, side="right") - 1)
+            return (q + (u - cum[q]) / (cum[q + 1] - cum[q])) / 4.0
+        y = quarters(x)
+        if p10 == 1:
+            y = (np.floor(y * 4.0) + quarters((y * 4.0) % 1.0)) / 4.0
+        x, p = y, 1.0
+    hs = np.minimum((1 << bits) - 1, np.floor(x ** p * (1 << bits))).astype(np.uint32)
     # per genome: sorted already (monotone map); drop the repeats the map creates
     gid = np.repeat(np.arange(n, dtype=np.int64), np.diff(off).astype(np.int64))
     key = (gid << bits) | hs
