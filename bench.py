@@ -354,10 +354,11 @@ def threshold_legs(env, index, n_pairs, steps=20):
     return out
 
 
-def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted", build_reps=0, strains=10, tiny=0):
+def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted", build_reps=0, strains=10, tiny=0, skew=0):
     """alldist over n_genomes synthetic sketches, this rank's block-cyclic row shard; rank 0 returns the report.
     order_mode: the order the collection is listed in ("sorted" as generated, "shuffled", "jitter": synth.genome_order);
-    strains: genomes per clade (> 10: a species tree, synth.strain_rates); tiny: extra 40-hash sketches"""
+    strains: genomes per clade (> 10: a species tree, synth.strain_rates); tiny: extra 40-hash sketches; skew: the hashes fill the
+    hash space as a canonical k-mer's leading bases do (synth.canonical_skew, levels = skew)"""
     from rabbitkssd_amd import capi, shard, synth
     torch, ctx, rank, world = env.torch, env.ctx, env.rank, env.world
     n_pairs = n_genomes * (n_genomes - 1) // 2
@@ -370,6 +371,8 @@ def alldist_block(env, n_genomes, steps, warmup, keep=None, order_mode="sorted",
                                                   tiny=tiny)
         n_genomes = len(names)
         n_pairs = n_genomes * (n_genomes - 1) // 2
+        if skew:
+            hashes, off = synth.canonical_skew(hashes, off, HASH_BITS, levels=skew)
         if order_mode != "sorted":
             order = synth.genome_order(n_genomes, order_mode)
             names, hashes, off = synth.permute_genomes(names, hashes, off, order)
@@ -1149,12 +1152,12 @@ def reference_alldist_pairs(names, hashes, off):
         return float(m.group(1)), wall, np.stack([lo[key], hi[key], cm[key]])
 
 
-def alldist_variant(env, head, n_genomes, steps, strains, tiny, what):
+def alldist_variant(env, head, n_genomes, steps, strains, tiny, what, skew=0):
     """the headline workload on a collection that does NOT look like the clade-of-ten generator: species of 100 / 1,000
     strains, a 40-hash sketch among the bacteria.  Kernel time, pairs per second against the headline's, and whether the
     reported pairs and counts are the reference's."""
     k = {}
-    b = alldist_block(env, n_genomes, steps, 3, k, strains=strains, tiny=tiny, build_reps=5)
+    b = alldist_block(env, n_genomes, steps, 3, k, strains=strains, tiny=tiny, build_reps=5, skew=skew)
     if env.rank != 0:
         return None
     res = {"workload": what, "genomes": b["genomes"], "pairs": b["pairs"], "hits": b["hits"], "kernel": b["kernel"],
@@ -1357,6 +1360,11 @@ def main():
             "clade1000": alldist_variant(env, head, n_genomes, vs, 1000, 0, "alldist over %d sketches in species of 1,000 strains (10 lineages "
                                          "of 100: pairs across lineages share ~28 %% of their hashes and are NOT within -D %g)" % (n_genomes, MAX_DIST)),
             "tiny": alldist_variant(env, head, n_genomes, vs, 10, 1, "the headline collection plus one 40-hash sketch (a plasmid)"),
+            "canonical_skew": alldist_variant(env, head, n_genomes, vs, 10, 0, "the headline collection with its hashes spread as a real sketcher's are: "
+                                              "the quarters of the hash space filled 7 : 5 : 3 : 1 (the leading base of a canonical k-mer; the bucket "
+                                              "sort's buckets are equal ranges of the hash space, DESIGN.md 8)", skew=1),
+            "canonical_skew2": alldist_variant(env, head, n_genomes, vs, 10, 0, "the same with the 7 : 5 : 3 : 1 once more inside every quarter (fullest "
+                                               "bucket 3.06x the mean: beyond the 2.67x the LDS sort holds -- k_bucket_heavy)", skew=2),
         }
     sharded_head = sharded_block(env, keep.get("hashes"), keep.get("off"), HASH_BITS) if world > 1 else None
     legs = None
