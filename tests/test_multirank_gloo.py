@@ -69,6 +69,21 @@ def test_two_rank_row_sharding_gloo(tmp_path):
     assert int(open(tmp_path / "ok").read()) > 0
 
 
+def test_canonical_skew_keeps_sketches_sets_and_fills_the_quarters_7_5_3_1():
+    # the synthetic collections are uniform; synth.canonical_skew spreads their hashes as a sketcher's are (bench.py: alldist_variants)
+    names, h, off = synth.clade_sketches(400, 300, 28, seed=5)
+    for levels in (1, 2):
+        hs, off2 = synth.canonical_skew(h, off, 28, levels=levels)
+        assert len(off2) == len(off) and int(off2[-1]) == len(hs) <= len(h) and len(hs) > 0.99 * len(h)
+        for g in range(len(names)):
+            a = hs[int(off2[g]):int(off2[g + 1])]
+            assert np.all(a[1:] > a[:-1])
+        share = np.bincount(hs >> 26, minlength=4) / len(hs)
+        assert np.allclose(share, np.array([7, 5, 3, 1]) / 16.0, atol=0.01)
+    share16 = np.bincount(hs >> 24, minlength=16) / len(hs)
+    assert abs(share16[0] - 49 / 256) < 0.01 and abs(share16[15] - 1 / 256) < 0.003
+
+
 def test_partition_arithmetic():
     for n in (1, 2, 7, 100, 10000):
         for world in (1, 2, 4, 8):
