@@ -571,6 +571,29 @@ def test_index_build_in_several_passes_over_the_hash_space(monkeypatch, pass_bit
     c.close()
 
 
+def test_hashes_that_crowd_one_end_of_the_hash_space(monkeypatch):
+    # a real sketch's hashes are pieces of canonical k-mers: the quarter of the hash space that starts with A is seven times as full
+    # as the one that starts with T (synth.canonical_skew; twice over here: the fullest buckets hold 3x the mean and leave the LDS
+    # sort for k_bucket_heavy although no list is long) -- same .dict / .index and hits as the oracle, tile records from the build
+    names, h, off = synth.clade_sketches(6000, 500, 26, seed=41)
+    h, off = synth.canonical_skew(h, off, 26, levels=2)
+    postings, counts = ok.index_build32(h, off, 26)
+    sizes = np.diff(off).astype(np.uint32)
+    top = np.bincount(h >> (26 - 11), minlength=1 << 11)
+    assert top.max() > 4096 and counts.max() < 200          # (buckets beyond the LDS sort, and not because of a long list)
+    monkeypatch.setenv("RK_INDEX_TILES", "1")
+    c = capi.Context(0)
+    idx = c.index_build(c.sketches_from_host(h, off), 26)
+    assert idx.built_fast and idx.products == 6
+    p2, c2 = idx.export()
+    assert np.array_equal(p2, postings) and np.array_equal(c2, counts)
+    for metric, D in ((0, 0.05), (1, 0.05), (0, 1.0)):
+        want, _ = ok.index_dist32(counts, 26, postings, sizes, h, off, 1, metric, 20, D, threads=8)
+        assert_hits_equal(c.dist_rows(idx, None, 1, metric, 20, D)[0], want)
+    del idx
+    c.close()
+
+
 def test_a_range_with_more_keys_than_estimated_is_built_again(monkeypatch):
     # the ranges of a real hash space are not equally full (the hashes are pieces of k-mers: base composition shows in their top
     # bits); a range pass -- of a one-GPU build or a shard -- whose keys exceed the estimated buffers has counted what it needs and
