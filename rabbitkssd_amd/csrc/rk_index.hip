@@ -1213,8 +1213,10 @@ static int index_build_impl(rk_ctx *ctx, const rk_sketches *s, int hash_bits, ui
             RK_HIP(ctx, proto.alloc(2 * tile_cap));
             RK_HIP(ctx, level_start.alloc(2 * (kTileTable + 1)));
             RK_HIP(ctx, t_contrib.alloc(slot_cap + 256));
-            RK_HIP(ctx, t_rows.alloc(slot_cap + 256));
-            RK_HIP(ctx, t_cols.alloc(slot_cap + 256));
+            if (rowsort_stage(n_blocks)) {   // (the split copy serves the scalar-row variant of the tile kernel: short launches over small collections)
+                RK_HIP(ctx, t_rows.alloc(slot_cap + 256));
+                RK_HIP(ctx, t_cols.alloc(slot_cap + 256));
+            }
             RK_HIP(ctx, t_dir_j.alloc(2 * tile_cap));
             RK_HIP(ctx, t_dir_c.alloc(2 * tile_cap));
         }
@@ -1814,8 +1816,10 @@ int rk_index_join_shard(rk_ctx *ctx, const rk_index *part, const void *recv_dev,
     RK_HIP(ctx, proto.alloc(2 * tile_cap));
     RK_HIP(ctx, level_start.alloc(2 * (kTileTable + 1)));
     RK_HIP(ctx, t_contrib.alloc(slot_cap + 256));
-    RK_HIP(ctx, t_rows.alloc(slot_cap + 256));
-    RK_HIP(ctx, t_cols.alloc(slot_cap + 256));
+    if (rowsort_stage(n_blocks)) {
+        RK_HIP(ctx, t_rows.alloc(slot_cap + 256));
+        RK_HIP(ctx, t_cols.alloc(slot_cap + 256));
+    }
     RK_HIP(ctx, t_dir_j.alloc(2 * tile_cap));
     RK_HIP(ctx, t_dir_c.alloc(2 * tile_cap));
     const size_t z_tres = 0, z_tcur = z_tres + (sizeof(TileResult) + 7) / 8, z_bins = z_tcur + (sizeof(TileCursors) + 7) / 8, z_end = z_bins + (size_t)n_blocks + 1;
